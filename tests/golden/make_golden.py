@@ -1,0 +1,357 @@
+"""Generate the golden fixtures in this directory BY RUNNING THE REFERENCE.
+
+Run once in the build container (where /root/reference is mounted read-only):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+It imports the reference's own functions (recipe: SURVEY.md §8c, _ref_import.py) and
+the third-party executors it drives (transformers Llama / Qwen2AudioEncoder, flex
+mask builder), feeds them seeded synthetic inputs and stores inputs + outputs as
+small .npz files.  The fixtures are DATA ONLY; no reference source is stored.
+The GPU box never runs this script (no /root/reference there).
+"""
+import os
+import sys
+import types
+import wave
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import _ref_import as R  # noqa: E402
+
+R.install()
+
+from touchnet.data import functions as ref_fn  # noqa: E402
+from touchnet.loss.cross_entropy import cross_entropy_loss as ref_ce  # noqa: E402
+from touchnet.models.llama.processing_llama import batch_text as ref_batch_text  # noqa: E402
+from touchnet.models.touch_audio.processing_touch_audio import \
+    batch_pairaudio_pairtext_packed as ref_batch_asr  # noqa: E402
+
+TOK = types.SimpleNamespace(bos=1, eos=2, pad=0)
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrs)
+    print(f"wrote {name}: {os.path.getsize(path)} bytes")
+
+
+def npy(t):
+    return t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+
+
+# ------------------------------------------------------------------ packers
+def text_cases():
+    rng = np.random.RandomState(2025)
+    cases = {}
+    # (name, B, T, drop_last, lengths)
+    cases["overflow"] = (3, 16, False, [int(x) for x in rng.randint(1, 9, size=40)])
+    cases["exactfit"] = (2, 8, False, [3, 3, 7, 1, 5, 7, 7])          # 4+4 | 8 | 2+6 | 8 8
+    cases["droplast"] = (2, 12, True, [int(x) for x in rng.randint(1, 11, size=17)])
+    cases["single"] = (4, 64, False, [int(x) for x in rng.randint(1, 13, size=9)])
+    out = {}
+    for name, (B, T, drop, lens) in cases.items():
+        sents = [[int(v) for v in rng.randint(3, 16, size=n)] for n in lens]
+        cfg = types.SimpleNamespace(dataset_batchsize=B, dataset_text_seqlen=T,
+                                    dataloader_drop_last_batch=drop)
+        batches = list(ref_batch_text(({"input_ids": s} for s in sents), cfg, TOK))
+        out[f"{name}/meta"] = np.array([B, T, int(drop), len(batches)])
+        out[f"{name}/lens"] = np.array(lens)
+        out[f"{name}/tokens"] = np.concatenate([np.array(s) for s in sents])
+        for i, b in enumerate(batches):
+            for k in ("input_ids", "labels", "position_ids", "attention_mask", "sentence_lens"):
+                out[f"{name}/b{i}/{k}"] = npy(b[k])
+            out[f"{name}/b{i}/num_sentence"] = np.array(b["num_sentence"])
+    save("packing_text.npz", **out)
+
+
+def asr_cases():
+    rng = np.random.RandomState(7)
+    F = 6
+    out = {}
+    for name, (B, T, drop, n) in {"mixed": (2, 24, False, 14), "droplast": (2, 20, True, 9)}.items():
+        alens = [int(x) for x in rng.randint(2, 14, size=n)]
+        tlens = [int(x) for x in rng.randint(1, 7, size=n)]
+        alens[3] = 30  # too long for any row -> dropped (processing_touch_audio.py:169-170)
+        feats = [rng.randn(a, F).astype(np.float32) for a in alens]
+        ids = [[int(v) for v in rng.randint(3, 16, size=t)] for t in tlens]
+        cfg = types.SimpleNamespace(dataset_batchsize=B, dataset_text_seqlen=T, dataset_audio_seqlen=T,
+                                    audiofeat_num_mel_bins=F, audiofeat_stack_length=1,
+                                    dataloader_drop_last_batch=drop)
+        data = ({"audiofeat": torch.from_numpy(f), "input_ids": i} for f, i in zip(feats, ids))
+        batches = list(ref_batch_asr(data, cfg, TOK))
+        out[f"{name}/meta"] = np.array([B, T, int(drop), len(batches), F])
+        out[f"{name}/alens"] = np.array(alens)
+        out[f"{name}/tlens"] = np.array(tlens)
+        out[f"{name}/feats"] = np.concatenate(feats, axis=0)
+        out[f"{name}/tokens"] = np.concatenate([np.array(s) for s in ids])
+        for i, b in enumerate(batches):
+            for k in ("input_ids", "labels", "position_ids", "attention_mask", "sentence_lens",
+                      "input_features", "shift_labels"):
+                out[f"{name}/b{i}/{k}"] = npy(b[k])
+            out[f"{name}/b{i}/num_sentence"] = np.array(b["num_sentence"])
+    save("packing_asr.npz", **out)
+
+
+# ------------------------------------------------------------------ loss
+def ce_cases():
+    out = {}
+    # (1) the literal label vectors of tests/touchnet/utils/test_pack_loss.py:135-161, packed
+    b1 = [-100, -100, 1, 2, 3]
+    b2 = [4, -100, 3, 4, 6, -100, -100, 7]
+    b3 = [-100, 6, 8]
+    b4 = [-100, 7, 8, -100]
+    b5 = [-100, -100, 7, 4, 2, 5]
+    b6 = [5, 8, -100]
+    order = [b1, b2, b3, b2, b6, b4, b5, b6]
+    labels = torch.tensor(sum(order, []), dtype=torch.int64)[None]            # [1, 40]
+    # per-sentence normaliser = number of valid labels (what the test divides by);
+    # the packers would use len+1, the loss only sees a tensor
+    sl = torch.tensor(sum([[sum(1 for v in s if v != -100)] * len(s) for s in order], []))[None]
+    torch.manual_seed(0)
+    logits = torch.randn(1, 40, 9, requires_grad=True)
+    ps, pt = ref_ce(logits, labels, sl, 8)
+    ps.backward()
+    out.update({"pack/logits": npy(logits), "pack/labels": npy(labels), "pack/sentence_lens": npy(sl),
+                "pack/num_sentence": np.array(8), "pack/loss_per_sample": npy(ps),
+                "pack/loss_per_token": npy(pt), "pack/dlogits": npy(logits.grad)})
+    # batch-split value of the same data (test_pack_loss.py:10-50) for the equivalence check
+    # (2) mixed B=2,T=16,V=16 with packer-style sentence_lens and a bf16 copy
+    torch.manual_seed(1)
+    logits = (torch.randn(2, 16, 16) * 3).requires_grad_()
+    labels = torch.randint(0, 16, (2, 16))
+    labels[0, :3] = -100
+    labels[1, 5:9] = -100
+    labels[1, 15] = -100
+    sl = torch.tensor([[4] * 4 + [7] * 7 + [5] * 5, [9] * 9 + [6] * 6 + [1]])
+    ps, pt = ref_ce(logits, labels, sl, 11)
+    ps.backward()
+    out.update({"mixed/logits": npy(logits), "mixed/labels": npy(labels), "mixed/sentence_lens": npy(sl),
+                "mixed/num_sentence": np.array(11), "mixed/loss_per_sample": npy(ps),
+                "mixed/loss_per_token": npy(pt), "mixed/dlogits": npy(logits.grad)})
+    # (3) nothing valid -> per-token 0 branch (cross_entropy.py:41-44)
+    logits = torch.randn(1, 4, 5)
+    labels = torch.full((1, 4), -100)
+    ps, pt = ref_ce(logits, labels, torch.ones(1, 4, dtype=torch.int64), 1)
+    out.update({"empty/logits": npy(logits), "empty/loss_per_sample": npy(ps), "empty/loss_per_token": npy(pt)})
+    save("ce_loss.npz", **out)
+
+
+# ------------------------------------------------------------------ doc mask
+def docmask_cases():
+    from transformers.integrations.flex_attention import make_flex_block_causal_mask
+    docs = torch.tensor([[1, 1, 1, 2, 2, 2, 0], [1, 1, 2, 2, 2, 3, 3]])          # processing_llama.py:38-40
+    rng = np.random.RandomState(3)
+    big = []
+    for _ in range(2):
+        row, d = [], 1
+        while len(row) < 150:
+            row += [d] * int(rng.randint(1, 40))
+            d += 1
+        row = row[:150]
+        row[140:] = [0] * 10
+        big.append(row)
+    out = {}
+    for name, ids in {"small": docs, "big": torch.tensor(big)}.items():
+        bm = make_flex_block_causal_mask(ids)
+        B, T = ids.shape
+        q = torch.arange(T)
+        allow = torch.zeros(B, T, T, dtype=torch.bool)
+        for b in range(B):
+            for i in range(T):
+                allow[b, i] = bm.mask_mod(torch.tensor(b), torch.tensor(0), torch.tensor(i), q)
+        out[f"{name}/doc_ids"] = npy(ids)
+        out[f"{name}/allow"] = npy(allow)
+    save("docmask.npz", **out)
+
+
+# ------------------------------------------------------------------ rope
+def rope_cases():
+    from transformers import LlamaConfig
+    from transformers.models.llama.modeling_llama import LlamaRotaryEmbedding
+    out = {}
+    for name, path in {"tiny": "tests/assets/config/tiny_llama.json",
+                       "llama1b": "examples/text/pretrain/fineweb-edu/config/Llama-3_2-1B.json"}.items():
+        cfg = LlamaConfig.from_json_file(f"{R.REF}/{path}")
+        rot = LlamaRotaryEmbedding(cfg)
+        # models/llama/__init__.py:23-27 re-derives inv_freq through `rope_init_fn`; transformers 5.x
+        # (installed here) dropped that attribute and computes the same table in __init__.
+        inv, scal = rot.inv_freq.clone(), rot.attention_scaling
+        pos = torch.tensor([list(range(5)) + list(range(9)) + list(range(3)) + [0] * 3])
+        cos, sin = rot(torch.zeros(1, 20, 4), pos)
+        out[f"{name}/inv_freq"] = npy(inv)
+        out[f"{name}/attention_scaling"] = np.array(scal)
+        out[f"{name}/position_ids"] = npy(pos)
+        out[f"{name}/cos"] = npy(cos)
+        out[f"{name}/sin"] = npy(sin)
+    save("rope.npz", **out)
+
+
+# ------------------------------------------------------------------ tiny Llama / TouchAudio
+def _allow4d(doc):
+    T = doc.shape[1]
+    q = torch.arange(T)
+    allow = (q[:, None] >= q[None, :])[None] & (doc[:, :, None] > 0) & (doc[:, :, None] == doc[:, None, :])
+    return torch.zeros(doc.shape[0], 1, T, T).masked_fill(~allow[:, None], torch.finfo(torch.float32).min)
+
+
+def tiny_llama_case():
+    from transformers import LlamaConfig, LlamaForCausalLM
+    cfg = LlamaConfig.from_json_file(f"{R.REF}/tests/assets/config/tiny_llama.json")
+    cfg._attn_implementation = "eager"
+    torch.manual_seed(0)
+    model = LlamaForCausalLM(cfg).float()
+    # reference post_init (models/llama/__init__.py:19-36) = re-derive inv_freq + ones_ on norm weights;
+    # both are what HF's own init already produced here (its `rope_init_fn` hook is gone in 5.x).
+    rng = np.random.RandomState(11)
+    sents = [[int(v) for v in rng.randint(3, 16, size=int(n))] for n in rng.randint(1, 13, size=14)]
+    dcfg = types.SimpleNamespace(dataset_batchsize=4, dataset_text_seqlen=32, dataloader_drop_last_batch=False)
+    batch = next(iter(ref_batch_text(({"input_ids": s} for s in sents), dcfg, TOK)))
+    out = model(input_ids=batch["input_ids"], attention_mask=_allow4d(batch["attention_mask"]),
+                position_ids=batch["position_ids"])
+    ps, pt = ref_ce(out.logits, batch["labels"], batch["sentence_lens"], batch["num_sentence"])
+    ps.backward()
+    arrs = {f"param/{n}": npy(p) for n, p in model.named_parameters()}
+    arrs.update({f"grad/{n}": npy(p.grad) for n, p in model.named_parameters()})
+    for k in ("input_ids", "labels", "position_ids", "attention_mask", "sentence_lens"):
+        arrs[f"batch/{k}"] = npy(batch[k])
+    arrs["batch/num_sentence"] = np.array(batch["num_sentence"])
+    arrs["logits"] = npy(out.logits)
+    arrs["loss_per_sample"] = npy(ps)
+    arrs["loss_per_token"] = npy(pt)
+    save("tiny_llama.npz", **arrs)
+
+
+def touch_audio_case():
+    from transformers import LlamaConfig
+    from touchnet.models.touch_audio.configuration_touch_audio import TouchAudioConfig
+    from touchnet.models.touch_audio.modeling_touch_audio import TouchAudioForCausalLM
+    tcfg = LlamaConfig.from_json_file(f"{R.REF}/tests/assets/config/tiny_llama.json").to_dict()
+    F = 21
+    cfg = TouchAudioConfig(text_config=tcfg, audio_config={"model_type": "touch_audio_projector", "input_size": F},
+                           pad_token_id=0)
+    cfg._attn_implementation = "eager"
+    cfg.text_config._attn_implementation = "eager"
+    torch.manual_seed(3)
+    model = TouchAudioForCausalLM(cfg).float()
+    rng = np.random.RandomState(5)
+    n = 9
+    feats = [rng.randn(int(a), F).astype(np.float32) for a in rng.randint(2, 12, size=n)]
+    ids = [[int(v) for v in rng.randint(3, 16, size=int(t))] for t in rng.randint(1, 6, size=n)]
+    dcfg = types.SimpleNamespace(dataset_batchsize=2, dataset_text_seqlen=48, dataset_audio_seqlen=48,
+                                 audiofeat_num_mel_bins=F, audiofeat_stack_length=1,
+                                 dataloader_drop_last_batch=False)
+    data = ({"audiofeat": torch.from_numpy(f), "input_ids": i} for f, i in zip(feats, ids))
+    batch = next(iter(ref_batch_asr(data, dcfg, TOK)))
+    out = model(input_ids=batch["input_ids"], input_features=batch["input_features"],
+                attention_mask=_allow4d(batch["attention_mask"]), position_ids=batch["position_ids"])
+    ps, pt = ref_ce(out.logits, batch["labels"], batch["sentence_lens"], batch["num_sentence"])
+    ps.backward()
+    arrs = {f"param/{n}": npy(p) for n, p in model.named_parameters()}
+    arrs.update({f"grad/{n}": npy(p.grad) for n, p in model.named_parameters()})
+    for k in ("input_ids", "labels", "position_ids", "attention_mask", "sentence_lens", "input_features"):
+        arrs[f"batch/{k}"] = npy(batch[k])
+    arrs["batch/num_sentence"] = np.array(batch["num_sentence"])
+    arrs["logits"] = npy(out.logits)
+    arrs["loss_per_sample"] = npy(ps)
+    arrs["loss_per_token"] = npy(pt)
+    save("touch_audio.npz", **arrs)
+
+
+# ------------------------------------------------------------------ Qwen2-Audio tower
+def qwen2_audio_tower_case():
+    from transformers.models.qwen2_audio.configuration_qwen2_audio import Qwen2AudioEncoderConfig
+    from transformers.models.qwen2_audio.modeling_qwen2_audio import Qwen2AudioEncoder
+    ref = R.load_file_as("ref_qwen2_audio_init", "touchnet/models/qwen2_audio/__init__.py")
+    acfg = Qwen2AudioEncoderConfig(num_mel_bins=8, encoder_layers=2, encoder_attention_heads=4,
+                                   encoder_ffn_dim=64, d_model=32, max_source_positions=10,
+                                   dropout=0.0, attention_dropout=0.0, activation_dropout=0.0)
+    acfg._attn_implementation = "sdpa"
+    torch.manual_seed(4)
+    tower = Qwen2AudioEncoder(acfg).float().eval()
+    with torch.no_grad():
+        tower.embed_positions.weight.copy_(torch.randn_like(tower.embed_positions.weight) * 0.1)
+    for layer in tower.layers:                       # qwen2_audio/__init__.py:191-192
+        layer.self_attn.is_causal = True
+
+    class AsTuple(torch.nn.Module):                  # 4.51.3 layers return a tuple, 5.x a tensor
+        def __init__(self, inner):
+            super().__init__()
+            self.inner = inner
+
+        def forward(self, h, mask=None, **kw):
+            return (self.inner(h, mask),)
+    tower.layers = torch.nn.ModuleList([AsTuple(l) for l in tower.layers])
+    mel = torch.randn(2, 8, 52)                      # 52 -> 26 frames > 10 positions: exercises tiling
+    out = ref.forward_audio_tower(tower, mel).last_hidden_state
+    arrs = {f"param/{n.replace('.inner', '')}": npy(p) for n, p in tower.named_parameters()}
+    arrs["embed_positions"] = npy(tower.embed_positions.weight)
+    arrs["mel"] = npy(mel)
+    arrs["out"] = npy(out)
+    arrs["cfg"] = np.array([8, 2, 4, 64, 32, 10])
+    save("qwen2_audio_tower.npz", **arrs)
+
+
+# ------------------------------------------------------------------ frontend
+def read_wav(path):
+    with wave.open(path, "rb") as w:
+        assert w.getsampwidth() == 2 and w.getnchannels() == 1
+        sr = w.getframerate()
+        pcm = np.frombuffer(w.readframes(w.getnframes()), dtype=np.int16)
+    return pcm, sr
+
+
+def frontend_cases():
+    import librosa  # MagicMock; give it the slaney filter the way SURVEY.md §8c does
+    from transformers.audio_utils import mel_filter_bank
+
+    def fake_mel(sr, n_fft, n_mels):
+        return mel_filter_bank(num_frequency_bins=1 + n_fft // 2, num_mel_filters=n_mels, min_frequency=0.0,
+                               max_frequency=sr / 2.0, sampling_rate=sr, norm="slaney",
+                               mel_scale="slaney").T.astype(np.float32)
+    librosa.filters.mel = fake_mel
+    out = {}
+    # stack
+    cases = {"arange": (np.arange(60, dtype=np.float32).reshape(20, 3), 7, 6)}
+    rng = np.random.RandomState(9)
+    for T in (1, 5, 6, 7, 13, 100):
+        cases[f"r{T}_7_6"] = (rng.randn(T, 80).astype(np.float32), 7, 6)
+    for T in (4, 9, 33, 257):
+        cases[f"r{T}_5_4"] = (rng.randn(T, 80).astype(np.float32), 5, 4)
+    cases["r50_4_4"] = (rng.randn(50, 16).astype(np.float32), 4, 4)
+    cases["r31_1_1"] = (rng.randn(31, 16).astype(np.float32), 1, 1)
+    for name, (x, stack, stride) in cases.items():
+        cfg = types.SimpleNamespace(audiofeat_stack_length=stack, audiofeat_stride_length=stride,
+                                    audiofeat_normalize=True)
+        y = next(iter(ref_fn.audiofeat_stack(iter([{"audiofeat": torch.from_numpy(x)}]), cfg)))["audiofeat"]
+        out[f"stack/{name}/x"] = x
+        out[f"stack/{name}/y"] = npy(y)
+        out[f"stack/{name}/ss"] = np.array([stack, stride])
+    save("audiofeat_stack.npz", **out)
+
+    out = {}
+    wavdir = f"{R.REF}/tests/assets/dataset"
+    for i, fn in enumerate(sorted(f for f in os.listdir(wavdir) if f.endswith(".wav"))):
+        pcm, sr = read_wav(os.path.join(wavdir, fn))
+        wav = torch.from_numpy(pcm.astype(np.float32) / 32768.0)[None]        # datapipe.py int16 -> /32768
+        for n_mels in (80, 128):
+            cfg = types.SimpleNamespace(audiofeat_padding=0, audiofeat_n_fft=400, audiofeat_hop_length=160,
+                                        audiofeat_num_mel_bins=n_mels)
+            y = next(iter(ref_fn.audio_compute_log_mel_spectrogram(
+                iter([{"sample_rate": sr, "waveform": wav}]), cfg)))["audiofeat"]
+            out[f"wav{i}/logmel{n_mels}"] = npy(y).astype(np.float32)
+        out[f"wav{i}/pcm"] = pcm
+        out[f"wav{i}/sr"] = np.array(sr)
+    out["mel_filters_128"] = fake_mel(16000, 400, 128)
+    save("logmel.npz", **out)
+
+
+if __name__ == "__main__":
+    only = set(sys.argv[1:])
+    for fn in (text_cases, asr_cases, ce_cases, docmask_cases, rope_cases, tiny_llama_case,
+               touch_audio_case, qwen2_audio_tower_case, frontend_cases):
+        if not only or fn.__name__ in only:
+            fn()
