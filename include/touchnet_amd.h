@@ -1,0 +1,123 @@
+/* touchnet_amd — C ABI of the MI355X (gfx950) packed-sequence training kernels.
+ *
+ * One shared library, libtouchnet_amd.so (hipcc --offload-arch=gfx950), plain pointers and sizes,
+ * no torch / C++ types.  This is the drop-in boundary: the reference is pure Python
+ * (SURVEY.md §0 fact 1), so the binding a TouchNet maintainer adds is a ctypes stub — see
+ * INTEGRATION.md and touchnet_amd/_C.py (the binding this repo ships).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) unless named host_*; buffers are dense row-major
+ *   - `dtype`: 0 = float32, 1 = bfloat16 (raw uint16 bits)
+ *   - `stream`: hipStream_t cast to void* (NULL = default stream); all entry points only ENQUEUE work
+ *     on that stream, never synchronise, never allocate; safe under hipGraph capture and from
+ *     autograd worker threads (no global mutable state)
+ *   - return value: 0 on success, a positive hipError_t from the launch, or -22 (EINVAL) for
+ *     unsupported arguments.  Callers must treat non-zero as fatal (the reference has no per-op
+ *     recovery either: touchnet/bin/train.py:639-648)
+ *   - ownership: the caller owns every buffer; outputs are fully overwritten unless stated
+ */
+#ifndef TOUCHNET_AMD_H_
+#define TOUCHNET_AMD_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- build identification -------------------------------------------------------------------- */
+const char* tn_version(void);   /* "touchnet_amd <ver> gfx950" */
+
+/* ---- RMSNorm (+ fused residual add)  — replaces LlamaRMSNorm / Qwen2RMSNorm forward+backward
+ *      transformers/models/llama/modeling_llama.py:62-67 and the residual adds at :306-324,
+ *      swapped in the way liger does at touchnet/models/llama/__init__.py:11-15.
+ * fwd:  h = x (+ res_in);  res_out = h (if res_in);  y = w * T(h * rsqrt(mean(h^2) + eps));  rstd[rows] fp32
+ * bwd:  dh = rmsnorm'(dy) (+ dres);  dw[H]     workspace: tn_norm_bwd_workspace_floats(rows, H) floats */
+int tn_norm_bwd_workspace_floats(int rows, int H);
+int tn_rmsnorm_fwd(const void* x, const void* res_in, const void* w, void* y, void* res_out, float* rstd,
+                   int rows, int H, float eps, int dtype, void* stream);
+int tn_rmsnorm_bwd(const void* dy, const void* h, const void* w, const float* rstd, const void* dres, void* dh,
+                   void* dw, float* workspace, int rows, int H, int dtype, void* stream);
+
+/* ---- LayerNorm (+ fused residual add) — Whisper-style encoder layers of the Qwen2-Audio tower
+ *      (touchnet/models/qwen2_audio/__init__.py:18-133 drives transformers' Qwen2AudioEncoderLayer). */
+int tn_layernorm_fwd(const void* x, const void* res_in, const void* w, const void* b, void* y, void* res_out,
+                     float* mean, float* rstd, int rows, int H, float eps, int dtype, void* stream);
+int tn_layernorm_bwd(const void* dy, const void* h, const void* w, const float* mean, const float* rstd,
+                     const void* dres, void* dh, void* dw, void* db, float* workspace, int rows, int H, int dtype,
+                     void* stream);
+
+/* ---- SwiGLU / GELU — transformers/models/llama/modeling_llama.py:174-176; encoder fc1 activation */
+int tn_swiglu_fwd(const void* gate, const void* up, void* out, long long n, int dtype, void* stream);
+int tn_swiglu_bwd(const void* dout, const void* gate, const void* up, void* dgate, void* dup, long long n,
+                  int dtype, void* stream);
+int tn_gelu_fwd(const void* x, void* out, long long n, int dtype, void* stream);
+int tn_gelu_bwd(const void* dout, const void* x, void* dx, long long n, int dtype, void* stream);
+
+/* ---- RoPE from packed position_ids — transformers/models/llama/modeling_llama.py:113-160 with
+ *      position_ids restarting per sentence (touchnet/models/llama/processing_llama.py:96-97).
+ * table: cos/sin [n, half] in `dtype` = cos/sin(position_ids[n] * inv_freq[half]) * attention_scaling
+ * apply: q [n, hq, D] -> q_out, k [n, hk, D] -> k_out (may alias; half-split rotate_half convention);
+ *        backward = 1 applies the transpose rotation to gradients */
+int tn_rope_table(const long long* position_ids, const float* inv_freq, void* cos_t, void* sin_t, int n, int half,
+                  float attention_scaling, int dtype, void* stream);
+int tn_rope_apply(const void* q, const void* k, void* q_out, void* k_out, const void* cos_t, const void* sin_t,
+                  int n, int hq, int hk, int D, int backward, int dtype, void* stream);
+
+/* ---- packed cross-entropy + accuracy — touchnet/loss/__init__.py:7-28,
+ *      touchnet/loss/cross_entropy.py:12-50, touchnet/utils/metrics.py:26-50.
+ * logits [n, V]; labels, sentence_lens int64 [n]; num_sentence, grad_out: device float[1]
+ * forward: nll[n], lse[n] fp32, hit[n] int32, out[4] = {loss_per_sample, loss_per_token, accuracy, n_valid}
+ * backward: dlogits (may alias logits) = (softmax - onehot) * grad_out / (sentence_lens * num_sentence) */
+int tn_ce_forward(const void* logits, const long long* labels, const long long* sentence_lens,
+                  const float* num_sentence, float* nll, float* lse, int* hit, float* out, int n, int V,
+                  long long ignore_index, int dtype, void* stream);
+int tn_ce_reduce(const float* nll, const int* hit, const long long* labels, const long long* sentence_lens,
+                 const float* num_sentence, float* out, int n, long long ignore_index, void* stream);
+int tn_ce_backward(const void* logits, void* dlogits, const long long* labels, const long long* sentence_lens,
+                   const float* lse, const float* num_sentence, const float* grad_out, int n, int V,
+                   long long ignore_index, int dtype, void* stream);
+
+/* ---- packed (document-masked causal) attention — replaces flex_attention / SDPA
+ *      (transformers/integrations/flex_attention.py:190-201,264-340 as selected by
+ *      "attn_implementation": "flex_attention", examples/text/pretrain/fineweb-edu/config/Llama-3_2-1B.json:7;
+ *      mask built from the packers' document ids, touchnet/models/llama/processing_llama.py:38-40).
+ * q [B,T,Nh,D], k/v [B,T,Nkv,D], o [B,T,Nh,D] bf16, D in {64,128}; doc int32 [B,T] (0 = pad);
+ * lse2, delta fp32 [B,Nh,T]; meta: int32[tn_attn_meta_ints(B,T)] filled by tn_attn_build_meta once per batch */
+int tn_attn_meta_ints(int B, int T);
+int tn_attn_build_meta(const int* doc, int* meta, int B, int T, void* stream);
+int tn_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse2, const int* doc, const int* meta,
+                int B, int T, int Nh, int Nkv, int D, float scale, void* stream);
+int tn_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse2,
+                float* delta, void* dq, void* dk, void* dv, const int* doc, const int* meta, int B, int T, int Nh,
+                int Nkv, int D, float scale, void* stream);
+
+/* ---- audio frontend on device — touchnet/data/functions.py:117-134 (kaldi fbank),
+ *      :159-190 (whisper log-mel), :258-286 (stack / stride / normalise).
+ * fbank:  wav fp32 [n_samples] in [-1,1) -> feat fp32 [tn_fbank_frames(n_samples), n_mels]
+ *         (x32768, 25 ms / 10 ms frames at 16 kHz, dc removal, pre-emphasis 0.97, povey window, 512-pt
+ *         power spectrum, kaldi mel (20 Hz..Nyquist), log(max(., FLT_EPSILON)))
+ * logmel: wav fp32 [n_samples] -> feat fp32 [n_samples/160, n_mels]; `mel_fb` = slaney filter bank
+ *         fp32 [n_mels, 201] supplied by the host (it is a constant table)
+ * stack:  feat fp32 [T, F] -> out fp32 [ceil(T/stride), F*stack], optional per-row normalisation */
+int tn_fbank_frames(int n_samples);
+int tn_kaldi_fbank(const float* wav, float* feat, int n_samples, int n_mels, void* stream);
+int tn_log_mel(const float* wav, const float* mel_fb, float* feat, float* scratch_max, int n_samples, int n_mels,
+               void* stream);
+int tn_audiofeat_stack(const float* feat, float* out, int T, int F, int stack, int stride, int normalize,
+                       void* stream);
+
+/* ---- fused AdamW on fp32 master weights with bf16 shadow write-back and device-side
+ *      skip-on-nonfinite — touchnet/utils/optimizer.py:157-172 + touchnet/bin/train.py:458-474.
+ * step 1: tn_sumsq accumulates sum(g^2) of one (flat) tensor into norm_sq[0] (fp32, zeroed by the caller);
+ *         deterministic two-stage reduction through `scratch` (tn_sumsq_scratch_floats() floats)
+ * step 2: tn_adamw_step updates p/m/v (fp32) from g, scaling g by min(1, max_norm/(sqrt(norm_sq)+1e-6));
+ *         if norm_sq is NaN/Inf nothing is written (the reference skips the step, train.py:467-473) */
+int tn_sumsq_scratch_floats(void);
+int tn_sumsq(const void* g, float* scratch, float* norm_sq, long long n, int dtype, void* stream);
+int tn_adamw_step(float* p, float* m, float* v, const void* g, void* p_shadow_bf16, const float* norm_sq,
+                  long long n, float lr, float beta1, float beta2, float eps, float weight_decay, float max_norm,
+                  float bias_corr1, float bias_corr2, int g_dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TOUCHNET_AMD_H_ */

@@ -1,0 +1,349 @@
+"""GPU parity: every HIP kernel (through the C ABI / autograd wrappers) against the CPU oracle.
+
+Tolerances: fp32 kernels 1e-5 rel; bf16 kernels are compared with the oracle evaluated in fp32 on the
+same bf16-rounded inputs, tolerance = a few bf16 ulps of the output scale (stated per test)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import frontend as ofe
+from oracle import loss as oloss
+from oracle import nn as onn
+
+DEV = "cuda"
+
+
+def _f():
+    import touchnet_amd.functional as F
+    return F
+
+
+def _close(got, ref, atol, rtol, what):
+    got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+    err = (got - ref).abs()
+    tol = atol + rtol * ref.abs()
+    bad = err > tol
+    assert not bad.any(), (f"{what}: {int(bad.sum())}/{bad.numel()} off, max err {float(err.max()):.4g} "
+                           f"at {np.unravel_index(int(err.argmax()), err.shape)}, ref scale {float(ref.abs().max()):.4g}")
+
+
+def test_library_loads_on_gpu():
+    from touchnet_amd import _C
+    assert "gfx950" in _C.version()
+    assert torch.cuda.is_available()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,H", [(37, 64), (130, 256), (64, 1280), (96, 2048), (33, 4096), (16, 8192)])
+def test_rmsnorm(dtype, rows, H):
+    F = _f()
+    g = torch.Generator().manual_seed(rows * H)
+    x = torch.randn(rows, H, generator=g).to(dtype)
+    w = (1 + 0.1 * torch.randn(H, generator=g)).to(dtype)
+    dy = torch.randn(rows, H, generator=g).to(dtype)
+    xr, wr = x.float().requires_grad_(), w.float().requires_grad_()
+    yr = onn.rms_norm(xr, wr, 1e-5)
+    yr.backward(dy.float())
+    xd, wd = x.to(DEV).requires_grad_(), w.to(DEV).requires_grad_()
+    y = F.rms_norm(xd, wd, 1e-5)
+    y.backward(dy.to(DEV))
+    a, rt = (1e-5, 1e-5) if dtype == torch.float32 else (3e-2, 2e-2)
+    _close(y, yr, a, rt, "y")
+    _close(xd.grad, xr.grad, a, rt, "dx")
+    _close(wd.grad, wr.grad, a * math.sqrt(rows), rt, "dw")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_rmsnorm_residual_grads(dtype):
+    F = _f()
+    rows, H = 70, 512
+    g = torch.Generator().manual_seed(5)
+    x, r = torch.randn(rows, H, generator=g).to(dtype), torch.randn(rows, H, generator=g).to(dtype)
+    w = (1 + 0.1 * torch.randn(H, generator=g)).to(dtype)
+    dy, dh = torch.randn(rows, H, generator=g).to(dtype), torch.randn(rows, H, generator=g).to(dtype)
+    xr, rr, wr = x.float().requires_grad_(), r.float().requires_grad_(), w.float().requires_grad_()
+    h = xr + rr
+    yr = onn.rms_norm(h, wr, 1e-5)
+    torch.autograd.backward([yr, h], [dy.float(), dh.float()])
+    xd, rd, wd = x.to(DEV).requires_grad_(), r.to(DEV).requires_grad_(), w.to(DEV).requires_grad_()
+    y, hh = F.rms_norm(xd, wd, 1e-5, residual=rd)
+    torch.autograd.backward([y, hh], [dy.to(DEV), dh.to(DEV)])
+    a, rt = (1e-5, 1e-5) if dtype == torch.float32 else (4e-2, 2e-2)
+    _close(hh, h, a, rt, "h")
+    _close(xd.grad, xr.grad, a, rt, "dx")
+    _close(rd.grad, rr.grad, a, rt, "dres")
+    _close(wd.grad, wr.grad, a * 8, rt, "dw")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,H", [(50, 32), (130, 1280)])
+def test_layernorm(dtype, rows, H):
+    F = _f()
+    g = torch.Generator().manual_seed(3)
+    x, r = torch.randn(rows, H, generator=g).to(dtype), torch.randn(rows, H, generator=g).to(dtype)
+    w, b = (1 + 0.1 * torch.randn(H, generator=g)).to(dtype), (0.1 * torch.randn(H, generator=g)).to(dtype)
+    dy, dh = torch.randn(rows, H, generator=g).to(dtype), torch.randn(rows, H, generator=g).to(dtype)
+    xr, rr, wr, br = [t.float().requires_grad_() for t in (x, r, w, b)]
+    h = xr + rr
+    yr = onn.layer_norm(h, wr, br)
+    torch.autograd.backward([yr, h], [dy.float(), dh.float()])
+    xd, rd, wd, bd = [t.to(DEV).requires_grad_() for t in (x, r, w, b)]
+    y, hh = F.layer_norm(xd, wd, bd, 1e-5, residual=rd)
+    torch.autograd.backward([y, hh], [dy.to(DEV), dh.to(DEV)])
+    a, rt = (2e-5, 1e-5) if dtype == torch.float32 else (4e-2, 2e-2)
+    _close(y, yr, a, rt, "y")
+    _close(xd.grad, xr.grad, a, rt, "dx")
+    _close(wd.grad, wr.grad, a * 12, rt, "dw")
+    _close(bd.grad, br.grad, a * 12, rt, "db")
+    # no-residual variant
+    y2 = F.layer_norm(x.to(DEV), w.to(DEV), b.to(DEV), 1e-5)
+    _close(y2, onn.layer_norm(x.float(), w.float(), b.float()), a, rt, "y(no res)")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_swiglu_gelu(dtype):
+    F = _f()
+    g = torch.Generator().manual_seed(2)
+    a_, b_ = (torch.randn(77, 1024, generator=g) * 2).to(dtype), torch.randn(77, 1024, generator=g).to(dtype)
+    d = torch.randn(77, 1024, generator=g).to(dtype)
+    ar, br = a_.float().requires_grad_(), b_.float().requires_grad_()
+    onn.swiglu(ar, br).backward(d.float())
+    ad, bd = a_.to(DEV).requires_grad_(), b_.to(DEV).requires_grad_()
+    out = F.swiglu(ad, bd)
+    out.backward(d.to(DEV))
+    at, rt = (1e-5, 1e-5) if dtype == torch.float32 else (2e-2, 2e-2)
+    _close(out, onn.swiglu(a_.float(), b_.float()), at, rt, "swiglu")
+    _close(ad.grad, ar.grad, at, rt, "dgate")
+    _close(bd.grad, br.grad, at, rt, "dup")
+    xr = a_.float().requires_grad_()
+    torch.nn.functional.gelu(xr).backward(d.float())
+    xd = a_.to(DEV).requires_grad_()
+    o2 = F.gelu(xd)
+    o2.backward(d.to(DEV))
+    _close(o2, torch.nn.functional.gelu(a_.float()), at, rt, "gelu")
+    _close(xd.grad, xr.grad, at, rt, "dgelu")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("D,hq,hk", [(8, 8, 4), (64, 4, 2), (128, 4, 4)])
+def test_rope(golden, dtype, D, hq, hk):
+    F = _f()
+    scaling = dict(rope_type="llama3", factor=32.0, low_freq_factor=1.0, high_freq_factor=4.0,
+                   original_max_position_embeddings=64)
+    inv = F.rope_inv_freq(D, 500000.0, scaling)
+    np.testing.assert_allclose(inv.numpy(), onn.rope_inv_freq(D, 500000.0, scaling).numpy(), rtol=1e-6)
+    B, T = 2, 50
+    g = torch.Generator().manual_seed(1)
+    pos = torch.stack([torch.cat([torch.arange(20), torch.arange(25), torch.zeros(5, dtype=torch.int64)]),
+                       torch.arange(50)])
+    q, k = torch.randn(B, T, hq, D, generator=g).to(dtype), torch.randn(B, T, hk, D, generator=g).to(dtype)
+    dq, dk = torch.randn(B, T, hq, D, generator=g).to(dtype), torch.randn(B, T, hk, D, generator=g).to(dtype)
+    cos, sin = F.rope_tables(pos.to(DEV), inv.to(DEV), dtype)
+    cr, sr = onn.rope_cos_sin(pos, inv, torch.float32)
+    at = 1e-5 if dtype == torch.float32 else 1e-2
+    _close(cos, cr[..., :D // 2].reshape(B * T, -1), at, 0, "cos")
+    _close(sin, sr[..., :D // 2].reshape(B * T, -1), at, 0, "sin")
+    qr, kr = q.float().requires_grad_(), k.float().requires_grad_()
+    cr2, sr2 = onn.rope_cos_sin(pos, inv, dtype)       # the eager path casts the table to the activation dtype
+    qo, ko = onn.apply_rope(qr.transpose(1, 2), kr.transpose(1, 2), cr2.float(), sr2.float())
+    torch.autograd.backward([qo, ko], [dq.float().transpose(1, 2), dk.float().transpose(1, 2)])
+    qd, kd = q.to(DEV).requires_grad_(), k.to(DEV).requires_grad_()
+    qo2, ko2 = F.apply_rope(qd, kd, cos, sin)
+    torch.autograd.backward([qo2, ko2], [dq.to(DEV), dk.to(DEV)])
+    at, rt = (1e-5, 1e-5) if dtype == torch.float32 else (3e-2, 1e-2)
+    _close(qo2, qo.transpose(1, 2), at, rt, "q")
+    _close(ko2, ko.transpose(1, 2), at, rt, "k")
+    _close(qd.grad, qr.grad, at, rt, "dq")
+    _close(kd.grad, kr.grad, at, rt, "dk")
+
+
+@pytest.mark.parametrize("case", ["pack", "mixed"])
+def test_ce_golden(golden, case):
+    F = _f()
+    g = golden("ce_loss.npz")
+    logits = torch.tensor(g[f"{case}/logits"]).to(DEV).requires_grad_()
+    labels, sl = torch.tensor(g[f"{case}/labels"]).to(DEV), torch.tensor(g[f"{case}/sentence_lens"]).to(DEV)
+    loss, stats = F.packed_cross_entropy(logits, labels, sl, int(g[f"{case}/num_sentence"]))
+    loss.backward()
+    assert float(stats[0]) == pytest.approx(float(g[f"{case}/loss_per_sample"]), abs=1e-6)
+    assert float(stats[1]) == pytest.approx(float(g[f"{case}/loss_per_token"]), abs=1e-6)
+    np.testing.assert_allclose(logits.grad.cpu().numpy(), g[f"{case}/dlogits"], atol=1e-7)
+    acc = oloss.accuracy(torch.tensor(g[f"{case}/logits"]), torch.tensor(g[f"{case}/labels"]))
+    assert float(stats[2]) == pytest.approx(float(acc), abs=1e-7)
+
+
+@pytest.mark.parametrize("dtype,V", [(torch.float32, 1000), (torch.bfloat16, 128256), (torch.bfloat16, 156032),
+                                      (torch.bfloat16, 1003)])
+def test_ce_large_vocab(dtype, V):
+    F = _f()
+    B, T = 2, 24
+    g = torch.Generator().manual_seed(V)
+    logits = (torch.randn(B, T, V, generator=g) * 2).to(dtype)
+    logits[0, 3, 17] = logits[0, 3].max() + 1          # a clear argmax
+    logits[1, 2, 5] = logits[1, 2, 900] = logits[1, 2].float().max() + 2   # a tie: first index wins
+    labels = torch.randint(0, V, (B, T), generator=g)
+    labels[0, 3], labels[1, 2] = 17, 5
+    labels[0, :5] = -100
+    labels[0, 3] = 17
+    labels[1, 20:] = -100
+    sl = torch.randint(1, 9, (B, T), generator=g)
+    ps, pt = oloss.cross_entropy_loss(logits.float().requires_grad_(), labels, sl, 7)
+    lr = logits.float().requires_grad_()
+    ps, pt = oloss.cross_entropy_loss(lr, labels, sl, 7)
+    (ps * 0.5).backward()
+    ld = logits.to(DEV).requires_grad_()
+    loss, stats = F.packed_cross_entropy(ld, labels.to(DEV), sl.to(DEV), torch.tensor(7, device=DEV))
+    (loss * 0.5).backward()
+    assert float(stats[0]) == pytest.approx(float(ps), rel=2e-6)
+    assert float(stats[1]) == pytest.approx(float(pt), rel=2e-6)
+    assert float(stats[2]) == pytest.approx(float(oloss.accuracy(logits.float(), labels)), abs=1e-7)
+    assert float(stats[3]) == float((labels != -100).sum())
+    at = 1e-8 if dtype == torch.float32 else 2e-4
+    _close(ld.grad, lr.grad, at, 1e-2 if dtype == torch.bfloat16 else 1e-5, "dlogits")
+    assert float(ld.grad[0, 0].abs().max()) == 0.0     # ignored rows are zero-filled
+
+
+def test_ce_all_ignored():
+    F = _f()
+    logits = torch.randn(1, 4, 16, device=DEV, requires_grad=True)
+    loss, stats = F.packed_cross_entropy(logits, torch.full((1, 4), -100, device=DEV),
+                                         torch.ones(1, 4, dtype=torch.int64, device=DEV), 1)
+    loss.backward()
+    assert stats.tolist() == [0.0, 0.0, 0.0, 0.0] and float(logits.grad.abs().max()) == 0.0
+
+
+def _docs(B, T, seed, maxlen, pad_tail):
+    rng = np.random.RandomState(seed)
+    out = np.zeros((B, T), dtype=np.int64)
+    for b in range(B):
+        t, d = 0, 1
+        end = T - (int(rng.randint(0, pad_tail + 1)) if pad_tail else 0)
+        while t < end:
+            n = int(rng.randint(1, maxlen + 1))
+            out[b, t:min(t + n, end)] = d
+            t += n
+            d += 1
+    return torch.from_numpy(out)
+
+
+ATT_CASES = [
+    # B, T, Nh, Nkv, D, maxdoc, pad
+    (2, 128, 2, 2, 64, 50, 10),
+    (1, 256, 4, 2, 128, 100, 30),
+    (2, 200, 4, 1, 64, 70, 20),        # T not a multiple of 64, GQA 4:1
+    (1, 512, 2, 2, 128, 512, 0),       # one or two long docs
+    (1, 1500, 2, 2, 64, 1500, 0),      # whisper-tower length, plain causal (single doc)
+    (2, 384, 8, 4, 128, 7, 5),         # many tiny docs
+    (1, 1024, 4, 4, 128, 300, 100),
+]
+
+
+@pytest.mark.parametrize("B,T,Nh,Nkv,D,maxdoc,pad", ATT_CASES)
+def test_packed_attention_fwd_bwd(B, T, Nh, Nkv, D, maxdoc, pad):
+    F = _f()
+    doc = _docs(B, T, T + Nh, maxdoc, pad)
+    g = torch.Generator().manual_seed(T)
+    q = torch.randn(B, T, Nh, D, generator=g).bfloat16()
+    k = torch.randn(B, T, Nkv, D, generator=g).bfloat16()
+    v = torch.randn(B, T, Nkv, D, generator=g).bfloat16()
+    do = torch.randn(B, T, Nh, D, generator=g).bfloat16()
+    qr, kr, vr = [t.float().requires_grad_() for t in (q, k, v)]
+    ref = onn.attention(qr.transpose(1, 2), kr.transpose(1, 2), vr.transpose(1, 2), onn.doc_causal_allow(doc),
+                        D ** -0.5)
+    ref.backward(do.float())
+    qd, kd, vd = [t.to(DEV).requires_grad_() for t in (q, k, v)]
+    mask = F.build_packed_mask(doc.to(DEV))
+    out = F.packed_attention(qd, kd, vd, mask)
+    out.backward(do.to(DEV))
+    torch.cuda.synchronize()
+    # bf16 output of O(1) values: 2 bf16 ulps ~ 1.6e-2; P is rounded to bf16 before P.V (as flash kernels do)
+    _close(out, ref, 2e-2, 2e-2, "O")
+    pad_rows = (doc == 0)
+    assert float(out.float().cpu()[pad_rows].abs().max() if pad_rows.any() else 0.0) == 0.0
+    _close(vd.grad, vr.grad, 4e-2, 3e-2, "dV")
+    _close(kd.grad, kr.grad, 4e-2, 3e-2, "dK")
+    _close(qd.grad, qr.grad, 4e-2, 3e-2, "dQ")
+    if pad_rows.any():
+        assert float(qd.grad.float().cpu()[pad_rows].abs().max()) == 0.0
+
+
+def test_packed_attention_online_softmax_rescale():
+    """Force a large running-max jump at a late KV tile (guide rule 26: the rescale branch needs its own test)."""
+    F = _f()
+    B, T, Nh, D = 1, 384, 1, 128
+    g = torch.Generator().manual_seed(0)
+    q = (torch.randn(B, T, Nh, D, generator=g) * 0.3).bfloat16()
+    k = (torch.randn(B, T, Nh, D, generator=g) * 0.3).bfloat16()
+    v = torch.randn(B, T, Nh, D, generator=g).bfloat16()
+    k[0, 300, 0] = q[0, 350, 0] * 40        # spike: row 350 sees its max jump at KV tile 4
+    doc = torch.ones(B, T, dtype=torch.int64)
+    ref = onn.attention(q.float().transpose(1, 2), k.float().transpose(1, 2), v.float().transpose(1, 2),
+                        onn.doc_causal_allow(doc), D ** -0.5)
+    out = F.packed_attention(q.to(DEV), k.to(DEV), v.to(DEV), F.build_packed_mask(doc.to(DEV)))
+    _close(out, ref, 2e-2, 2e-2, "O with spike")
+
+
+def test_packed_mask_metadata_matches_predicate(golden):
+    """Block-sparsity metadata must never drop an allowed (q, kv) pair (bit-exact predicate coverage)."""
+    F = _f()
+    g = golden("docmask.npz")
+    doc = torch.tensor(g["big/doc_ids"])
+    B, T = doc.shape
+    m = F.build_packed_mask(doc.to(DEV))
+    meta = m.meta.cpu().numpy().reshape(5, B, -1)
+    nt = meta.shape[2]
+    allow = g["big/allow"]
+    for b in range(B):
+        for qt in range(nt):
+            lo, = meta[3, b, qt:qt + 1]
+            rows = allow[b, qt * 64:(qt + 1) * 64]
+            used = np.nonzero(rows.any(0))[0]
+            if used.size:
+                assert lo <= used.min() // 64, (b, qt, lo, used.min())
+        for kt in range(nt):
+            hi, = meta[4, b, kt:kt + 1]
+            cols = allow[b, :, kt * 64:(kt + 1) * 64]
+            used = np.nonzero(cols.any(1))[0]
+            if used.size:
+                assert hi >= used.max() // 64, (b, kt, hi, used.max())
+
+
+def test_frontend_stack(golden):
+    F = _f()
+    g = golden("audiofeat_stack.npz")
+    for n in sorted({k.split("/")[1] for k in g.files}):
+        stack, stride = [int(v) for v in g[f"stack/{n}/ss"]]
+        y = F.audiofeat_stack(torch.tensor(g[f"stack/{n}/x"]).to(DEV), stack, stride).cpu().numpy()
+        assert y.shape == g[f"stack/{n}/y"].shape, n
+        if g[f"stack/{n}/x"].shape[1] * stack > 1:
+            np.testing.assert_allclose(y, g[f"stack/{n}/y"], atol=5e-5, err_msg=n)
+
+
+def test_frontend_log_mel(golden):
+    F = _f()
+    g = golden("logmel.npz")
+    np.testing.assert_allclose(F.slaney_mel_filters(128, "cpu").numpy(), g["mel_filters_128"], atol=1e-7)
+    for i in (0, 1):
+        wav = torch.tensor(g[f"wav{i}/pcm"].astype(np.float32) / 32768.0).to(DEV)
+        for n_mels in (80, 128):
+            y = F.log_mel_spectrogram(wav, n_mels).cpu().numpy()
+            ref = g[f"wav{i}/logmel{n_mels}"]
+            assert y.shape == ref.shape
+            np.testing.assert_allclose(y, ref, atol=1e-3)
+
+
+def test_frontend_kaldi_fbank():
+    """Against the oracle restatement (parity with torchaudio itself is UNPINNED, see oracle/frontend.py)."""
+    F = _f()
+    rng = np.random.RandomState(0)
+    for n in (400, 16000, 16000 * 3 + 77):
+        wav = np.clip(rng.randn(n) * 0.1, -1, 1).astype(np.float32)
+        y = F.kaldi_fbank(torch.tensor(wav).to(DEV), 80).cpu().numpy()
+        ref = ofe.kaldi_fbank(wav, 16000, 80)
+        assert y.shape == ref.shape
+        np.testing.assert_allclose(y, ref, atol=2e-3)
+    assert F.kaldi_fbank(torch.zeros(399, device=DEV), 80).shape == (0, 80)

@@ -1,0 +1,103 @@
+"""ctypes binding of libtouchnet_amd.so — the C ABI declared in include/touchnet_amd.h.
+
+This is the stub a TouchNet maintainer would add to bind the MI355X kernels;
+the reference itself is pure Python and calls everything through torch / transformers.
+There is NO fallback: if the library is missing or a kernel returns an error we raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_lib", "libtouchnet_amd.so")
+
+_vp, _i, _f, _ll = C.c_void_p, C.c_int, C.c_float, C.c_longlong
+
+# name -> argtypes (all return int unless listed in _RESTYPE)
+PROTOTYPES = {
+    "tn_version": [],
+    "tn_norm_bwd_workspace_floats": [_i, _i],
+    "tn_rmsnorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp],
+    "tn_rmsnorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "tn_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp],
+    "tn_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "tn_swiglu_fwd": [_vp, _vp, _vp, _ll, _i, _vp],
+    "tn_swiglu_bwd": [_vp, _vp, _vp, _vp, _vp, _ll, _i, _vp],
+    "tn_gelu_fwd": [_vp, _vp, _ll, _i, _vp],
+    "tn_gelu_bwd": [_vp, _vp, _vp, _ll, _i, _vp],
+    "tn_rope_table": [_vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp],
+    "tn_rope_apply": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "tn_ce_forward": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _ll, _i, _vp],
+    "tn_ce_reduce": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _ll, _vp],
+    "tn_ce_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _ll, _i, _vp],
+    "tn_attn_meta_ints": [_i, _i],
+    "tn_attn_build_meta": [_vp, _vp, _i, _i, _vp],
+    "tn_attn_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp],
+    "tn_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp],
+    "tn_fbank_frames": [_i],
+    "tn_kaldi_fbank": [_vp, _vp, _i, _i, _vp],
+    "tn_log_mel": [_vp, _vp, _vp, _vp, _i, _i, _vp],
+    "tn_audiofeat_stack": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "tn_sumsq_scratch_floats": [],
+    "tn_sumsq": [_vp, _vp, _vp, _ll, _i, _vp],
+    "tn_adamw_step": [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _f, _f, _f, _f, _i, _vp],
+}
+_RESTYPE = {"tn_version": C.c_char_p}
+
+_lib = None
+
+
+class KernelError(RuntimeError):
+    pass
+
+
+def lib() -> C.CDLL:
+    """Load (once) the HIP library.  Raises if it is absent — there is no CPU/eager fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: build it with `python -m touchnet_amd.build` "
+                "(touchnet_amd has no fallback path; the HIP extension is mandatory)")
+        handle = C.CDLL(LIB_PATH)
+        for name, argtypes in PROTOTYPES.items():
+            fn = getattr(handle, name)      # AttributeError if the ABI and this stub ever drift
+            fn.argtypes = argtypes
+            fn.restype = _RESTYPE.get(name, C.c_int)
+        _lib = handle
+    return _lib
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        raise KernelError(f"{what} failed with code {code} "
+                          f"({'EINVAL: unsupported shape/dtype' if code == -22 else 'hipError_t'})")
+
+
+DTYPE_CODE = {torch.float32: 0, torch.bfloat16: 1}
+
+
+def dcode(t: torch.Tensor) -> int:
+    try:
+        return DTYPE_CODE[t.dtype]
+    except KeyError:
+        raise KernelError(f"unsupported dtype {t.dtype} (float32 / bfloat16 only)") from None
+
+
+def ptr(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise KernelError("touchnet_amd kernels need device (HIP) tensors; got a CPU tensor")
+    return C.c_void_p(t.data_ptr())
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def version() -> str:
+    return lib().tn_version().decode()

@@ -1,0 +1,305 @@
+// Packed (document-masked, causal) flash attention FORWARD for gfx950 — LDS-tiled, MFMA 32x32x16 bf16.
+//
+// Replaces the flex_attention / SDPA call the reference makes per decoder layer
+// (SURVEY.md §2.3 K6/K6'; transformers/integrations/flex_attention.py:264-340 driven by the document-id
+// `attention_mask` of touchnet/models/llama/processing_llama.py:38-40 and
+// touchnet/models/touch_audio/processing_touch_audio.py:205-206; plain causal for the Qwen2-Audio path,
+// touchnet/models/qwen2_audio/__init__.py:190-193,231-236 = all ids 1).
+//
+// Layout (chosen for the producing GEMMs, no transposes anywhere):
+//   Q [B, T, Nh, D]   K, V [B, T, Nkv, D]   O [B, T, Nh, D]   bf16, D in {64, 128}
+//   LSE2 [B, Nh, T] fp32 = log2-domain log-sum-exp of scale*log2(e)*S (+inf on fully masked rows)
+//   doc [B, T] int32 document ids (0 = pad)
+//
+// Work decomposition: grid = (ceil(T/128), Nh, B); a 256-thread workgroup owns 128 query rows of one
+// head, wave w owns rows 32w..32w+31.  KV is consumed in 64-row tiles; tiles whose document-id range
+// cannot meet the query tile's range are never loaded (block-sparse over the packed batch), tiles fully
+// inside one document strictly below the diagonal skip the per-element mask.
+//
+// Per KV tile and wave:  S^T = K Q^T (A = K from LDS, B = Q in registers) so that every lane owns ONE
+// query column: softmax statistics are lane-local (one cross-half shuffle), P never leaves registers and
+// feeds O^T += V^T P^T directly as the B operand (A = V^T from a transposed, swizzled LDS image).
+#include "attn_common.h"
+
+namespace tn {
+
+// ------------------------------------------------------------------------------------------------
+// Metadata pre-pass: one thread per 64-position tile.
+// ------------------------------------------------------------------------------------------------
+__global__ void attn_meta_stats_kernel(const int* __restrict__ doc, int* tmin, int* tmax, int* tminpos, int B, int T,
+                                       int nt) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * nt) return;
+  const int b = idx / nt, t = idx % nt;
+  int mn = 0x7fffffff, mx = 0, mnp = 0x7fffffff;
+  for (int i = 0; i < kTile; ++i) {
+    const int p = t * kTile + i;
+    const int d = p < T ? doc[(size_t)b * T + p] : 0;
+    mn = min(mn, d);
+    mx = max(mx, d);
+    if (d > 0) mnp = min(mnp, d);
+  }
+  tmin[idx] = mn;
+  tmax[idx] = mx;
+  tminpos[idx] = mnp;
+}
+
+__global__ void attn_meta_range_kernel(const int* __restrict__ tmax, const int* __restrict__ tminpos, int* q_lo,
+                                       int* kv_hi, int B, int nt) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * nt) return;
+  const int b = idx / nt, t = idx % nt;
+  const int* mx = tmax + (size_t)b * nt;
+  const int* mp = tminpos + (size_t)b * nt;
+  int lo = t + 1;
+  for (int j = 0; j <= t; ++j)
+    if (tile_may_interact(mp[t], mx[t], mp[j], mx[j])) {
+      lo = j;
+      break;
+    }
+  int hi = t - 1;
+  for (int i = nt - 1; i >= t; --i)
+    if (tile_may_interact(mp[i], mx[i], mp[t], mx[t])) {
+      hi = i;
+      break;
+    }
+  q_lo[idx] = lo;
+  kv_hi[idx] = hi;
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                       const bf16_t* __restrict__ V, bf16_t* __restrict__ O,
+                                                       float* __restrict__ LSE2, const int* __restrict__ doc,
+                                                       AttnMeta meta, int T, int Nh, int Nkv, float scale_log2) {
+  constexpr int BM = 128, BN = 64;
+  constexpr int KSTEPS = D / 16;   // MFMA k-steps over the head dim
+  constexpr int DBLK = D / 32;     // 32-wide output blocks over the head dim
+  constexpr int KLD = D + 8;       // row-major K image leading dim (elements)
+  __shared__ __attribute__((aligned(16))) bf16_t smem[BN * KLD + D * TLds<BN>::STRIDE + 2 * BN];
+  bf16_t* Ks = smem;
+  bf16_t* Vt = smem + BN * KLD;
+  int* docs = reinterpret_cast<int*>(smem + BN * KLD + D * TLds<BN>::STRIDE);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int hk = h / (Nh / Nkv);
+  const int q0 = qt * BM;
+  const int wq0 = q0 + 32 * wave;
+  const int qrow = wq0 + l31;
+  const bool qvalid = qrow < T;
+
+  // ---- this lane's query row: MFMA B operand for every k-step, and its document id
+  bf16x8_t qreg[KSTEPS];
+  {
+    const bf16_t* qp = Q + (((size_t)b * T + (qvalid ? qrow : 0)) * Nh + h) * D + 8 * hi;
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (qvalid) v = *reinterpret_cast<const uint4*>(qp + 16 * s);
+      qreg[s] = as_bf16x8(v);
+    }
+  }
+  const int dq = qvalid ? doc[(size_t)b * T + qrow] : 0;
+  // wave-level id range of the 32 query rows (both 32-lane halves hold the same rows)
+  int wminpos = dq > 0 ? dq : 0x7fffffff, wmax = dq;
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) {
+    wminpos = min(wminpos, __shfl_xor(wminpos, o, 64));
+    wmax = max(wmax, __shfl_xor(wmax, o, 64));
+  }
+  const bool w_has_zero = __any(dq == 0);
+
+  // ---- block-level tile range from the metadata of the two 64-row halves of the query tile
+  const int* m_min = meta.tmin + (size_t)b * meta.nt;
+  const int* m_max = meta.tmax + (size_t)b * meta.nt;
+  const int* m_minpos = meta.tminpos + (size_t)b * meta.nt;
+  const int t0 = 2 * qt, t1 = min(2 * qt + 1, meta.nt - 1);
+  const int bminpos = min(m_minpos[t0], m_minpos[t1]);
+  const int bmax = max(m_max[t0], m_max[t1]);
+  const int j_hi = t1;
+  int j = min(meta.q_lo[(size_t)b * meta.nt + t0], meta.q_lo[(size_t)b * meta.nt + t1]);
+  auto advance = [&](int jj) {
+    while (jj <= j_hi && !tile_may_interact(bminpos, bmax, m_minpos[jj], m_max[jj])) ++jj;
+    return jj;
+  };
+  j = advance(j);
+
+  f32x16_t oacc[DBLK];
+#pragma unroll
+  for (int i = 0; i < DBLK; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;
+
+  RowMajorStage<BN, D, 256> kst;
+  TransposeStage<BN, D, 256> vst;
+  int dstage = 0;
+  const size_t kvld = (size_t)Nkv * D;
+  auto issue = [&](int jj) {
+    const int k0 = jj * BN;
+    const size_t base = (((size_t)b * T + k0) * Nkv + hk) * D;
+    kst.load(K + base, kvld, T - k0, tid);
+    vst.load(V + base, kvld, T - k0, tid);
+    if (tid < BN) dstage = (k0 + tid < T) ? doc[(size_t)b * T + k0 + tid] : 0;
+  };
+  if (j <= j_hi) issue(j);
+
+  while (j <= j_hi) {
+    const int jn = advance(j + 1);
+    __syncthreads();  // everyone finished reading the previous tile
+    kst.store(Ks, tid);
+    vst.store(Vt, tid);
+    if (tid < BN) docs[tid] = dstage;
+    __syncthreads();
+    if (jn <= j_hi) issue(jn);  // next tile's HBM loads fly under this tile's MFMAs
+
+    const int k0 = j * BN;
+    const int kminpos = m_minpos[j], kmax = m_max[j];
+    if (k0 <= wq0 + 31 && tile_may_interact(wminpos, wmax, kminpos, kmax)) {
+      const bool need_mask =
+          !(m_min[j] == kmax && kmax == wminpos && wminpos == wmax && !w_has_zero && (k0 + BN - 1 <= wq0));
+      // ---- S^T[kv, q] = K[kv, :] . Q[q, :]
+      f32x16_t sacc[2];
+#pragma unroll
+      for (int blk = 0; blk < 2; ++blk) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[blk][r] = 0.f;
+        const bf16_t* kp = Ks + (32 * blk + l31) * KLD + 8 * hi;
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s)
+          sacc[blk] = mfma32(as_bf16x8(*reinterpret_cast<const uint4*>(kp + 16 * s)), qreg[s], sacc[blk]);
+      }
+      // ---- scale, mask, online softmax (lane-local: this lane's query column)
+      float mx = -INFINITY;
+#pragma unroll
+      for (int blk = 0; blk < 2; ++blk) {
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          int4 dk = make_int4(0, 0, 0, 0);
+          if (need_mask) dk = *reinterpret_cast<const int4*>(docs + 32 * blk + 8 * r4 + 4 * hi);
+          const int dkk[4] = {dk.x, dk.y, dk.z, dk.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * r4 + e;
+            float s = sacc[blk][r] * scale_log2;
+            if (need_mask) {
+              const int kv = k0 + 32 * blk + 8 * r4 + 4 * hi + e;
+              const bool ok = (kv <= qrow) && (dkk[e] == dq) && (dq > 0);
+              s = ok ? s : -INFINITY;
+            }
+            sacc[blk][r] = s;
+            mx = fmaxf(mx, s);
+          }
+        }
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = fast_exp2(m_run - m_new);
+      m_run = m_new;
+      float psum = 0.f;
+      bf16x8_t pb[2][2];
+#pragma unroll
+      for (int blk = 0; blk < 2; ++blk) {
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp) {
+          float p[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            p[e] = fast_exp2(sacc[blk][8 * sp + e] - m_new);
+            psum += p[e];
+          }
+          u32x4_t t = {pack2bf(p[0], p[1]), pack2bf(p[2], p[3]), pack2bf(p[4], p[5]), pack2bf(p[6], p[7])};
+          pb[blk][sp] = __builtin_bit_cast(bf16x8_t, t);
+        }
+      }
+      l_run = l_run * alpha + psum;
+      if (!__all(alpha == 1.f)) {
+#pragma unroll
+        for (int i = 0; i < DBLK; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+      }
+      // ---- O^T[d, q] += V^T[d, kv] P^T[kv, q]
+#pragma unroll
+      for (int db = 0; db < DBLK; ++db) {
+        const int d = 32 * db + l31;
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+#pragma unroll
+          for (int sp = 0; sp < 2; ++sp) {
+            const int g0 = 8 * blk + 4 * sp + hi;
+            const uint2 a0 = *reinterpret_cast<const uint2*>(Vt + TLds<BN>::off(d, g0));
+            const uint2 a1 = *reinterpret_cast<const uint2*>(Vt + TLds<BN>::off(d, g0 + 2));
+            oacc[db] = mfma32(as_bf16x8(a0, a1), pb[blk][sp], oacc[db]);
+          }
+        }
+      }
+    }
+    j = jn;
+  }
+
+  // ---- epilogue: normalise, store O (4 consecutive head-dim elements = 8 bytes per store) and LSE2
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
+  if (qvalid) {
+    bf16_t* op = O + (((size_t)b * T + qrow) * Nh + h) * D;
+#pragma unroll
+    for (int db = 0; db < DBLK; ++db) {
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        uint2 o;
+        o.x = pack2bf(oacc[db][4 * r4 + 0] * inv, oacc[db][4 * r4 + 1] * inv);
+        o.y = pack2bf(oacc[db][4 * r4 + 2] * inv, oacc[db][4 * r4 + 3] * inv);
+        *reinterpret_cast<uint2*>(op + 32 * db + 8 * r4 + 4 * hi) = o;
+      }
+    }
+    if (hi == 0) LSE2[((size_t)b * Nh + h) * T + qrow] = l_tot > 0.f ? m_run + log2f(l_tot) : INFINITY;
+  }
+}
+
+}  // namespace tn
+
+using namespace tn;
+
+extern "C" {
+
+// meta buffers: 5 int32 arrays of B*nt each, nt = ceil(T/64):  [tmin | tmax | tminpos | q_lo | kv_hi]
+int tn_attn_meta_ints(int B, int T) { return 5 * B * ((T + kTile - 1) / kTile); }
+
+int tn_attn_build_meta(const int* doc, int* meta, int B, int T, void* stream) {
+  if (B <= 0 || T <= 0) return TN_EINVAL;
+  const int nt = (T + kTile - 1) / kTile, n = B * nt;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(attn_meta_stats_kernel, dim3((n + 127) / 128), dim3(128), 0, st, doc, meta, meta + n,
+                     meta + 2 * n, B, T, nt);
+  TN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(attn_meta_range_kernel, dim3((n + 127) / 128), dim3(128), 0, st, meta + n, meta + 2 * n,
+                     meta + 3 * n, meta + 4 * n, B, nt);
+  TN_LAUNCH_CHECK();
+  return TN_OK;
+}
+
+int tn_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse2, const int* doc, const int* meta,
+                int B, int T, int Nh, int Nkv, int D, float scale, void* stream) {
+  if (B <= 0 || T <= 0 || Nh <= 0 || Nkv <= 0 || Nh % Nkv) return TN_EINVAL;
+  const int nt = (T + kTile - 1) / kTile, n = B * nt;
+  AttnMeta m = {meta, meta + n, meta + 2 * n, meta + 3 * n, meta + 4 * n, nt};
+  dim3 grid((T + 127) / 128, Nh, B), block(256);
+  const float sl2 = scale * 1.4426950408889634f;
+  hipStream_t st = (hipStream_t)stream;
+  if (D == 128)
+    hipLaunchKernelGGL((attn_fwd_kernel<128>), grid, block, 0, st, (const bf16_t*)q, (const bf16_t*)k,
+                       (const bf16_t*)v, (bf16_t*)o, lse2, doc, m, T, Nh, Nkv, sl2);
+  else if (D == 64)
+    hipLaunchKernelGGL((attn_fwd_kernel<64>), grid, block, 0, st, (const bf16_t*)q, (const bf16_t*)k,
+                       (const bf16_t*)v, (bf16_t*)o, lse2, doc, m, T, Nh, Nkv, sl2);
+  else
+    return TN_EINVAL;
+  TN_LAUNCH_CHECK();
+  return TN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,119 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels of touchnet_amd.
+// wave = 64 lanes; all kernels assume blockDim.x is a multiple of 64.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define TN_OK 0
+#define TN_EINVAL (-22)
+
+#define TN_LAUNCH_CHECK()                                   \
+  do {                                                      \
+    hipError_t e__ = hipGetLastError();                     \
+    if (e__ != hipSuccess) return (int)e__;                 \
+  } while (0)
+
+namespace tn {
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;   // MFMA A/B operand (4 VGPRs)
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;   // 32x32 MFMA accumulator
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+
+// round-to-nearest-even, NaN preserved (same rounding as torch's float->bfloat16)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+
+// raw v_exp_f32 (2^x, ~1 ulp, flushes denormal results): the softmax inner loops must not pay for the
+// denormal fix-up sequence libm's exp2f adds
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+  static __device__ __forceinline__ float ld(const float* p) { return *p; }
+  static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct Elem<bf16_t> {
+  static __device__ __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
+  static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
+};
+
+// 16-byte vector of T: 8 bf16 or 4 fp32 -----------------------------------------------
+template <typename T> struct Vec16;
+template <> struct Vec16<bf16_t> {
+  static constexpr int N = 8;
+  uint4 raw;
+  __device__ __forceinline__ void load(const bf16_t* p) { raw = *reinterpret_cast<const uint4*>(p); }
+  __device__ __forceinline__ void store(bf16_t* p) const { *reinterpret_cast<uint4*>(p) = raw; }
+  __device__ __forceinline__ void unpack(float (&f)[8]) const {
+    const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f[2 * i] = __uint_as_float(w[i] << 16);
+      f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+  }
+  __device__ __forceinline__ void pack(const float (&f)[8]) {
+    raw.x = pack2bf(f[0], f[1]);
+    raw.y = pack2bf(f[2], f[3]);
+    raw.z = pack2bf(f[4], f[5]);
+    raw.w = pack2bf(f[6], f[7]);
+  }
+};
+template <> struct Vec16<float> {
+  static constexpr int N = 4;
+  float4 raw;
+  __device__ __forceinline__ void load(const float* p) { raw = *reinterpret_cast<const float4*>(p); }
+  __device__ __forceinline__ void store(float* p) const { *reinterpret_cast<float4*>(p) = raw; }
+  __device__ __forceinline__ void unpack(float (&f)[4]) const {
+    f[0] = raw.x; f[1] = raw.y; f[2] = raw.z; f[3] = raw.w;
+  }
+  __device__ __forceinline__ void pack(const float (&f)[4]) { raw = make_float4(f[0], f[1], f[2], f[3]); }
+};
+
+// wave64 / block reductions ------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// block-wide sum; `sm` must hold >= blockDim.x/64 floats; result broadcast to all threads
+__device__ __forceinline__ float block_sum(float v, float* sm) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if (lane == 0) sm[w] = v;
+  __syncthreads();
+  float r = 0.f;
+  for (int i = 0; i < nw; ++i) r += sm[i];
+  return r;
+}
+__device__ __forceinline__ float block_max(float v, float* sm) {
+  v = wave_max(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if (lane == 0) sm[w] = v;
+  __syncthreads();
+  float r = sm[0];
+  for (int i = 1; i < nw; ++i) r = fmaxf(r, sm[i]);
+  return r;
+}
+
+}  // namespace tn

@@ -1,0 +1,256 @@
+// Audio frontend on the GPU: waveform -> Kaldi log-fbank / Whisper log-mel -> stack+stride+normalise.
+//
+// Replaces the CPU dataloader-worker stages
+//   audio_compute_fbank               touchnet/data/functions.py:117-134 (torchaudio.compliance.kaldi.fbank,
+//                                     energy_floor=0.0, dither=0.0, waveform * 32768)
+//   audio_compute_log_mel_spectrogram touchnet/data/functions.py:159-190 (torch.stft hann-400 hop-160
+//                                     center/reflect, drop last frame, slaney mel, log10, max-8, (x+4)/4);
+//                                     same numbers as HF WhisperFeatureExtractor used by
+//                                     touchnet/models/qwen2_audio/processing_qwen2_audio.py:63-70
+//   audiofeat_stack                   touchnet/data/functions.py:258-286
+// so the dataloader can hand raw PCM to the device (SURVEY.md §8b hook 4).  16 kHz only (every recipe).
+//
+// All three are HBM-trivial (320 B in, 320-512 B out per 10 ms frame); the kernels keep one frame's
+// working set in LDS and are bounded by LDS/VALU, not memory: fbank = 512-point radix-2 FFT in LDS,
+// log-mel = 400-point direct DFT (400 is not a power of two; 4 frames share each twiddle load).
+#include "common.h"
+#include <float.h>
+
+namespace tn {
+
+constexpr int kWin = 400, kShift = 160, kPad = 512, kBins = 257;
+constexpr float kSr = 16000.f;
+
+__device__ __forceinline__ int bitrev9(int x) { return (int)(__brev((unsigned)x) >> 23); }
+
+__global__ __launch_bounds__(256) void kaldi_fbank_kernel(const float* __restrict__ wav, float* __restrict__ feat,
+                                                          int n_frames, int n_mels) {
+  __shared__ float re[kPad], im[kPad], twc[kPad / 2], tws[kPad / 2], win[kWin], melk[kBins + 3], pw[kBins + 3];
+  __shared__ float red[4];
+  const int tid = threadIdx.x;
+  {  // per-block constants
+    float s, c;
+    sincospif((float)tid / 256.f, &s, &c);  // angle = 2*pi*tid/512
+    twc[tid] = c;
+    tws[tid] = -s;
+    for (int n = tid; n < kWin; n += 256)
+      win[n] = powf(0.5f - 0.5f * cospif(2.f * (float)n / (float)(kWin - 1)), 0.85f);
+    for (int k = tid; k < kBins; k += 256) melk[k] = 1127.f * logf(1.f + (kSr / kPad) * (float)k / 700.f);
+  }
+  const float mel_lo = 1127.f * logf(1.f + 20.f / 700.f);
+  const float mel_hi = 1127.f * logf(1.f + (0.5f * kSr) / 700.f);
+  const float mdelta = (mel_hi - mel_lo) / (float)(n_mels + 1);
+  __syncthreads();
+
+  for (int f = blockIdx.x; f < n_frames; f += gridDim.x) {
+    const float* src = wav + (size_t)f * kShift;
+    float part = 0.f;
+    for (int n = tid; n < kWin; n += 256) {
+      const float x = src[n] * 32768.f;
+      im[n] = x;  // raw samples parked in `im`
+      part += x;
+    }
+    const float mean = block_sum(part, red) / (float)kWin;  // (contains the barriers that publish im[])
+    for (int n = tid; n < kPad; n += 256) {
+      float y = 0.f;
+      if (n < kWin) {
+        const float cur = im[n] - mean;
+        const float prev = (n > 0 ? im[n - 1] : im[0]) - mean;
+        y = (cur - 0.97f * prev) * win[n];
+      }
+      re[bitrev9(n)] = y;
+    }
+    __syncthreads();
+    for (int n = tid; n < kPad; n += 256) im[n] = 0.f;
+    __syncthreads();
+#pragma unroll 1
+    for (int s = 1; s <= 9; ++s) {
+      const int half = 1 << (s - 1);
+      const int pos = tid & (half - 1);
+      const int i = ((tid >> (s - 1)) << s) + pos;
+      const int j = i + half;
+      const int tw = pos << (9 - s);
+      const float c = twc[tw], sn = tws[tw];
+      const float br = re[j] * c - im[j] * sn, bi = re[j] * sn + im[j] * c;
+      const float ar = re[i], ai = im[i];
+      re[i] = ar + br;
+      im[i] = ai + bi;
+      re[j] = ar - br;
+      im[j] = ai - bi;
+      __syncthreads();
+    }
+    for (int k = tid; k < kBins; k += 256) pw[k] = re[k] * re[k] + im[k] * im[k];
+    __syncthreads();
+    if (tid < n_mels) {
+      const float left = mel_lo + (float)tid * mdelta, center = left + mdelta, right = center + mdelta;
+      float acc = 0.f;
+      for (int k = 0; k < kPad / 2; ++k) {  // bin 256 carries zero weight (torchaudio pads one zero column)
+        const float m = melk[k];
+        const float w = fminf((m - left) / (center - left), (right - m) / (right - center));
+        if (w > 0.f) acc += w * pw[k];
+      }
+      feat[(size_t)f * n_mels + tid] = logf(fmaxf(acc, FLT_EPSILON));
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- log-mel
+constexpr int kNfft = 400, kHop = 160, kFreq = 201, kFr = 4;
+
+__device__ __forceinline__ void atomic_max_float(float* addr, float v) {
+  if (v >= 0.f)
+    atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));
+  else
+    atomicMin(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
+}
+
+__global__ void fill_kernel(float* p, float v) { p[0] = v; }
+
+__global__ __launch_bounds__(256) void log_mel_kernel(const float* __restrict__ wav, const float* __restrict__ fb,
+                                                      float* __restrict__ feat, float* __restrict__ gmax,
+                                                      int n_samples, int n_frames, int n_mels) {
+  __shared__ float twc[kNfft], tws[kNfft], hann[kNfft], xs[kFr][kNfft], pws[kFr][kFreq + 3];
+  __shared__ float red[4];
+  const int tid = threadIdx.x;
+  for (int n = tid; n < kNfft; n += 256) {
+    float s, c;
+    sincospif(2.f * (float)n / (float)kNfft, &s, &c);
+    twc[n] = c;
+    tws[n] = s;
+    hann[n] = 0.5f - 0.5f * c;  // periodic hann: 0.5 - 0.5 cos(2 pi n / 400)
+  }
+  __syncthreads();
+  float lmax = -INFINITY;
+  const int n_groups = (n_frames + kFr - 1) / kFr;
+  for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+    const int t0 = grp * kFr;
+    for (int e = tid; e < kFr * kNfft; e += 256) {
+      const int f = e / kNfft, n = e % kNfft;
+      int src = (t0 + f) * kHop + n - kNfft / 2;  // center=True, reflect padding
+      if (src < 0) src = -src;
+      if (src >= n_samples) src = 2 * (n_samples - 1) - src;
+      const float x = (t0 + f < n_frames && src >= 0 && src < n_samples) ? wav[src] : 0.f;
+      xs[f][n] = x * hann[n];
+    }
+    __syncthreads();
+    if (tid < kFreq) {
+      float re[kFr], im[kFr];
+#pragma unroll
+      for (int f = 0; f < kFr; ++f) re[f] = im[f] = 0.f;
+      int idx = 0;
+      for (int n = 0; n < kNfft; ++n) {
+        const float c = twc[idx], s = tws[idx];
+#pragma unroll
+        for (int f = 0; f < kFr; ++f) {
+          const float x = xs[f][n];
+          re[f] += x * c;
+          im[f] -= x * s;
+        }
+        idx += tid;
+        if (idx >= kNfft) idx -= kNfft;
+      }
+#pragma unroll
+      for (int f = 0; f < kFr; ++f) pws[f][tid] = re[f] * re[f] + im[f] * im[f];
+    }
+    __syncthreads();
+    for (int e = tid; e < kFr * n_mels; e += 256) {
+      const int f = e / n_mels, m = e % n_mels;
+      if (t0 + f < n_frames) {
+        const float* w = fb + (size_t)m * kFreq;
+        float acc = 0.f;
+        for (int k = 0; k < kFreq; ++k) acc += w[k] * pws[f][k];
+        const float v = log10f(fmaxf(acc, 1e-10f));
+        feat[(size_t)(t0 + f) * n_mels + m] = v;
+        lmax = fmaxf(lmax, v);
+      }
+    }
+    __syncthreads();
+  }
+  lmax = block_max(lmax, red);
+  if (tid == 0 && lmax > -INFINITY) atomic_max_float(gmax, lmax);
+}
+
+__global__ void log_mel_finish_kernel(float* __restrict__ feat, const float* __restrict__ gmax, size_t n) {
+  const float floor_v = gmax[0] - 8.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    feat[i] = (fmaxf(feat[i], floor_v) + 4.f) * 0.25f;
+}
+
+// ---------------------------------------------------------------------------------------------- stack
+__global__ __launch_bounds__(256) void audiofeat_stack_kernel(const float* __restrict__ feat, float* __restrict__ out,
+                                                              int T, int F, int stack, int stride, int t_lfr,
+                                                              int normalize) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= t_lfr) return;
+  const int n = stack * F, lp = (stack - 1) / 2;
+  auto src = [&](int e) {
+    const int j = e / F, f = e % F;
+    int t = row * stride + j - lp;  // left pad = copies of frame 0, right pad = copies of the last frame
+    t = t < 0 ? 0 : (t > T - 1 ? T - 1 : t);
+    return feat[(size_t)t * F + f];
+  };
+  float mean = 0.f, inv = 1.f;
+  if (normalize) {
+    float s = 0.f;
+    for (int e = lane; e < n; e += 64) s += src(e);
+    mean = wave_sum(s) / (float)n;
+    float ss = 0.f;
+    for (int e = lane; e < n; e += 64) {
+      const float d = src(e) - mean;
+      ss += d * d;
+    }
+    const float var = wave_sum(ss) / (float)(n - 1);  // unbiased, as torch.std
+    inv = 1.f / (sqrtf(var) + 1e-5f);
+  }
+  for (int e = lane; e < n; e += 64) out[(size_t)row * n + e] = (src(e) - mean) * inv;
+}
+
+}  // namespace tn
+
+using namespace tn;
+
+extern "C" {
+
+int tn_fbank_frames(int n_samples) { return n_samples < kWin ? 0 : 1 + (n_samples - kWin) / kShift; }
+
+int tn_kaldi_fbank(const float* wav, float* feat, int n_samples, int n_mels, void* stream) {
+  const int nf = tn_fbank_frames(n_samples);
+  if (n_mels <= 0 || n_mels > 256) return TN_EINVAL;
+  if (nf == 0) return TN_OK;
+  hipLaunchKernelGGL(kaldi_fbank_kernel, dim3(nf < 2048 ? nf : 2048), dim3(256), 0, (hipStream_t)stream, wav, feat,
+                     nf, n_mels);
+  TN_LAUNCH_CHECK();
+  return TN_OK;
+}
+
+// scratch_max: device float[1]
+int tn_log_mel(const float* wav, const float* mel_fb, float* feat, float* scratch_max, int n_samples, int n_mels,
+               void* stream) {
+  if (n_mels <= 0 || n_samples <= kNfft / 2) return TN_EINVAL;
+  const int nf = n_samples / kHop;
+  if (nf == 0) return TN_OK;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(fill_kernel, dim3(1), dim3(1), 0, st, scratch_max, -INFINITY);
+  const int groups = (nf + kFr - 1) / kFr;
+  hipLaunchKernelGGL(log_mel_kernel, dim3(groups < 1024 ? groups : 1024), dim3(256), 0, st, wav, mel_fb, feat,
+                     scratch_max, n_samples, nf, n_mels);
+  const size_t n = (size_t)nf * n_mels;
+  hipLaunchKernelGGL(log_mel_finish_kernel, dim3((int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048)), dim3(256),
+                     0, st, feat, scratch_max, n);
+  TN_LAUNCH_CHECK();
+  return TN_OK;
+}
+
+int tn_audiofeat_stack(const float* feat, float* out, int T, int F, int stack, int stride, int normalize,
+                       void* stream) {
+  if (T <= 0 || F <= 0 || stack <= 0 || stride <= 0) return TN_EINVAL;
+  const int t_lfr = (T + stride - 1) / stride;
+  hipLaunchKernelGGL(audiofeat_stack_kernel, dim3((t_lfr + 3) / 4), dim3(256), 0, (hipStream_t)stream, feat, out, T,
+                     F, stack, stride, t_lfr, normalize);
+  TN_LAUNCH_CHECK();
+  return TN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,388 @@
+"""PyTorch-ROCm custom ops over the HIP kernels (autograd.Function wrappers around the C ABI).
+
+Every function here runs on the device through libtouchnet_amd.so and raises if that is impossible
+(CPU tensor, unsupported dtype/shape, missing library).  There is no eager fallback anywhere.
+
+Signatures mirror the modules the reference swaps (the liger precedent at
+touchnet/models/llama/__init__.py:11-15): RMSNorm, rotary embedding, SwiGLU MLP activation, the
+attention interface (transformers attention-function contract, SURVEY.md §8b hook 2) and the
+TrainSpec loss / acc functions (hook 3).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import _C
+
+_cur = _C.stream
+_p = _C.ptr
+
+
+def _c(t: torch.Tensor) -> torch.Tensor:
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ------------------------------------------------------------------------------------ norms
+class _RMSNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, residual, weight, eps):
+        H = x.shape[-1]
+        x2 = _c(x).view(-1, H)
+        rows = x2.shape[0]
+        r2 = _c(residual).view(-1, H) if residual is not None else None
+        w = _c(weight).to(x.dtype)
+        y = torch.empty_like(x2)
+        h = torch.empty_like(x2) if r2 is not None else x2
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        _C.check(_C.lib().tn_rmsnorm_fwd(_p(x2), _p(r2), _p(w), _p(y), _p(h) if r2 is not None else None,
+                                         _p(rstd), rows, H, float(eps), _C.dcode(x2), _cur()), "tn_rmsnorm_fwd")
+        ctx.save_for_backward(h, w, rstd)
+        ctx.has_res = r2 is not None
+        ctx.wdtype = weight.dtype
+        if r2 is not None:
+            return y.view(x.shape), h.view(x.shape)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy, dh_new=None):
+        h, w, rstd = ctx.saved_tensors
+        rows, H = h.shape
+        dy2 = _c(dy).view(rows, H)
+        dres = _c(dh_new).view(rows, H) if dh_new is not None else None
+        dh = torch.empty_like(h)
+        dw = torch.empty(H, dtype=h.dtype, device=h.device)
+        ws = torch.empty(_C.lib().tn_norm_bwd_workspace_floats(rows, H), dtype=torch.float32, device=h.device)
+        _C.check(_C.lib().tn_rmsnorm_bwd(_p(dy2), _p(h), _p(w), _p(rstd), _p(dres), _p(dh), _p(dw), _p(ws), rows, H,
+                                         _C.dcode(h), _cur()), "tn_rmsnorm_bwd")
+        dh = dh.view(dy.shape)
+        return dh, (dh if ctx.has_res else None), dw.to(ctx.wdtype), None
+
+
+def rms_norm(x, weight, eps, residual=None):
+    """y = RMSNorm(x (+ residual)) * weight.  With ``residual`` returns ``(y, x + residual)``: the
+    residual add of the decoder layer (modeling_llama.py:306-324) is fused into the norm that follows it."""
+    return _RMSNorm.apply(x, residual, weight, eps)
+
+
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, residual, weight, bias, eps):
+        H = x.shape[-1]
+        x2 = _c(x).view(-1, H)
+        rows = x2.shape[0]
+        r2 = _c(residual).view(-1, H) if residual is not None else None
+        w, b = _c(weight).to(x.dtype), _c(bias).to(x.dtype)
+        y = torch.empty_like(x2)
+        h = torch.empty_like(x2) if r2 is not None else x2
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        _C.check(_C.lib().tn_layernorm_fwd(_p(x2), _p(r2), _p(w), _p(b), _p(y), _p(h) if r2 is not None else None,
+                                           _p(mean), _p(rstd), rows, H, float(eps), _C.dcode(x2), _cur()),
+                 "tn_layernorm_fwd")
+        ctx.save_for_backward(h, w, mean, rstd)
+        ctx.has_res = r2 is not None
+        ctx.wdtype = weight.dtype
+        if r2 is not None:
+            return y.view(x.shape), h.view(x.shape)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy, dh_new=None):
+        h, w, mean, rstd = ctx.saved_tensors
+        rows, H = h.shape
+        dy2 = _c(dy).view(rows, H)
+        dres = _c(dh_new).view(rows, H) if dh_new is not None else None
+        dh = torch.empty_like(h)
+        dw = torch.empty(H, dtype=h.dtype, device=h.device)
+        db = torch.empty_like(dw)
+        ws = torch.empty(_C.lib().tn_norm_bwd_workspace_floats(rows, H), dtype=torch.float32, device=h.device)
+        _C.check(_C.lib().tn_layernorm_bwd(_p(dy2), _p(h), _p(w), _p(mean), _p(rstd), _p(dres), _p(dh), _p(dw),
+                                           _p(db), _p(ws), rows, H, _C.dcode(h), _cur()), "tn_layernorm_bwd")
+        dh = dh.view(dy.shape)
+        return dh, (dh if ctx.has_res else None), dw.to(ctx.wdtype), db.to(ctx.wdtype), None
+
+
+def layer_norm(x, weight, bias, eps=1e-5, residual=None):
+    return _LayerNorm.apply(x, residual, weight, bias, eps)
+
+
+# ------------------------------------------------------------------------------------ activations
+class _SwiGLU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, gate, up):
+        g, u = _c(gate), _c(up)
+        out = torch.empty_like(g)
+        _C.check(_C.lib().tn_swiglu_fwd(_p(g), _p(u), _p(out), g.numel(), _C.dcode(g), _cur()), "tn_swiglu_fwd")
+        ctx.save_for_backward(g, u)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        g, u = ctx.saved_tensors
+        d = _c(dout)
+        dg, du = torch.empty_like(g), torch.empty_like(u)
+        _C.check(_C.lib().tn_swiglu_bwd(_p(d), _p(g), _p(u), _p(dg), _p(du), g.numel(), _C.dcode(g), _cur()),
+                 "tn_swiglu_bwd")
+        return dg, du
+
+
+def swiglu(gate, up):
+    """silu(gate) * up (modeling_llama.py:174-176)."""
+    return _SwiGLU.apply(gate, up)
+
+
+class _GELU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        out = torch.empty_like(x)
+        _C.check(_C.lib().tn_gelu_fwd(_p(x), _p(out), x.numel(), _C.dcode(x), _cur()), "tn_gelu_fwd")
+        ctx.save_for_backward(x)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (x,) = ctx.saved_tensors
+        d = _c(dout)
+        dx = torch.empty_like(x)
+        _C.check(_C.lib().tn_gelu_bwd(_p(d), _p(x), _p(dx), x.numel(), _C.dcode(x), _cur()), "tn_gelu_bwd")
+        return dx
+
+
+def gelu(x):
+    return _GELU.apply(x)
+
+
+# ------------------------------------------------------------------------------------ RoPE
+def rope_inv_freq(head_dim: int, theta: float, scaling: Optional[dict] = None, device=None) -> torch.Tensor:
+    """fp32 [head_dim/2] inverse frequencies, default or llama3-scaled
+    (the table `post_init` re-derives at touchnet/models/llama/__init__.py:23-27)."""
+    inv = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.int64).float() / head_dim))
+    kind = (scaling or {}).get("rope_type", (scaling or {}).get("type", "default"))
+    if kind == "llama3":
+        factor, lo, hi = scaling["factor"], scaling["low_freq_factor"], scaling["high_freq_factor"]
+        old = scaling["original_max_position_embeddings"]
+        wavelen = 2 * math.pi / inv
+        inv_l = torch.where(wavelen > old / lo, inv / factor, inv)
+        smooth = (old / wavelen - lo) / (hi - lo)
+        smoothed = (1 - smooth) * inv_l / factor + smooth * inv_l
+        medium = ~(wavelen < old / hi) & ~(wavelen > old / lo)
+        inv = torch.where(medium, smoothed, inv_l)
+    elif kind != "default":
+        raise _C.KernelError(f"unsupported rope_type {kind!r}")
+    return inv.to(device) if device is not None else inv
+
+
+def rope_tables(position_ids: torch.Tensor, inv_freq: torch.Tensor, dtype, attention_scaling: float = 1.0):
+    """cos/sin [B*T, D/2] in ``dtype`` from packed int64 position_ids [B, T] (once per forward)."""
+    pos = _c(position_ids).to(torch.int64).view(-1)
+    inv = _c(inv_freq).float()
+    n, half = pos.numel(), inv.numel()
+    cos = torch.empty(n, half, dtype=dtype, device=pos.device)
+    sin = torch.empty_like(cos)
+    _C.check(_C.lib().tn_rope_table(_p(pos), _p(inv), _p(cos), _p(sin), n, half, float(attention_scaling),
+                                    _C.dcode(cos), _cur()), "tn_rope_table")
+    return cos, sin
+
+
+class _RoPE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, cos, sin):
+        q, k = _c(q), _c(k)
+        B, T, hq, D = q.shape
+        hk = k.shape[2]
+        qo, ko = torch.empty_like(q), torch.empty_like(k)
+        _C.check(_C.lib().tn_rope_apply(_p(q), _p(k), _p(qo), _p(ko), _p(cos), _p(sin), B * T, hq, hk, D, 0,
+                                        _C.dcode(q), _cur()), "tn_rope_apply")
+        ctx.save_for_backward(cos, sin)
+        return qo, ko
+
+    @staticmethod
+    def backward(ctx, dq, dk):
+        cos, sin = ctx.saved_tensors
+        dq, dk = _c(dq), _c(dk)
+        B, T, hq, D = dq.shape
+        hk = dk.shape[2]
+        gq, gk = torch.empty_like(dq), torch.empty_like(dk)
+        _C.check(_C.lib().tn_rope_apply(_p(dq), _p(dk), _p(gq), _p(gk), _p(cos), _p(sin), B * T, hq, hk, D, 1,
+                                        _C.dcode(dq), _cur()), "tn_rope_apply(bwd)")
+        return gq, gk, None, None
+
+
+def apply_rope(q, k, cos, sin):
+    """q [B,T,Nh,D], k [B,T,Nkv,D] (the GEMM output layout — no head transpose), tables from rope_tables."""
+    return _RoPE.apply(q, k, cos, sin)
+
+
+# ------------------------------------------------------------------------------------ attention
+@dataclass
+class PackedMask:
+    """Device-side form of the packers' document-id `attention_mask`
+    (touchnet/models/llama/processing_llama.py:38-40): int32 ids + per-64-tile range metadata.
+    Built once per batch and shared by all layers (the reference builds its BlockMask once per forward)."""
+    doc: torch.Tensor     # int32 [B, T], 0 = pad
+    meta: torch.Tensor    # int32 [5 * B * ceil(T/64)]
+    B: int
+    T: int
+
+
+def build_packed_mask(doc_ids: torch.Tensor) -> PackedMask:
+    B, T = doc_ids.shape
+    doc = _c(doc_ids).to(torch.int32)
+    meta = torch.empty(_C.lib().tn_attn_meta_ints(B, T), dtype=torch.int32, device=doc.device)
+    _C.check(_C.lib().tn_attn_build_meta(_p(doc), _p(meta), B, T, _cur()), "tn_attn_build_meta")
+    return PackedMask(doc, meta, B, T)
+
+
+def causal_mask(B: int, T: int, device) -> PackedMask:
+    """Plain causal attention (the Qwen2-Audio training path, qwen2_audio/__init__.py:231-236) =
+    one document per row."""
+    return build_packed_mask(torch.ones(B, T, dtype=torch.int32, device=device))
+
+
+class _PackedAttention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, mask: PackedMask, scale):
+        q, k, v = _c(q), _c(k), _c(v)
+        if q.dtype != torch.bfloat16:
+            raise _C.KernelError("packed_attention: bf16 only (MFMA 32x32x16 bf16 kernel)")
+        B, T, Nh, D = q.shape
+        Nkv = k.shape[2]
+        if (B, T) != (mask.B, mask.T):
+            raise _C.KernelError(f"mask built for {(mask.B, mask.T)}, got q {(B, T)}")
+        o = torch.empty_like(q)
+        lse2 = torch.empty(B, Nh, T, dtype=torch.float32, device=q.device)
+        _C.check(_C.lib().tn_attn_fwd(_p(q), _p(k), _p(v), _p(o), _p(lse2), _p(mask.doc), _p(mask.meta), B, T, Nh,
+                                      Nkv, D, float(scale), _cur()), "tn_attn_fwd")
+        ctx.save_for_backward(q, k, v, o, lse2)
+        ctx.mask, ctx.scale = mask, float(scale)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, o, lse2 = ctx.saved_tensors
+        do = _c(do)
+        B, T, Nh, D = q.shape
+        Nkv = k.shape[2]
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        delta = torch.empty_like(lse2)
+        m = ctx.mask
+        _C.check(_C.lib().tn_attn_bwd(_p(q), _p(k), _p(v), _p(o), _p(do), _p(lse2), _p(delta), _p(dq), _p(dk),
+                                      _p(dv), _p(m.doc), _p(m.meta), B, T, Nh, Nkv, D, ctx.scale, _cur()),
+                 "tn_attn_bwd")
+        return dq, dk, dv, None, None
+
+
+def packed_attention(q, k, v, mask: PackedMask, scale: Optional[float] = None):
+    """softmax(scale * Q K^T + doc-causal mask) V with q [B,T,Nh,D], k/v [B,T,Nkv,D] -> [B,T,Nh,D]."""
+    if scale is None:
+        scale = q.shape[-1] ** -0.5
+    return _PackedAttention.apply(q, k, v, mask, scale)
+
+
+# ------------------------------------------------------------------------------------ loss
+def _num_sentence_dev(num_sentence, device):
+    if isinstance(num_sentence, torch.Tensor):
+        return num_sentence.to(device=device, dtype=torch.float32).reshape(1)
+    return torch.tensor([float(num_sentence)], dtype=torch.float32, device=device)
+
+
+class _PackedCE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, labels, sentence_lens, num_sentence, ignore_index, inplace_grad):
+        V = pred.shape[-1]
+        logits = _c(pred).view(-1, V)
+        n = logits.shape[0]
+        lab = _c(labels).to(torch.int64).view(-1)
+        sl = _c(sentence_lens).to(torch.int64).view(-1)
+        ns = _num_sentence_dev(num_sentence, pred.device)
+        nll = torch.empty(n, dtype=torch.float32, device=pred.device)
+        lse = torch.empty_like(nll)
+        hit = torch.empty(n, dtype=torch.int32, device=pred.device)
+        out = torch.empty(4, dtype=torch.float32, device=pred.device)
+        _C.check(_C.lib().tn_ce_forward(_p(logits), _p(lab), _p(sl), _p(ns), _p(nll), _p(lse), _p(hit), _p(out), n, V,
+                                        int(ignore_index), _C.dcode(logits), _cur()), "tn_ce_forward")
+        ctx.save_for_backward(logits, lab, sl, lse, ns)
+        ctx.ignore_index, ctx.shape, ctx.inplace = int(ignore_index), pred.shape, bool(inplace_grad)
+        ctx.mark_non_differentiable(out)
+        return out[0].clone(), out
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_out):
+        logits, lab, sl, lse, ns = ctx.saved_tensors
+        n, V = logits.shape
+        g = _c(g_loss).to(torch.float32).reshape(1)
+        dlog = logits if ctx.inplace else torch.empty_like(logits)
+        _C.check(_C.lib().tn_ce_backward(_p(logits), _p(dlog), _p(lab), _p(sl), _p(lse), _p(ns), _p(g), n, V,
+                                         ctx.ignore_index, _C.dcode(logits), _cur()), "tn_ce_backward")
+        return dlog.view(ctx.shape), None, None, None, None, None
+
+
+def packed_cross_entropy(pred, labels, sentence_lens, num_sentence, ignore_index=-100, inplace_grad=False):
+    """Returns ``(loss_per_sample [differentiable], stats)`` with
+    ``stats = [loss_per_sample, loss_per_token, accuracy, n_valid]`` (fp32 device tensor, no host sync)."""
+    return _PackedCE.apply(pred, labels, sentence_lens, num_sentence, ignore_index, inplace_grad)
+
+
+# ------------------------------------------------------------------------------------ frontend
+_MEL_CACHE = {}
+
+
+def slaney_mel_filters(n_mels: int, device) -> torch.Tensor:
+    """librosa.filters.mel(sr=16000, n_fft=400, n_mels) (touchnet/data/functions.py:179-182): slaney scale
+    and norm.  A constant table, built on the host once per (n_mels, device)."""
+    key = (n_mels, str(device))
+    if key not in _MEL_CACHE:
+        import numpy as np
+        sr, n_fft = 16000.0, 400
+        f_sp, min_log_hz = 200.0 / 3, 1000.0
+        min_log_mel, logstep = min_log_hz / f_sp, np.log(6.4) / 27.0
+        to_mel = lambda f: np.where(f >= min_log_hz, min_log_mel + np.log(np.maximum(f, 1e-10) / min_log_hz) / logstep,
+                                    f / f_sp)
+        to_hz = lambda m: np.where(m >= min_log_mel, min_log_hz * np.exp(logstep * (m - min_log_mel)), f_sp * m)
+        fftfreqs = np.linspace(0.0, sr / 2, 1 + n_fft // 2)
+        mel_f = to_hz(np.linspace(to_mel(np.float64(0.0)), to_mel(np.float64(sr / 2)), n_mels + 2))
+        fdiff = np.diff(mel_f)
+        ramps = mel_f[:, None] - fftfreqs[None, :]
+        lower = -ramps[:-2] / fdiff[:-1, None]
+        upper = ramps[2:] / fdiff[1:, None]
+        w = np.maximum(0.0, np.minimum(lower, upper)) * (2.0 / (mel_f[2:] - mel_f[:-2]))[:, None]
+        _MEL_CACHE[key] = torch.from_numpy(w.astype(np.float32)).to(device).contiguous()
+    return _MEL_CACHE[key]
+
+
+def kaldi_fbank(wav: torch.Tensor, num_mel_bins: int = 80) -> torch.Tensor:
+    """wav fp32 [N] in [-1, 1) at 16 kHz -> fp32 [frames, num_mel_bins] (functions.py:117-134)."""
+    wav = _c(wav).float().view(-1)
+    nf = _C.lib().tn_fbank_frames(wav.numel())
+    feat = torch.empty(nf, num_mel_bins, dtype=torch.float32, device=wav.device)
+    _C.check(_C.lib().tn_kaldi_fbank(_p(wav), _p(feat), wav.numel(), num_mel_bins, _cur()), "tn_kaldi_fbank")
+    return feat
+
+
+def log_mel_spectrogram(wav: torch.Tensor, num_mel_bins: int = 128, padding: int = 0) -> torch.Tensor:
+    """wav fp32 [N] at 16 kHz -> fp32 [N // 160, num_mel_bins] (functions.py:159-190)."""
+    wav = _c(wav).float().view(-1)
+    if padding > 0:
+        wav = torch.nn.functional.pad(wav, (0, padding))
+    nf = wav.numel() // 160
+    feat = torch.empty(nf, num_mel_bins, dtype=torch.float32, device=wav.device)
+    gmax = torch.empty(1, dtype=torch.float32, device=wav.device)
+    fb = slaney_mel_filters(num_mel_bins, wav.device)
+    _C.check(_C.lib().tn_log_mel(_p(wav), _p(fb), _p(feat), _p(gmax), wav.numel(), num_mel_bins, _cur()),
+             "tn_log_mel")
+    return feat
+
+
+def audiofeat_stack(feat: torch.Tensor, stack: int, stride: int, normalize: bool = True) -> torch.Tensor:
+    """feat fp32 [T, F] -> fp32 [ceil(T/stride), F*stack] (functions.py:258-286)."""
+    feat = _c(feat).float()
+    T, F = feat.shape
+    out = torch.empty((T + stride - 1) // stride, F * stack, dtype=torch.float32, device=feat.device)
+    _C.check(_C.lib().tn_audiofeat_stack(_p(feat), _p(out), T, F, stack, stride, int(normalize), _cur()),
+             "tn_audiofeat_stack")
+    return out
