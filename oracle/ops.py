@@ -1,0 +1,77 @@
+"""Oracle op namespace with the SAME signatures as touchnet_amd.functional (TEST INFRASTRUCTURE).
+
+Lets the CPU test-suite run the product's module wiring / packers / sharding logic end to end
+(`touchnet_amd.models.backend.use_ops(oracle.ops)`), and serves as the checker for the GPU path.
+Every op is the eager restatement from oracle/nn.py / oracle/loss.py; layouts follow the product
+([B, T, heads, D] attention tensors, [B*T, D/2] rope tables).
+"""
+from types import SimpleNamespace
+
+import torch
+
+from . import loss as _loss
+from . import nn as _nn
+
+
+def rms_norm(x, weight, eps, residual=None):
+    if residual is None:
+        return _nn.rms_norm(x, weight.to(x.dtype), eps)
+    h = x + residual
+    return _nn.rms_norm(h, weight.to(x.dtype), eps), h
+
+
+def layer_norm(x, weight, bias, eps=1e-5, residual=None):
+    if residual is None:
+        return _nn.layer_norm(x, weight.to(x.dtype), bias.to(x.dtype), eps)
+    h = x + residual
+    return _nn.layer_norm(h, weight.to(x.dtype), bias.to(x.dtype), eps), h
+
+
+swiglu = _nn.swiglu
+gelu = torch.nn.functional.gelu
+
+
+def rope_inv_freq(head_dim, theta, scaling=None, device=None):
+    inv = _nn.rope_inv_freq(head_dim, theta, scaling)
+    return inv.to(device) if device is not None else inv
+
+
+def rope_tables(position_ids, inv_freq, dtype, attention_scaling=1.0):
+    cos, sin = _nn.rope_cos_sin(position_ids, inv_freq, dtype)
+    half = inv_freq.numel()
+    return cos[..., :half].reshape(-1, half), sin[..., :half].reshape(-1, half)
+
+
+def apply_rope(q, k, cos, sin):
+    B, T = q.shape[:2]
+    c = torch.cat([cos, cos], -1).view(B, T, -1)
+    s = torch.cat([sin, sin], -1).view(B, T, -1)
+    qo, ko = _nn.apply_rope(q.transpose(1, 2), k.transpose(1, 2), c, s)
+    return qo.transpose(1, 2), ko.transpose(1, 2)
+
+
+def build_packed_mask(doc_ids):
+    return SimpleNamespace(doc=doc_ids, allow=_nn.doc_causal_allow(doc_ids), B=doc_ids.shape[0], T=doc_ids.shape[1])
+
+
+def causal_mask(B, T, device):
+    return build_packed_mask(torch.ones(B, T, dtype=torch.int64, device=device))
+
+
+def packed_attention(q, k, v, mask, scale=None):
+    scale = q.shape[-1] ** -0.5 if scale is None else scale
+    return _nn.attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), mask.allow, scale)
+
+
+def _num_sentence_dev(num_sentence, device):
+    if isinstance(num_sentence, torch.Tensor):
+        return num_sentence.to(device=device, dtype=torch.float32).reshape(1)
+    return torch.tensor([float(num_sentence)], dtype=torch.float32, device=device)
+
+
+def packed_cross_entropy(pred, labels, sentence_lens, num_sentence, ignore_index=-100, inplace_grad=False):
+    ns = _num_sentence_dev(num_sentence, pred.device)[0]
+    ps, pt = _loss.cross_entropy_loss(pred, labels, sentence_lens, ns, ignore_index)
+    acc = _loss.accuracy(pred.detach(), labels, ignore_index)
+    nvalid = (labels != ignore_index).sum().float()
+    return ps, torch.stack([ps.detach(), pt.detach(), acc.float(), nvalid])

@@ -22,6 +22,15 @@ def _f():
     return F
 
 
+def _ref(t):
+    """fp32 CPU leaf (a real copy: `.float()` of an fp32 tensor would alias its input)."""
+    return t.detach().float().clone().requires_grad_()
+
+
+def _dev(t):
+    return t.detach().clone().to(DEV).requires_grad_()
+
+
 def _close(got, ref, atol, rtol, what):
     got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
     err = (got - ref).abs()
@@ -41,14 +50,16 @@ def test_library_loads_on_gpu():
 @pytest.mark.parametrize("rows,H", [(37, 64), (130, 256), (64, 1280), (96, 2048), (33, 4096), (16, 8192)])
 def test_rmsnorm(dtype, rows, H):
     F = _f()
+    if dtype == torch.float32 and H > 4096:
+        pytest.skip("fp32 rows wider than 4096 are outside the kernel's register budget (bf16 goes to 8192)")
     g = torch.Generator().manual_seed(rows * H)
     x = torch.randn(rows, H, generator=g).to(dtype)
     w = (1 + 0.1 * torch.randn(H, generator=g)).to(dtype)
     dy = torch.randn(rows, H, generator=g).to(dtype)
-    xr, wr = x.float().requires_grad_(), w.float().requires_grad_()
+    xr, wr = _ref(x), _ref(w)
     yr = onn.rms_norm(xr, wr, 1e-5)
     yr.backward(dy.float())
-    xd, wd = x.to(DEV).requires_grad_(), w.to(DEV).requires_grad_()
+    xd, wd = _dev(x), _dev(w)
     y = F.rms_norm(xd, wd, 1e-5)
     y.backward(dy.to(DEV))
     a, rt = (1e-5, 1e-5) if dtype == torch.float32 else (3e-2, 2e-2)
@@ -65,11 +76,11 @@ def test_rmsnorm_residual_grads(dtype):
     x, r = torch.randn(rows, H, generator=g).to(dtype), torch.randn(rows, H, generator=g).to(dtype)
     w = (1 + 0.1 * torch.randn(H, generator=g)).to(dtype)
     dy, dh = torch.randn(rows, H, generator=g).to(dtype), torch.randn(rows, H, generator=g).to(dtype)
-    xr, rr, wr = x.float().requires_grad_(), r.float().requires_grad_(), w.float().requires_grad_()
+    xr, rr, wr = _ref(x), _ref(r), _ref(w)
     h = xr + rr
     yr = onn.rms_norm(h, wr, 1e-5)
     torch.autograd.backward([yr, h], [dy.float(), dh.float()])
-    xd, rd, wd = x.to(DEV).requires_grad_(), r.to(DEV).requires_grad_(), w.to(DEV).requires_grad_()
+    xd, rd, wd = _dev(x), _dev(r), _dev(w)
     y, hh = F.rms_norm(xd, wd, 1e-5, residual=rd)
     torch.autograd.backward([y, hh], [dy.to(DEV), dh.to(DEV)])
     a, rt = (1e-5, 1e-5) if dtype == torch.float32 else (4e-2, 2e-2)
@@ -87,11 +98,11 @@ def test_layernorm(dtype, rows, H):
     x, r = torch.randn(rows, H, generator=g).to(dtype), torch.randn(rows, H, generator=g).to(dtype)
     w, b = (1 + 0.1 * torch.randn(H, generator=g)).to(dtype), (0.1 * torch.randn(H, generator=g)).to(dtype)
     dy, dh = torch.randn(rows, H, generator=g).to(dtype), torch.randn(rows, H, generator=g).to(dtype)
-    xr, rr, wr, br = [t.float().requires_grad_() for t in (x, r, w, b)]
+    xr, rr, wr, br = [_ref(t) for t in (x, r, w, b)]
     h = xr + rr
     yr = onn.layer_norm(h, wr, br)
     torch.autograd.backward([yr, h], [dy.float(), dh.float()])
-    xd, rd, wd, bd = [t.to(DEV).requires_grad_() for t in (x, r, w, b)]
+    xd, rd, wd, bd = [_dev(t) for t in (x, r, w, b)]
     y, hh = F.layer_norm(xd, wd, bd, 1e-5, residual=rd)
     torch.autograd.backward([y, hh], [dy.to(DEV), dh.to(DEV)])
     a, rt = (2e-5, 1e-5) if dtype == torch.float32 else (4e-2, 2e-2)
@@ -110,18 +121,18 @@ def test_swiglu_gelu(dtype):
     g = torch.Generator().manual_seed(2)
     a_, b_ = (torch.randn(77, 1024, generator=g) * 2).to(dtype), torch.randn(77, 1024, generator=g).to(dtype)
     d = torch.randn(77, 1024, generator=g).to(dtype)
-    ar, br = a_.float().requires_grad_(), b_.float().requires_grad_()
+    ar, br = _ref(a_), _ref(b_)
     onn.swiglu(ar, br).backward(d.float())
-    ad, bd = a_.to(DEV).requires_grad_(), b_.to(DEV).requires_grad_()
+    ad, bd = _dev(a_), _dev(b_)
     out = F.swiglu(ad, bd)
     out.backward(d.to(DEV))
     at, rt = (1e-5, 1e-5) if dtype == torch.float32 else (2e-2, 2e-2)
     _close(out, onn.swiglu(a_.float(), b_.float()), at, rt, "swiglu")
     _close(ad.grad, ar.grad, at, rt, "dgate")
     _close(bd.grad, br.grad, at, rt, "dup")
-    xr = a_.float().requires_grad_()
+    xr = _ref(a_)
     torch.nn.functional.gelu(xr).backward(d.float())
-    xd = a_.to(DEV).requires_grad_()
+    xd = _dev(a_)
     o2 = F.gelu(xd)
     o2.backward(d.to(DEV))
     _close(o2, torch.nn.functional.gelu(a_.float()), at, rt, "gelu")
@@ -147,11 +158,11 @@ def test_rope(golden, dtype, D, hq, hk):
     at = 1e-5 if dtype == torch.float32 else 1e-2
     _close(cos, cr[..., :D // 2].reshape(B * T, -1), at, 0, "cos")
     _close(sin, sr[..., :D // 2].reshape(B * T, -1), at, 0, "sin")
-    qr, kr = q.float().requires_grad_(), k.float().requires_grad_()
+    qr, kr = _ref(q), _ref(k)
     cr2, sr2 = onn.rope_cos_sin(pos, inv, dtype)       # the eager path casts the table to the activation dtype
     qo, ko = onn.apply_rope(qr.transpose(1, 2), kr.transpose(1, 2), cr2.float(), sr2.float())
     torch.autograd.backward([qo, ko], [dq.float().transpose(1, 2), dk.float().transpose(1, 2)])
-    qd, kd = q.to(DEV).requires_grad_(), k.to(DEV).requires_grad_()
+    qd, kd = _dev(q), _dev(k)
     qo2, ko2 = F.apply_rope(qd, kd, cos, sin)
     torch.autograd.backward([qo2, ko2], [dq.to(DEV), dk.to(DEV)])
     at, rt = (1e-5, 1e-5) if dtype == torch.float32 else (3e-2, 1e-2)
@@ -191,11 +202,10 @@ def test_ce_large_vocab(dtype, V):
     labels[0, 3] = 17
     labels[1, 20:] = -100
     sl = torch.randint(1, 9, (B, T), generator=g)
-    ps, pt = oloss.cross_entropy_loss(logits.float().requires_grad_(), labels, sl, 7)
-    lr = logits.float().requires_grad_()
+    lr = _ref(logits)
     ps, pt = oloss.cross_entropy_loss(lr, labels, sl, 7)
     (ps * 0.5).backward()
-    ld = logits.to(DEV).requires_grad_()
+    ld = _dev(logits)
     loss, stats = F.packed_cross_entropy(ld, labels.to(DEV), sl.to(DEV), torch.tensor(7, device=DEV))
     (loss * 0.5).backward()
     assert float(stats[0]) == pytest.approx(float(ps), rel=2e-6)
@@ -251,11 +261,11 @@ def test_packed_attention_fwd_bwd(B, T, Nh, Nkv, D, maxdoc, pad):
     k = torch.randn(B, T, Nkv, D, generator=g).bfloat16()
     v = torch.randn(B, T, Nkv, D, generator=g).bfloat16()
     do = torch.randn(B, T, Nh, D, generator=g).bfloat16()
-    qr, kr, vr = [t.float().requires_grad_() for t in (q, k, v)]
+    qr, kr, vr = [_ref(t) for t in (q, k, v)]
     ref = onn.attention(qr.transpose(1, 2), kr.transpose(1, 2), vr.transpose(1, 2), onn.doc_causal_allow(doc),
                         D ** -0.5)
     ref.backward(do.float())
-    qd, kd, vd = [t.to(DEV).requires_grad_() for t in (q, k, v)]
+    qd, kd, vd = [_dev(t) for t in (q, k, v)]
     mask = F.build_packed_mask(doc.to(DEV))
     out = F.packed_attention(qd, kd, vd, mask)
     out.backward(do.to(DEV))

@@ -1,0 +1,91 @@
+"""Host logic of the product models on CPU: module wiring, HF parameter names, fused-residual scheduling.
+The ops are the ORACLE's (explicitly injected — the product itself has no CPU path); what is under test
+is everything around them, against the reference-generated goldens."""
+import numpy as np
+import pytest
+import torch
+
+import oracle.ops as oops
+from touchnet_amd.loss.cross_entropy import cross_entropy_loss
+from touchnet_amd.models.backend import use_ops
+from touchnet_amd.models.llama import DecoderConfig, PackedCausalLM, get_num_flop_per_token, get_num_params
+from touchnet_amd.models.qwen2_audio import AudioEncoderConfig
+from touchnet_amd.models.qwen2_audio.modeling_qwen2_audio import Qwen2AudioEncoder
+from touchnet_amd.models.touch_audio import TouchAudioConfig, TouchAudioForCausalLM
+from touchnet_amd.utils.metrics import accuracy
+
+TINY = dict(vocab_size=16, hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=8,
+            num_key_value_heads=4, head_dim=8, rms_norm_eps=1e-5, rope_theta=500000.0, tie_word_embeddings=True,
+            rope_scaling=dict(rope_type="llama3", factor=32.0, low_freq_factor=1.0, high_freq_factor=4.0,
+                              original_max_position_embeddings=64))
+
+
+def _load(model, g, prefix="param/"):
+    sd = {k[len(prefix):]: torch.tensor(g[k]) for k in g.files if k.startswith(prefix)}
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all("lm_head" in m for m in missing), missing          # tied head is absent from HF's named_parameters
+    return sd
+
+
+def _check(model, g, fwd):
+    batch = {k[len("batch/"):]: torch.tensor(g[k]) for k in g.files if k.startswith("batch/")}
+    with use_ops(oops):
+        logits = fwd(batch).logits
+        valid = batch["attention_mask"] > 0
+        np.testing.assert_allclose(logits[valid].detach().numpy(), g["logits"][valid.numpy()], atol=2e-5)
+        ps, pt = cross_entropy_loss(logits, batch["labels"], batch["sentence_lens"], int(batch["num_sentence"]))
+        acc = accuracy(logits, batch["labels"])
+        ps.backward()
+    assert float(ps) == pytest.approx(float(g["loss_per_sample"]), abs=1e-5)
+    assert float(pt) == pytest.approx(float(g["loss_per_token"]), abs=1e-5)
+    assert 0.0 <= float(acc) <= 1.0
+    for name, p in model.named_parameters():
+        np.testing.assert_allclose(p.grad.numpy(), g["grad/" + name], atol=2e-5, err_msg=name)
+
+
+def test_tiny_llama_matches_reference_stack(golden):
+    g = golden("tiny_llama.npz")
+    model = PackedCausalLM(DecoderConfig.from_dict(TINY))
+    _load(model, g)
+    assert {n for n, _ in model.named_parameters()} == {k[len("param/"):] for k in g.files if k.startswith("param/")}
+    _check(model, g, lambda b: model(input_ids=b["input_ids"], position_ids=b["position_ids"],
+                                     attention_mask=b["attention_mask"]))
+
+
+def test_touch_audio_matches_reference(golden):
+    g = golden("touch_audio.npz")
+    model = TouchAudioForCausalLM(TouchAudioConfig(text_config=DecoderConfig.from_dict(TINY), input_size=21))
+    _load(model, g)
+    _check(model, g, lambda b: model(input_ids=b["input_ids"], input_features=b["input_features"],
+                                     position_ids=b["position_ids"], attention_mask=b["attention_mask"]))
+
+
+def test_qwen2_audio_tower_matches_reference(golden):
+    g = golden("qwen2_audio_tower.npz")
+    tower = Qwen2AudioEncoder(AudioEncoderConfig(num_mel_bins=8, d_model=32, encoder_layers=2,
+                                                 encoder_attention_heads=4, encoder_ffn_dim=64,
+                                                 max_source_positions=10))
+    sd = {k[len("param/"):]: torch.tensor(g[k]) for k in g.files if k.startswith("param/")}
+    sd["embed_positions.weight"] = torch.tensor(g["embed_positions"])
+    tower.load_state_dict(sd, strict=True)
+    with use_ops(oops), torch.no_grad():
+        out = tower(torch.tensor(g["mel"]))
+    np.testing.assert_allclose(out.numpy(), g["out"], atol=2e-5)
+
+
+def test_meta_device_construction_and_counts():
+    cfg = DecoderConfig.from_dict(TINY)
+    with torch.device("meta"):
+        m = PackedCausalLM(cfg)
+    assert all(p.is_meta for p in m.parameters())
+    n, ne = get_num_params(m), get_num_params(m, exclude_embedding=True)
+    assert n - ne == 16 * 64 and get_num_flop_per_token(ne, cfg, 32) == 6 * ne + 12 * 2 * 8 * 8 * 32
+
+
+def test_product_ops_refuse_cpu_tensors():
+    """No silent fallback: the HIP wrappers must raise on CPU tensors."""
+    import touchnet_amd.functional as F
+    from touchnet_amd._C import KernelError
+    with pytest.raises((KernelError, ImportError)):
+        F.rms_norm(torch.randn(4, 64), torch.ones(64), 1e-5)

@@ -1,0 +1,166 @@
+"""Packed-sequence Llama / Qwen2 causal LM on the HIP kernels.
+
+Parameter names and shapes are exactly Hugging Face's (`model.embed_tokens.weight`,
+`model.layers.N.self_attn.q_proj.weight`, ..., `lm_head.weight`) so the reference's DCP / HF
+converters and `get_num_params` (touchnet/models/llama/__init__.py:57-67) keep working.
+The arithmetic follows transformers/models/llama/modeling_llama.py:53-67,113-160,174-176,243-324
+(see oracle/nn.py for the line-by-line restatement used as checker), re-scheduled for MI355X:
+
+  * Q/K/V stay in the GEMM output layout [B, T, heads, D]; no transposes, no repeat_kv
+  * residual add is fused into the RMSNorm that follows it (one HBM round trip instead of three)
+  * RoPE tables come from the packed `position_ids` once per forward
+  * attention = LDS-tiled MFMA kernel with document-masked block sparsity; the packers'
+    `attention_mask` (document ids) is turned into tile metadata once per forward
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from ..backend import ops
+from .configuration import DecoderConfig
+
+
+class RMSNorm(nn.Module):
+    def __init__(self, hidden_size, eps):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(hidden_size))
+        self.variance_epsilon = eps
+
+    def forward(self, x, residual=None):
+        return ops().rms_norm(x, self.weight, self.variance_epsilon, residual=residual)
+
+
+class RotaryEmbedding(nn.Module):
+    def __init__(self, config: DecoderConfig):
+        super().__init__()
+        self.config = config
+        self.attention_scaling = 1.0
+        self.register_buffer("inv_freq", self.compute_inv_freq(config), persistent=False)
+
+    @staticmethod
+    def compute_inv_freq(config, device=None):
+        return ops().rope_inv_freq(config.head_dim, config.rope_theta, config.rope_scaling, device=device)
+
+    def forward(self, position_ids, dtype):
+        return ops().rope_tables(position_ids, self.inv_freq, dtype, self.attention_scaling)
+
+
+class Attention(nn.Module):
+    def __init__(self, config: DecoderConfig):
+        super().__init__()
+        H, D = config.hidden_size, config.head_dim
+        self.num_heads, self.num_kv_heads, self.head_dim = config.num_attention_heads, config.num_key_value_heads, D
+        self.q_proj = nn.Linear(H, self.num_heads * D, bias=config.attention_bias)
+        self.k_proj = nn.Linear(H, self.num_kv_heads * D, bias=config.attention_bias)
+        self.v_proj = nn.Linear(H, self.num_kv_heads * D, bias=config.attention_bias)
+        self.o_proj = nn.Linear(self.num_heads * D, H, bias=False)
+        self.scaling = D ** -0.5
+
+    def forward(self, x, cos, sin, mask):
+        B, T, _ = x.shape
+        q = self.q_proj(x).view(B, T, self.num_heads, self.head_dim)
+        k = self.k_proj(x).view(B, T, self.num_kv_heads, self.head_dim)
+        v = self.v_proj(x).view(B, T, self.num_kv_heads, self.head_dim)
+        q, k = ops().apply_rope(q, k, cos, sin)
+        a = ops().packed_attention(q, k, v, mask, self.scaling)
+        return self.o_proj(a.view(B, T, self.num_heads * self.head_dim))
+
+
+class MLP(nn.Module):
+    def __init__(self, config: DecoderConfig):
+        super().__init__()
+        H, I = config.hidden_size, config.intermediate_size
+        self.gate_proj = nn.Linear(H, I, bias=False)
+        self.up_proj = nn.Linear(H, I, bias=False)
+        self.down_proj = nn.Linear(I, H, bias=False)
+
+    def forward(self, x):
+        return self.down_proj(ops().swiglu(self.gate_proj(x), self.up_proj(x)))
+
+
+class DecoderLayer(nn.Module):
+    def __init__(self, config: DecoderConfig):
+        super().__init__()
+        self.self_attn = Attention(config)
+        self.mlp = MLP(config)
+        self.input_layernorm = RMSNorm(config.hidden_size, config.rms_norm_eps)
+        self.post_attention_layernorm = RMSNorm(config.hidden_size, config.rms_norm_eps)
+
+    def forward(self, delta, residual, cos, sin, mask):
+        """`delta` is the previous sub-layer's output still to be added to the `residual` stream."""
+        if residual is None:
+            residual = delta
+            x = self.input_layernorm(delta)
+        else:
+            x, residual = self.input_layernorm(delta, residual)
+        a = self.self_attn(x, cos, sin, mask)
+        x, residual = self.post_attention_layernorm(a, residual)
+        return self.mlp(x), residual
+
+
+class DecoderModel(nn.Module):
+    def __init__(self, config: DecoderConfig):
+        super().__init__()
+        self.config = config
+        self.embed_tokens = nn.Embedding(config.vocab_size, config.hidden_size)
+        self.layers = nn.ModuleList([DecoderLayer(config) for _ in range(config.num_hidden_layers)])
+        self.norm = RMSNorm(config.hidden_size, config.rms_norm_eps)
+        self.rotary_emb = RotaryEmbedding(config)
+
+    def forward(self, input_ids=None, inputs_embeds=None, position_ids=None, attention_mask=None):
+        if inputs_embeds is None:
+            inputs_embeds = self.embed_tokens(input_ids)
+        B, T, _ = inputs_embeds.shape
+        if position_ids is None:
+            position_ids = torch.arange(T, device=inputs_embeds.device).expand(B, T)
+        cos, sin = self.rotary_emb(position_ids, inputs_embeds.dtype)
+        mask = attention_mask
+        if mask is None:                                   # plain causal (Qwen2-Audio training path)
+            mask = ops().causal_mask(B, T, inputs_embeds.device)
+        elif isinstance(mask, torch.Tensor):               # the packers' document ids, [B, T] ints
+            mask = ops().build_packed_mask(mask)
+        delta, residual = inputs_embeds, None
+        for layer in self.layers:
+            delta, residual = layer(delta, residual, cos, sin, mask)
+        h, _ = self.norm(delta, residual)
+        return h
+
+
+class PackedCausalLM(nn.Module):
+    """Drop-in for LlamaForCausalLM / Qwen2ForCausalLM on packed batches
+    (forward(**batch) -> object with `.logits`, the contract of touchnet/bin/train.py:440-452)."""
+    base_model_prefix = "model"
+    config_class = DecoderConfig
+
+    def __init__(self, config: DecoderConfig):
+        super().__init__()
+        self.config = config
+        self.model = DecoderModel(config)
+        self.lm_head = nn.Linear(config.hidden_size, config.vocab_size, bias=False)
+        if config.tie_word_embeddings:
+            self.lm_head.weight = self.model.embed_tokens.weight
+
+    def post_init(self):
+        """HF-style init (normal(0, initializer_range) for Linear/Embedding, ones for norms)."""
+        std = self.config.initializer_range
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.normal_(m.weight, mean=0.0, std=std)
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+            elif isinstance(m, nn.Embedding):
+                nn.init.normal_(m.weight, mean=0.0, std=std)
+            elif isinstance(m, RMSNorm):
+                nn.init.ones_(m.weight)
+
+    def forward(self, input_ids=None, inputs_embeds=None, position_ids=None, attention_mask=None,
+                return_hidden: bool = False, **unused):
+        h = self.model(input_ids=input_ids, inputs_embeds=inputs_embeds, position_ids=position_ids,
+                       attention_mask=attention_mask)
+        if return_hidden:
+            return SimpleNamespace(logits=None, hidden_states=h)
+        return SimpleNamespace(logits=self.lm_head(h), hidden_states=None)

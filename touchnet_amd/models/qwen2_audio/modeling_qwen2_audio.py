@@ -1,0 +1,206 @@
+"""Qwen2-Audio on the HIP path, PACKED: Whisper-style audio tower -> projector -> audio features written
+into the packed token sequence -> Qwen2 decoder with document-masked attention.
+
+What the reference runs (padded, un-packed):
+  tower    touchnet/models/qwen2_audio/__init__.py:18-133 (conv stem, tiled positions :52-73, 32 pre-LN
+           layers with attention FORCED causal :190-193, avg-pool(2), LayerNorm)
+  merge    :186-229 (projector, boolean compaction of valid frames, masked_scatter at the AUDIO tokens)
+  decoder  :231-249 (plain causal SDPA per padded row)
+Here several samples share one packed row; the decoder sees their document ids, which gives every sample
+exactly the causal attention it had in its own padded row (the equivalence
+tests/touchnet/utils/test_pack_loss.py proves for the loss).  Parameter names follow
+Qwen2AudioForConditionalGeneration (transformers 4.51.3): `audio_tower.*`,
+`multi_modal_projector.linear.*`, `language_model.*`.
+"""
+from __future__ import annotations
+
+import json
+from dataclasses import dataclass, field
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as TF
+
+from ..backend import ops
+from ..llama.configuration import DecoderConfig
+from ..llama.modeling_llama import PackedCausalLM
+
+
+@dataclass
+class AudioEncoderConfig:
+    num_mel_bins: int = 128
+    d_model: int = 1280
+    encoder_layers: int = 32
+    encoder_attention_heads: int = 20
+    encoder_ffn_dim: int = 5120
+    max_source_positions: int = 1500
+    init_std: float = 0.02
+
+    @classmethod
+    def from_dict(cls, d):
+        return cls(**{k: d[k] for k in cls.__dataclass_fields__ if k in d})
+
+
+@dataclass
+class Qwen2AudioConfig:
+    audio_config: AudioEncoderConfig = field(default_factory=AudioEncoderConfig)
+    text_config: DecoderConfig = field(default_factory=lambda: DecoderConfig(model_type="qwen2"))
+    audio_token_index: int = 151646
+
+    @classmethod
+    def from_dict(cls, d):
+        tc = dict(d.get("text_config", {}))
+        tc.setdefault("model_type", "qwen2")
+        return cls(audio_config=AudioEncoderConfig.from_dict(d.get("audio_config", {})),
+                   text_config=DecoderConfig.from_dict(tc), audio_token_index=d.get("audio_token_index", 151646))
+
+    @classmethod
+    def from_json_file(cls, path):
+        with open(path) as f:
+            return cls.from_dict(json.load(f))
+
+
+class LayerNorm(nn.Module):
+    def __init__(self, dim, eps=1e-5):
+        super().__init__()
+        self.weight, self.bias, self.eps = nn.Parameter(torch.ones(dim)), nn.Parameter(torch.zeros(dim)), eps
+
+    def forward(self, x, residual=None):
+        return ops().layer_norm(x, self.weight, self.bias, self.eps, residual=residual)
+
+    def reset_parameters(self):
+        nn.init.ones_(self.weight)
+        nn.init.zeros_(self.bias)
+
+
+class EncoderAttention(nn.Module):
+    def __init__(self, dim, heads):
+        super().__init__()
+        self.num_heads, self.head_dim = heads, dim // heads
+        self.k_proj = nn.Linear(dim, dim, bias=False)
+        self.v_proj = nn.Linear(dim, dim, bias=True)
+        self.q_proj = nn.Linear(dim, dim, bias=True)
+        self.out_proj = nn.Linear(dim, dim, bias=True)
+
+    def forward(self, x, mask):
+        B, T, C = x.shape
+        q = self.q_proj(x).view(B, T, self.num_heads, self.head_dim)
+        k = self.k_proj(x).view(B, T, self.num_heads, self.head_dim)
+        v = self.v_proj(x).view(B, T, self.num_heads, self.head_dim)
+        a = ops().packed_attention(q, k, v, mask, self.head_dim ** -0.5)
+        return self.out_proj(a.view(B, T, C))
+
+
+class EncoderLayer(nn.Module):
+    def __init__(self, cfg: AudioEncoderConfig):
+        super().__init__()
+        self.self_attn = EncoderAttention(cfg.d_model, cfg.encoder_attention_heads)
+        self.self_attn_layer_norm = LayerNorm(cfg.d_model)
+        self.fc1 = nn.Linear(cfg.d_model, cfg.encoder_ffn_dim)
+        self.fc2 = nn.Linear(cfg.encoder_ffn_dim, cfg.d_model)
+        self.final_layer_norm = LayerNorm(cfg.d_model)
+
+    def forward(self, delta, residual, mask):
+        if delta is None:
+            x = self.self_attn_layer_norm(residual)
+        else:
+            x, residual = self.self_attn_layer_norm(delta, residual)
+        a = self.self_attn(x, mask)
+        x, residual = self.final_layer_norm(a, residual)
+        return self.fc2(ops().gelu(self.fc1(x))), residual
+
+
+class Qwen2AudioEncoder(nn.Module):
+    def __init__(self, cfg: AudioEncoderConfig):
+        super().__init__()
+        self.config = cfg
+        self.conv1 = nn.Conv1d(cfg.num_mel_bins, cfg.d_model, kernel_size=3, padding=1)
+        self.conv2 = nn.Conv1d(cfg.d_model, cfg.d_model, kernel_size=3, stride=2, padding=1)
+        self.embed_positions = nn.Embedding(cfg.max_source_positions, cfg.d_model)
+        self.embed_positions.requires_grad_(False)
+        self.layers = nn.ModuleList([EncoderLayer(cfg) for _ in range(cfg.encoder_layers)])
+        self.layer_norm = LayerNorm(cfg.d_model)
+
+    def positions(self, seq_len):
+        """qwen2_audio/__init__.py:52-73: slice the table, or tile it for audio longer than 30 s."""
+        pos = self.embed_positions.weight
+        n = pos.shape[0]
+        if n >= seq_len:
+            return pos[:seq_len]
+        reps, rem = divmod(seq_len, n)
+        return torch.cat([pos] * reps + ([pos[:rem]] if rem else []), dim=0)
+
+    def forward(self, input_features):
+        """mel [n, num_mel_bins, Tm] -> [n, Tm // 4, d_model]"""
+        x = input_features.to(self.conv1.weight.dtype)
+        x = ops().gelu(self.conv1(x))
+        x = ops().gelu(self.conv2(x))
+        h = x.permute(0, 2, 1).contiguous()
+        h = h + self.positions(h.shape[1])[None].to(h.dtype)
+        n, T, _ = h.shape
+        mask = ops().causal_mask(n, T, h.device)           # is_causal forced True (:190-193), per sample
+        delta, residual = None, h
+        for layer in self.layers:
+            delta, residual = layer(delta, residual, mask)
+        h = residual + delta
+        h = TF.avg_pool1d(h.permute(0, 2, 1), 2, 2).permute(0, 2, 1).contiguous()
+        return self.layer_norm(h)
+
+
+class MultiModalProjector(nn.Module):
+    def __init__(self, d_in, d_out):
+        super().__init__()
+        self.linear = nn.Linear(d_in, d_out, bias=True)
+
+    def forward(self, x):
+        return self.linear(x)
+
+
+class Qwen2AudioPackedForConditionalGeneration(nn.Module):
+    config_class = Qwen2AudioConfig
+    base_model_prefix = "language_model"
+
+    def __init__(self, config: Qwen2AudioConfig):
+        super().__init__()
+        self.config = config
+        self.audio_tower = Qwen2AudioEncoder(config.audio_config)
+        self.multi_modal_projector = MultiModalProjector(config.audio_config.d_model, config.text_config.hidden_size)
+        self.language_model = PackedCausalLM(config.text_config)
+
+    def post_init(self):
+        self.language_model.post_init()
+        std = self.config.audio_config.init_std
+        for m in list(self.audio_tower.modules()) + list(self.multi_modal_projector.modules()):
+            if isinstance(m, (nn.Linear, nn.Conv1d)):
+                nn.init.normal_(m.weight, mean=0.0, std=std)
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+            elif isinstance(m, nn.Embedding):
+                nn.init.normal_(m.weight, mean=0.0, std=std)
+            elif isinstance(m, LayerNorm):
+                m.reset_parameters()
+
+    def forward(self, input_ids=None, input_features=None, audio_output_lengths=None, audio_positions=None,
+                attention_mask=None, position_ids=None, return_hidden: bool = False, **unused):
+        """input_ids [B, T] packed, AUDIO placeholder tokens where audio features go;
+        input_features [n_audio, n_mels, Tm]; audio_output_lengths int64 [n_audio] (valid tokens per audio,
+        `((L-1)//2+1-2)//2+1`, processing_qwen2_audio.py:79-82); audio_positions int64 [sum(lengths)] flat
+        indices into B*T (computed from input_ids when omitted — that costs a host sync)."""
+        emb = self.language_model.model.embed_tokens(input_ids)
+        B, T, H = emb.shape
+        if input_features is not None:
+            feats = self.multi_modal_projector(self.audio_tower(input_features))        # [n, Ta, H]
+            n, Ta, _ = feats.shape
+            if audio_output_lengths is not None:
+                keep = torch.arange(Ta, device=feats.device)[None, :] < audio_output_lengths[:, None]
+                feats = feats[keep]                                                      # `:202-205`
+            else:
+                feats = feats.reshape(n * Ta, H)
+            if audio_positions is None:
+                audio_positions = (input_ids.reshape(-1) == self.config.audio_token_index).nonzero().squeeze(1)
+            if feats.shape[0] != audio_positions.numel():
+                raise ValueError(f"audio features ({feats.shape[0]}) and audio tokens "
+                                 f"({audio_positions.numel()}) mismatch")
+            emb = emb.reshape(B * T, H).index_copy(0, audio_positions, feats.to(emb.dtype)).view(B, T, H)
+        return self.language_model(inputs_embeds=emb, position_ids=position_ids, attention_mask=attention_mask,
+                                   return_hidden=return_hidden)
