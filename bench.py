@@ -1,0 +1,343 @@
+#!/usr/bin/env python
+"""Headline benchmark of the MI355X packed-sequence training path (contract: see the task statement).
+
+    python bench.py --gpus 1 --steps K --warmup W                      # one MI355X
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W      # N MI355X, FSDP2 over RCCL/xGMI
+
+One "step" = one full training step on one packed batch per GPU (weak scaling): device-side audio
+frontend (waveform -> log-mel / fbank) -> model forward -> fused lm_head + packed CE -> backward ->
+global-norm clip + AdamW.  Nothing is skipped or cached inside the timed region; inputs (waveforms, token
+buffers) are resident in HBM before it starts.
+
+Workloads (BASELINE.json `configs`):
+    qwen2_audio_7b  (default) Qwen2-Audio-7B ASR SFT, packed B=2 x T=8192 per GPU   <- the metric's config
+    llama_asr_1b              LlamaForASR-1B, fbank-80 stack5/stride4, packed B=1 x T=8192
+    tiny                      2-layer d=256 smoke configuration
+Weights are random-init (HF init, seed 2025), data is synthetic: there is no network for checkpoints/datasets.
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_PEAK = 2.5e15   # dense bf16 FLOP/s per MI355X (MI355X_MICROARCH.md; vendor 5 PF figure is 2:1 sparse)
+HBM_PEAK = 8.0e12
+
+
+def qwen2_audio_7b_config():
+    from touchnet_amd.models.qwen2_audio import Qwen2AudioConfig
+    # examples/audio/sft/asr/wenetspeech/config/Qwen2-Audio-7B.json (shape source)
+    return Qwen2AudioConfig.from_dict({
+        "audio_config": {"d_model": 1280, "encoder_attention_heads": 20, "encoder_ffn_dim": 5120,
+                         "encoder_layers": 32, "max_source_positions": 1500, "num_mel_bins": 128,
+                         "init_std": 0.02},
+        "audio_token_index": 151646,
+        "text_config": {"model_type": "qwen2", "hidden_size": 4096, "intermediate_size": 11008,
+                        "num_attention_heads": 32, "num_hidden_layers": 32, "num_key_value_heads": 32,
+                        "rms_norm_eps": 1e-5, "rope_theta": 10000, "vocab_size": 156032,
+                        "initializer_range": 0.02, "tie_word_embeddings": False}})
+
+
+def llama_1b_text_config():
+    from touchnet_amd.models.llama import DecoderConfig
+    # examples/text/pretrain/fineweb-edu/config/Llama-3_2-1B.json
+    return DecoderConfig.from_dict({
+        "model_type": "llama", "hidden_size": 2048, "intermediate_size": 8192, "num_attention_heads": 32,
+        "num_hidden_layers": 16, "num_key_value_heads": 8, "head_dim": 64, "rms_norm_eps": 1e-5,
+        "rope_theta": 500000.0, "vocab_size": 128256, "tie_word_embeddings": True, "initializer_range": 0.02,
+        "rope_scaling": {"factor": 32.0, "high_freq_factor": 4.0, "low_freq_factor": 1.0,
+                         "original_max_position_embeddings": 8192, "rope_type": "llama3"}})
+
+
+def tiny_text_config():
+    from touchnet_amd.models.llama import DecoderConfig
+    return DecoderConfig.from_dict({
+        "model_type": "llama", "hidden_size": 256, "intermediate_size": 512, "num_attention_heads": 4,
+        "num_hidden_layers": 2, "num_key_value_heads": 2, "head_dim": 64, "rms_norm_eps": 1e-5,
+        "rope_theta": 500000.0, "vocab_size": 1024, "tie_word_embeddings": True, "initializer_range": 0.02})
+
+
+class Workload:
+    """Holds the device-resident inputs of one rank and produces the batch dict inside the timed step."""
+
+    def __init__(self, name, device, rank, B=None, T=None):
+        import touchnet_amd.functional as F
+        from touchnet_amd.bin.train import TrainConfig
+        from touchnet_amd.data import synthetic
+        from touchnet_amd.models.touch_audio import TouchAudioConfig
+        self.name, self.device, self.F = name, device, F
+        seed = 2025 + rank
+        self.job = TrainConfig()
+        if name == "qwen2_audio_7b":
+            self.B, self.T = B or 2, T or 8192
+            self.job.training_model_name = "qwen2_audio_mi355"
+            self.job.lr_scheduler_lr = 2e-5
+            self.model_config = qwen2_audio_7b_config()
+            self.seq_cfg = self.model_config.text_config
+            tok, n_audio = synthetic.qwen2_audio_plan(self.seq_cfg.vocab_size, self.model_config.audio_token_index,
+                                                      self.B, self.T, seed)
+            g = torch.Generator().manual_seed(seed)
+            # 30 s-padded utterances (WhisperFeatureExtractor padding="max_length"): speech-shaped noise for
+            # U[2, 14.5] s, zeros to 30 s.  The frontend runs on all 480 000 samples, like the reference.
+            wav = torch.zeros(n_audio, 480000)
+            for i in range(n_audio):
+                n = int(float(torch.empty(1).uniform_(2.0, 14.5, generator=g)) * 16000)
+                wav[i, :n] = (torch.randn(n, generator=g) * 0.1).clamp_(-1, 1)
+            self.wav = wav.to(device)
+            self.tokens = {k: (v.to(device) if isinstance(v, torch.Tensor) else v) for k, v in tok.items()}
+            self.data_desc = (f"synthetic: {n_audio} x 30 s-padded 16 kHz clips/GPU -> 750 audio tokens each, "
+                              f"~14-token prompt, U{{5..40}}-token transcripts, packed B={self.B} x T={self.T}")
+        elif name in ("llama_asr_1b", "tiny"):
+            text = llama_1b_text_config() if name == "llama_asr_1b" else tiny_text_config()
+            self.B, self.T = B or 1, T or (8192 if name == "llama_asr_1b" else 512)
+            self.job.training_model_name = "touch_audio_mi355"
+            self.model_config = TouchAudioConfig(text_config=text, input_size=400)
+            self.seq_cfg = text
+            self.utts, _ = synthetic.asr_waveforms(self.T, self.B, seed)
+            g = torch.Generator().manual_seed(seed)
+            self.wavs = [(torch.randn(n, generator=g) * 0.1).clamp_(-1, 1).to(device) for n, _ in self.utts]
+            self.seed = seed
+            self.data_desc = (f"synthetic AISHELL-shaped: U[1.5,14.5] s 16 kHz clips, U{{4..25}}-token "
+                              f"transcripts, fbank80 stack5/stride4, packed B={self.B} x T={self.T}")
+        else:
+            raise SystemExit(f"unknown workload {name}")
+
+    def make_batch(self):
+        """Runs the device frontend and returns the batch dict (everything already on the device)."""
+        F = self.F
+        if self.name == "qwen2_audio_7b":
+            mel = torch.stack([F.log_mel_spectrogram(w, 128) for w in self.wav])       # [n, 3000, 128]
+            batch = dict(self.tokens)
+            batch["input_features"] = mel.transpose(1, 2)                              # [n, 128, 3000]
+            return batch
+        from touchnet_amd.data.synthetic import asr_batch_from_device_frontend
+        batch, _, _ = asr_batch_from_device_frontend(self.seq_cfg.vocab_size, self.B, self.T, self.device,
+                                                     seed=self.seed, frontend=F, wavs=self.wavs, utts=self.utts)
+        return batch
+
+
+def cpu_baseline(workload: "Workload", seconds_budget: float = 20.0):
+    """The reference's CPU path timed beside the GPU number: it has no CPU training entry point
+    (SURVEY.md §0 fact 5), so this is the ORACLE restatement (oracle/nn.py + oracle/loss.py: eager HF maths +
+    reference loss) in fp32 on the host cores — a bounded sample: ONE decoder block forward+backward at the
+    workload's widths on T=256 tokens plus the lm_head+CE on 64 tokens, extrapolated x layers to tokens/s.
+    It is a reported baseline ("port"), never the measured product path."""
+    from oracle import loss as oloss
+    from oracle import nn as onn
+    cfg = workload.seq_cfg
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    T = 256
+    H, I, Nh, Nkv, D, V = (cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads,
+                           cfg.num_key_value_heads, cfg.head_dim, cfg.vocab_size)
+    g = torch.Generator().manual_seed(0)
+    sd = {"l.input_layernorm.weight": torch.ones(H), "l.post_attention_layernorm.weight": torch.ones(H)}
+    for n, (o, i) in {"self_attn.q_proj": (Nh * D, H), "self_attn.k_proj": (Nkv * D, H),
+                      "self_attn.v_proj": (Nkv * D, H), "self_attn.o_proj": (H, Nh * D),
+                      "mlp.gate_proj": (I, H), "mlp.up_proj": (I, H), "mlp.down_proj": (H, I)}.items():
+        sd[f"l.{n}.weight"] = (torch.randn(o, i, generator=g) * 0.02).requires_grad_()
+    c = dict(num_attention_heads=Nh, num_key_value_heads=Nkv, head_dim=D, rms_norm_eps=cfg.rms_norm_eps)
+    doc = torch.ones(1, T, dtype=torch.int64)
+    pos = torch.arange(T)[None]
+    inv = onn.rope_inv_freq(D, cfg.rope_theta, cfg.rope_scaling)
+    cos, sin = onn.rope_cos_sin(pos, inv, torch.float32)
+    allow = onn.doc_causal_allow(doc)
+    x = torch.randn(1, T, H, generator=g).requires_grad_()
+
+    def block():
+        y = onn.decoder_layer(sd, "l.", c, x, cos, sin, allow)
+        y.sum().backward()
+    block()
+    t0, n = time.perf_counter(), 0
+    while time.perf_counter() - t0 < seconds_budget * 0.6 or n < 2:
+        block()
+        n += 1
+    t_block = (time.perf_counter() - t0) / n / T                       # s per token per layer
+    Th = 64
+    w = (torch.randn(V, H, generator=g) * 0.02).requires_grad_()
+    hh = torch.randn(1, Th, H, generator=g).requires_grad_()
+    labels = torch.randint(0, V, (1, Th), generator=g)
+
+    def head():
+        ps, _ = oloss.cross_entropy_loss(torch.nn.functional.linear(hh, w), labels, torch.full((1, Th), 8), 8)
+        ps.backward()
+    head()
+    t0, n = time.perf_counter(), 0
+    while time.perf_counter() - t0 < seconds_budget * 0.3 or n < 2:
+        head()
+        n += 1
+    t_head = (time.perf_counter() - t0) / n / Th
+    per_token = t_block * cfg.num_hidden_layers + t_head
+    return {"value": round(1.0 / per_token, 2), "unit": "tokens/s (extrapolated)", "cores": cores, "kind": "port",
+            "sample": f"oracle fp32 eager: 1 decoder block fwd+bwd on T={T} tokens x{cfg.num_hidden_layers} layers "
+                      f"+ lm_head/CE on {Th} tokens; attention cost at T={T} (not {workload.T}), audio tower and "
+                      f"optimizer excluded -> an upper bound on CPU throughput"}
+
+
+def kernel_rooflines(workload: "Workload"):
+    """Live HIP-event timings (on torch's current stream = the stream the C ABI is given) of the hand-written
+    kernels at this workload's shapes: achieved algorithmic bytes/flops per launch vs the roofline."""
+    F, dev, cfg = workload.F, workload.device, workload.seq_cfg
+    B, T = workload.B, workload.T
+    N, H, I, Nh, Nkv, D = (B * T, cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads,
+                           cfg.num_key_value_heads, cfg.head_dim)
+    bf = torch.bfloat16
+    out = []
+
+    def t_ms(fn, it=10):
+        for _ in range(3):
+            fn()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(it):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        return s.elapsed_time(e) / it
+
+    def add(name, ms, bytes_=None, flops=None):
+        if bytes_ is not None:
+            a = bytes_ / (ms * 1e-3) / 1e9
+            out.append({"kernel": name, "bound": "hbm", "ms": round(ms, 4), "achieved": round(a, 1),
+                        "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(a * 1e9 / HBM_PEAK, 3)})
+        else:
+            a = flops / (ms * 1e-3) / 1e12
+            out.append({"kernel": name, "bound": "mfma", "ms": round(ms, 4), "achieved": round(a, 1),
+                        "peak": MFMA_PEAK / 1e12, "unit": "TFLOP/s", "frac": round(a * 1e12 / MFMA_PEAK, 3)})
+    x = torch.randn(N, H, dtype=bf, device=dev)
+    r = torch.randn(N, H, dtype=bf, device=dev)
+    w = torch.ones(H, dtype=bf, device=dev)
+    add("add+rmsnorm fwd", t_ms(lambda: F.rms_norm(x, w, 1e-5, residual=r)), bytes_=4 * N * H * 2)
+    g_, u_ = torch.randn(N, I, dtype=bf, device=dev), torch.randn(N, I, dtype=bf, device=dev)
+    add("swiglu fwd", t_ms(lambda: F.swiglu(g_, u_)), bytes_=3 * N * I * 2)
+    del g_, u_
+    doc = workload.tokens["attention_mask"] if hasattr(workload, "tokens") else torch.ones(B, T, device=dev)
+    mask = F.build_packed_mask(doc)
+    q = torch.randn(B, T, Nh, D, dtype=bf, device=dev)
+    k = torch.randn(B, T, Nkv, D, dtype=bf, device=dev)
+    v = torch.randn(B, T, Nkv, D, dtype=bf, device=dev)
+    allowed = 0
+    for row in doc.cpu().numpy():
+        ids, counts = np.unique(row[row > 0], return_counts=True)
+        allowed += int(sum(int(c) * (int(c) + 1) // 2 for c in counts))
+    fl = 4.0 * D * Nh * allowed
+    add("packed attention fwd (true masked flops)", t_ms(lambda: F.packed_attention(q, k, v, mask)), flops=fl)
+    qg, kg, vg = [t.clone().requires_grad_() for t in (q, k, v)]
+    o = F.packed_attention(qg, kg, vg, mask)
+    do = torch.randn_like(o)
+    add("packed attention bwd (true masked flops)",
+        t_ms(lambda: torch.autograd.grad(o, [qg, kg, vg], do, retain_graph=True)), flops=2.5 * fl)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default=os.environ.get("TN_BENCH_WORKLOAD", "qwen2_audio_7b"))
+    ap.add_argument("--batch", type=int, default=None)
+    ap.add_argument("--seqlen", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-rooflines", action="store_true")
+    ap.add_argument("--unfused-ce", action="store_true")
+    args = ap.parse_args()
+
+    import touchnet_amd.specs  # noqa: F401  (registers the TrainSpecs)
+    from touchnet_amd.bin.train import Trainer
+    from touchnet_amd.utils.distributed import build_dp_mesh, init_distributed
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    rank, local, world = init_distributed("cuda")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    device = torch.device("cuda", local)
+    mesh = build_dp_mesh("cuda", world) if world > 1 else None
+
+    wl = Workload(args.workload, device, rank, args.batch, args.seqlen)
+    wl.job.training_enable_fused_ce = not args.unfused_ce
+    trainer = Trainer(wl.job, wl.model_config, device, dp_mesh=mesh)
+
+    def step():
+        batch = trainer.next_batch(wl.make_batch())
+        return trainer.train_step(batch)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        stats = step()
+    fence()
+    torch.cuda.reset_peak_memory_stats()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        stats = step()
+    ev1.record()
+    fence()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t)
+    ev_ms = ev0.elapsed_time(ev1) / args.steps
+
+    tokens_per_step = wl.B * wl.T * world                       # reference convention: labels.numel() (train.py:345)
+    tps = tokens_per_step * args.steps / elapsed
+    fpt = trainer.spec.get_num_flop_per_token_fn(trainer.num_params_wo_emb, wl.model_config, wl.T)
+    mfu = fpt * (tps / world) / MFMA_PEAK
+    nonpad = int((wl.tokens["attention_mask"] > 0).sum()) if hasattr(wl, "tokens") else None
+    loss = float(stats["loss_per_sample"])
+    if rank == 0:
+        line = {
+            "metric": "audio+text tokens/sec/node (packed seq, full train step) + step MFU",
+            "value": round(tps, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": wl.data_desc + "; random-init weights",
+            "config": {"workload": wl.name, "model": wl.job.training_model_name, "global_batch": wl.B * world,
+                       "seq_len": wl.T, "parallelism": f"fsdp2-dp{world}" if world > 1 else "single-gpu",
+                       "params": trainer.num_params, "flop_per_token": fpt,
+                       "fused_linear_ce": wl.job.training_enable_fused_ce},
+            "step_mfu": round(mfu, 4),
+            "mfu_convention": "6*N_wo_emb + 12*L*H*Dh*T per token (touchnet/models/*/__init__.py), no causal/packing "
+                              "discount, no recompute credit, tokens = all B*T slots incl. pad",
+            "nonpad_tokens_per_step_rank0": nonpad,
+            "loss_per_sample_last": round(loss, 5), "hip_event_ms_per_step_rank0": round(ev_ms, 2),
+            "peak_mem_GB_rank0": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
+            "roofline": {"bound": "mfma", "achieved": round(fpt * (tps / world) / 1e12, 1), "peak": MFMA_PEAK / 1e12,
+                         "unit": "TFLOP/s", "frac": round(mfu, 4), "traffic": None,
+                         "note": "whole training step per GPU against the dense bf16 MFMA peak (reference MFU "
+                                 "formula); per-kernel rooflines of the hand-written HIP kernels in `kernels`"},
+        }
+        if not args.no_kernel_rooflines and args.workload != "tiny":
+            try:
+                line["kernels"] = kernel_rooflines(wl)
+            except Exception as e:  # never lose the headline number to a diagnostics failure
+                line["kernels_error"] = repr(e)
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(wl)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,120 @@
+"""Step driver for the packed path.
+
+The reference's touchnet/bin/train.py cannot run with WORLD_SIZE=1 nor on a host without a GPU
+(SURVEY.md §0 fact 5), so the single-GPU configurations need a driver of their own; with more ranks the
+same code path runs under FSDP2 exactly as `Trainer.train_step` does (train.py:395-506), minus its host
+synchronisations:
+
+  next_batch   train.py:334-393   H2D copy, global `num_sentence` = SUM over dp   (device all-reduce)
+  train_step   train.py:395-506   zero_grad -> forward -> loss_fn/acc_fn -> backward -> clip -> AdamW
+                                  (NaN/Inf grad norm skips the update — decided on the device)
+
+It consumes a TrainSpec (touchnet_amd.utils.train_spec, the reference's registry surface), so the model
+families are switched by `training_model_name` exactly like in the reference.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+from touchnet_amd.loss.cross_entropy import fused_linear_cross_entropy
+from touchnet_amd.models.helper_func import apply_fsdp
+from touchnet_amd.utils.distributed import dist_sum
+from touchnet_amd.utils.optimizer import FusedAdamW, linear_warmup_linear_decay
+from touchnet_amd.utils.train_spec import TrainSpec, get_train_spec
+
+
+@dataclass
+class TrainConfig:
+    """The subset of touchnet/bin/__init__.py:65-642 the step needs (same field names)."""
+    training_model_name: str = "llama_mi355"
+    training_seed: int = 2025
+    training_max_norm: float = 1.0
+    training_mixed_precision_param: str = "bfloat16"
+    training_mixed_precision_reduce: str = "float32"
+    training_fsdp_reshard_after_forward: str = "never"
+    training_enable_fused_ce: bool = True      # role of `training_enable_liger_kernel`'s fused-linear-CE branch
+    training_ce_chunk_tokens: int = 16384
+    lr_scheduler_lr: float = 8e-4
+    lr_scheduler_warmup_steps: int = 2000
+    lr_scheduler_steps: int = 100000
+    optimizer_weight_decay: float = 0.1
+
+
+class Trainer:
+    def __init__(self, job: TrainConfig, model_config, device: torch.device, dp_mesh=None,
+                 spec: Optional[TrainSpec] = None):
+        self.job, self.device, self.dp_mesh = job, device, dp_mesh
+        self.spec = spec or get_train_spec(job.training_model_name)
+        self.dp_group = dp_mesh.get_group() if dp_mesh is not None else None
+        self.dp_world = dp_mesh.size() if dp_mesh is not None else 1
+        if self.spec.additional_pre_init_fn:
+            self.spec.additional_pre_init_fn(job)                      # train.py:121-122
+        torch.manual_seed(job.training_seed)
+        with torch.device("meta"):                                     # train.py:179-182
+            model = self.spec.model_cls(model_config)
+        self.model_config = model_config
+        self.num_params = self.spec.get_num_params_fn(model)
+        self.num_params_wo_emb = self.spec.get_num_params_fn(model, exclude_embedding=True)
+        if dp_mesh is not None and self.dp_world > 1:
+            model = self.spec.parallelize_fn(model, dp_mesh, job)      # fp32 shards, bf16 compute
+            model.to_empty(device=device)
+            with torch.no_grad():
+                model.post_init()
+                if self.spec.additional_post_init_fn:
+                    self.spec.additional_post_init_fn(model, device)
+        else:
+            model.to_empty(device=device)
+            with torch.no_grad():
+                model.post_init()
+                if self.spec.additional_post_init_fn:
+                    self.spec.additional_post_init_fn(model, device)
+            if device.type == "cuda":
+                model.to(getattr(torch, job.training_mixed_precision_param))
+        self.model = model
+        self.optimizer = FusedAdamW(model.parameters(), lr=job.lr_scheduler_lr,
+                                    weight_decay=job.optimizer_weight_decay, max_norm=job.training_max_norm,
+                                    process_group=self.dp_group if self.dp_world > 1 else None)
+        self.step = 0
+
+    # ------------------------------------------------------------------ data
+    def next_batch(self, batch: dict) -> dict:
+        out = {}
+        for k, v in batch.items():
+            out[k] = v.to(self.device, non_blocking=True) if isinstance(v, torch.Tensor) else v
+        ns = out["num_sentence"]
+        ns = ns.to(self.device, torch.float32) if isinstance(ns, torch.Tensor) else torch.tensor(
+            float(ns), dtype=torch.float32, device=self.device)
+        out["num_sentence"] = dist_sum(ns.reshape(1), self.dp_group)   # global over dp (train.py:339-343)
+        return out
+
+    # ------------------------------------------------------------------ step
+    def forward_loss(self, data: dict):
+        data = dict(data)
+        labels, ns, sl = data.pop("labels"), data.pop("num_sentence"), data.pop("sentence_lens")
+        data.pop("shift_labels", None)
+        if self.job.training_enable_fused_ce:
+            out = self.model(**data, return_hidden=True)
+            lm = getattr(self.model, "language_model", self.model)
+            return fused_linear_cross_entropy(out.hidden_states, lm.lm_head.weight, labels, sl, ns,
+                                              chunk_tokens=self.job.training_ce_chunk_tokens)
+        pred = self.model(**data)
+        loss, per_token = self.spec.loss_fn(pred.logits, labels, sl, ns)
+        acc = self.spec.acc_fn(pred.logits, labels) if self.spec.acc_fn else None
+        return loss, per_token, acc
+
+    def train_step(self, data: dict) -> dict:
+        self.optimizer.zero_grad()
+        loss, per_token, acc = self.forward_loss(data)
+        # Exactly the reference (train.py:456): backward on the loss normalised by the GLOBAL num_sentence;
+        # FSDP2's reduce-scatter then AVERAGES over dp, i.e. gradients are 1/dp of the global-batch mean
+        # gradient.  We keep that scale for parity (AdamW is invariant to it, the clip threshold is not).
+        loss.backward()
+        lr = self.job.lr_scheduler_lr * linear_warmup_linear_decay(
+            self.step, self.job.lr_scheduler_warmup_steps, self.job.lr_scheduler_steps)
+        grad_norm = self.optimizer.step(lr)
+        self.step += 1
+        return {"loss_per_sample": loss.detach(), "loss_per_token": per_token, "acc": acc, "grad_norm": grad_norm}

@@ -1,0 +1,119 @@
+"""Synthetic packed batches of the shapes BASELINE.json / SURVEY.md §8d name (no datasets or checkpoints
+are reachable: weights are random-init, data is synthetic — and says so in every bench line).
+
+All generators are seeded with the reference's default seed 2025 (touchnet/bin/__init__.py:223-228) plus
+the dp rank, and go through the SAME packers the real datapipe ends with.
+"""
+from __future__ import annotations
+
+import types
+
+import numpy as np
+import torch
+
+from touchnet_amd.models.llama.processing_llama import batch_text
+from touchnet_amd.models.touch_audio.processing_touch_audio import batch_pairaudio_pairtext_packed
+
+
+def _tok(vocab):
+    return types.SimpleNamespace(bos=1, eos=2, pad=0)
+
+
+def text_batch(vocab: int, batchsize: int, seqlen: int, seed: int = 2025, min_len: int = 1, max_len: int = 12):
+    """Config A: sentences of U{min..max} tokens packed into [B, T]."""
+    rng = np.random.RandomState(seed)
+    cfg = types.SimpleNamespace(dataset_batchsize=batchsize, dataset_text_seqlen=seqlen,
+                                dataloader_drop_last_batch=False)
+
+    def gen():
+        while True:
+            n = int(rng.randint(min_len, max_len + 1))
+            yield {"input_ids": [int(v) for v in rng.randint(3, vocab, size=n)]}
+    return next(iter(batch_text(gen(), cfg, _tok(vocab))))
+
+
+def asr_waveforms(seqlen: int, batchsize: int, seed: int = 2025, frames_per_sec: float = 25.0,
+                  min_s: float = 1.5, max_s: float = 14.5, min_tok: int = 4, max_tok: int = 25):
+    """Config B: AISHELL-shaped utterances — duration U[1.5, 14.5] s of N(0, 0.1^2) noise clipped to
+    [-1, 1] at 16 kHz, transcripts of U{4..25} tokens; enough of them to fill B rows of T slots."""
+    rng = np.random.RandomState(seed)
+    utts, slots = [], 0
+    while slots < batchsize * seqlen * 1.05:
+        dur = float(rng.uniform(min_s, max_s))
+        n = int(dur * 16000)
+        ntok = int(rng.randint(min_tok, max_tok + 1))
+        utts.append((n, ntok))
+        slots += int(dur * frames_per_sec) + ntok + 1
+    return utts, rng
+
+
+def asr_batch_from_device_frontend(vocab: int, batchsize: int, seqlen: int, device, num_mel_bins: int = 80,
+                                   stack: int = 5, stride: int = 4, seed: int = 2025, frontend=None, wavs=None,
+                                   utts=None):
+    """waveform (on device) -> kaldi fbank -> stack/stride/normalise (HIP kernels) -> packed ASR batch.
+    `frontend` = op namespace (touchnet_amd.functional on the GPU).  Returns (batch, wavs, utts) so a
+    benchmark can keep the waveforms resident and re-run the frontend inside the timed step."""
+    if utts is None:
+        utts, rng = asr_waveforms(seqlen, batchsize, seed)
+    else:
+        rng = np.random.RandomState(seed + 1)
+    if wavs is None:
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        wavs = [(torch.randn(n, generator=g) * 0.1).clamp_(-1, 1).to(device) for n, _ in utts]
+    tok_rng = np.random.RandomState(seed + 7)
+    cfg = types.SimpleNamespace(dataset_batchsize=batchsize, dataset_text_seqlen=seqlen, dataset_audio_seqlen=seqlen,
+                                audiofeat_num_mel_bins=num_mel_bins, audiofeat_stack_length=stack,
+                                dataloader_drop_last_batch=False)
+
+    def gen():
+        for wav, (_, ntok) in zip(wavs, utts):
+            feat = frontend.audiofeat_stack(frontend.kaldi_fbank(wav, num_mel_bins), stack, stride, True)
+            yield {"audiofeat": feat, "input_ids": [int(v) for v in tok_rng.randint(3, vocab, size=ntok)]}
+    batch = next(iter(batch_pairaudio_pairtext_packed(gen(), cfg, _tok(vocab))))
+    return batch, wavs, utts
+
+
+def qwen2_audio_plan(vocab: int, audio_token: int, batchsize: int, seqlen: int, seed: int = 2025,
+                     audio_tokens: int = 750, prompt_pre: int = 8, prompt_post: int = 6, min_resp: int = 5,
+                     max_resp: int = 40):
+    """Config C (Qwen2-Audio-7B ASR SFT, packed — beyond what the reference can run):
+    per sample a 30 s-padded utterance -> 750 AUDIO placeholder tokens inside a ~14-token prompt, then a
+    response of U{5..40} tokens + eos.  Labels follow processing_qwen2_audio.py:96-104: -100 on the prompt
+    (pre-shifted), response + eos after it; sentence_lens = len(response) + 1 over the whole sample.
+    Samples are packed greedily into [B, T] with document ids and per-sample position ids.
+    Returns the int64 batch tensors + the number of audio clips (their waveforms are made by the caller)."""
+    rng = np.random.RandomState(seed)
+    B, T = batchsize, seqlen
+    input_ids = np.zeros((B, T), dtype=np.int64)
+    labels = np.full((B, T), -100, dtype=np.int64)
+    position_ids = np.zeros((B, T), dtype=np.int64)
+    doc = np.zeros((B, T), dtype=np.int64)
+    sentence_lens = np.ones((B, T), dtype=np.int64)
+    audio_pos, n_sent = [], 0
+    for b in range(B):
+        col, d = 0, 1
+        while True:
+            nresp = int(rng.randint(min_resp, max_resp + 1))
+            plen = prompt_pre + audio_tokens + prompt_post
+            tot = plen + nresp
+            if col + tot > T:
+                break
+            ids = np.concatenate([rng.randint(3, vocab - 2000, size=prompt_pre),
+                                  np.full(audio_tokens, audio_token),
+                                  rng.randint(3, vocab - 2000, size=prompt_post),
+                                  rng.randint(3, vocab - 2000, size=nresp)])
+            input_ids[b, col:col + tot] = ids
+            labels[b, col + plen - 1:col + tot - 1] = ids[plen:]
+            labels[b, col + tot - 1] = 2                                   # eos
+            position_ids[b, col:col + tot] = np.arange(tot)
+            doc[b, col:col + tot] = d
+            sentence_lens[b, col:col + tot] = nresp + 1
+            audio_pos.append(b * T + col + prompt_pre + np.arange(audio_tokens))
+            col += tot
+            d += 1
+            n_sent += 1
+    t = torch.from_numpy
+    return {"input_ids": t(input_ids), "labels": t(labels), "position_ids": t(position_ids),
+            "attention_mask": t(doc), "sentence_lens": t(sentence_lens), "num_sentence": n_sent,
+            "audio_positions": t(np.concatenate(audio_pos)),
+            "audio_output_lengths": torch.full((n_sent,), audio_tokens, dtype=torch.int64)}, n_sent

@@ -21,7 +21,8 @@ def _emit_asr(buf: PackBuffer, feats, sentences, feat_dim, bos, eos, pad):
     position_ids = np.zeros(B * T, dtype=np.int64)
     attention_mask = np.zeros(B * T, dtype=np.int64)
     sentence_lens = np.ones(B * T, dtype=np.int64)
-    input_features = torch.zeros(B, T, feat_dim, dtype=torch.float32)
+    dev = feats[0].device if feats else torch.device("cpu")   # a device-side frontend keeps features in HBM
+    input_features = torch.zeros(B, T, feat_dim, dtype=torch.float32, device=dev)
     if len(buf):
         seg, within, flat = buf.scatter_index()
         lens = np.asarray(buf.lens, dtype=np.int64)
