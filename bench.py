@@ -138,9 +138,9 @@ def cpu_baseline(workload: "Workload", seconds_budget: float = 20.0):
     from oracle import loss as oloss
     from oracle import nn as onn
     cfg = workload.seq_cfg
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 64)          # eager fp32 at these widths stops scaling past ~64 threads
     torch.set_num_threads(cores)
-    T = 256
+    T = 1024
     H, I, Nh, Nkv, D, V = (cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads,
                            cfg.num_key_value_heads, cfg.head_dim, cfg.vocab_size)
     g = torch.Generator().manual_seed(0)

@@ -7,7 +7,8 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import touchnet_amd.functional as F  # noqa: E402
 
 DEV = "cuda"

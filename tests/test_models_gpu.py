@@ -13,7 +13,7 @@ from touchnet_amd.models.backend import use_ops
 
 DEV = "cuda"
 TEXT = dict(model_type="llama", hidden_size=256, intermediate_size=512, num_attention_heads=4, num_hidden_layers=2,
-            num_key_value_heads=2, head_dim=64, vocab_size=512, tie_word_embeddings=True, rope_theta=500000.0,
+            num_key_value_heads=2, head_dim=64, vocab_size=512, tie_word_embeddings=True, rope_theta=500000.0, initializer_range=0.08,
             rope_scaling=dict(rope_type="llama3", factor=32.0, low_freq_factor=1.0, high_freq_factor=4.0,
                               original_max_position_embeddings=64))
 
@@ -46,12 +46,15 @@ def test_llama_text_step_matches_oracle():
     rel = abs(float(loss) - float(ps)) / abs(float(ps))
     assert rel < 1e-2, (float(loss), float(ps), rel)
     assert abs(float(per_tok) - float(pt)) / abs(float(pt)) < 1e-2
-    worst = 0.0
+    worst, report = 0.0, []
     for (n, p), (_, q) in zip(tr.model.named_parameters(), ref.named_parameters()):
         g, r = p.grad.float().cpu(), q.grad
         denom = r.abs().max().clamp_min(1e-6)
-        worst = max(worst, float((g - r).abs().max() / denom))
-    assert worst < 8e-2, f"worst relative grad error {worst}"
+        e = float((g - r).abs().max() / denom)
+        report.append((e, n, float(denom)))
+        worst = max(worst, e)
+    report.sort(reverse=True)
+    assert worst < 8e-2, f"worst relative grad errors {report[:6]}"
     print(f"loss rel err {rel:.2e}, worst grad rel err {worst:.2e}")
     # the fused lm_head+CE path must agree with the unfused one
     tr2 = Trainer(TrainConfig(training_model_name="llama_mi355", training_enable_fused_ce=True), cfg,
@@ -74,8 +77,8 @@ def test_touch_audio_step_with_device_frontend():
     from touchnet_amd.models.llama import DecoderConfig
     from touchnet_amd.models.touch_audio import TouchAudioConfig, TouchAudioForCausalLM
     cfg = TouchAudioConfig(text_config=DecoderConfig.from_dict(TEXT), input_size=400)
-    tr = Trainer(TrainConfig(training_model_name="touch_audio_mi355", training_enable_fused_ce=False), cfg,
-                 torch.device(DEV))
+    tr = Trainer(TrainConfig(training_model_name="touch_audio_mi355", training_enable_fused_ce=False,
+                             lr_scheduler_warmup_steps=0, lr_scheduler_lr=1e-3), cfg, torch.device(DEV))
     batch, _, _ = asr_batch_from_device_frontend(512, 2, 512, torch.device(DEV), frontend=F)
     assert batch["input_features"].is_cuda and batch["input_features"].shape == (2, 512, 400)
     data = tr.next_batch(batch)

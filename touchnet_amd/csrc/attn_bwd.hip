@@ -1,16 +1,22 @@
 // Packed (document-masked, causal) flash attention BACKWARD for gfx950 — MFMA 32x32x16 bf16.
 //
-// Same masking / layout contract as attn_fwd.hip.  Three kernels, all deterministic (no atomics):
+// Same masking / layout contract as attn_fwd.hip.  All kernels are deterministic (no atomics):
 //   1. delta[b,h,t] = sum_d dO[b,t,h,d] * O[b,t,h,d]                                (HBM-bound)
-//   2. dK/dV: a workgroup owns 128 KV rows of one KV head (32 per wave, K and V held in registers as
-//      MFMA B operands) and walks the query tiles (32 rows) of every query head of its GQA group that
-//      can see those rows:   S = Q K^T, P = exp2(S*c - LSE2), dP = dO V^T, dS = P o (dP - delta),
-//      dV^T += dO^T P, dK^T += Q^T dS.  S is computed un-transposed here so that the contraction index
-//      of the last two products (q) is the in-lane index of P / dS.
+//   2. dK / dV: a workgroup owns 128 KV rows of one KV head (32 per wave, K/V rows held in registers as MFMA
+//      B operands) and walks the 64-row query tiles of every query head of its GQA group that can see them:
+//          S = Q K^T,  P = exp2(S*c - LSE2),  dP = dO V^T,  dS = P o (dP - delta),
+//          dV^T += dO^T P,   dK^T += Q^T dS
+//      S is computed un-transposed here so that the contraction index of the last two products (q) is the
+//      in-lane index of P / dS.  MODE selects what one launch accumulates:
+//        D = 64 : one kernel does both (2 waves/SIMD)
+//        D = 128: a dV launch and a dK launch.  Keeping dK and dV accumulators (128 regs) plus K and V
+//                 operands (64) resident needs the 512-register file at 1 wave/SIMD and made hipcc shuttle
+//                 ~14 v_accvgpr moves per MFMA (measured: 15 VALU per MFMA, SQ_INSTS_VALU / SQ_INSTS_MFMA);
+//                 two lean kernels at 2 waves/SIMD recompute S once more (+25 % MFMA) and are faster.
 //   3. dQ: a workgroup owns 128 query rows of one head and walks KV tiles exactly like the forward:
-//      S^T = K Q^T, dP^T = V dO^T, dQ^T += K^T dS^T.
-// Recomputing S in both (7 matmuls instead of 5) buys determinism and needs no fp32 dQ scratch; the
-// reference's flex_attention backward does the same (inductor-generated two-loop Triton template).
+//      S^T = K Q^T, dP^T = V dO^T, dQ^T += K^T dS^T, one 32-row KV block at a time.
+// Recomputing S in each pass buys determinism and needs no fp32 dQ scratch; the reference's
+// flex_attention backward has the same two-loop structure (inductor-generated Triton template).
 #include "attn_common.h"
 
 namespace tn {
@@ -43,23 +49,27 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
-// dK / dV
+// dK / dV.   MODE 0: dV only   1: dK only   2: both
 // ------------------------------------------------------------------------------------------------
-template <int D>
-__global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(
+template <int D, int MODE>
+__global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(
     const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
     const bf16_t* __restrict__ dO, const float* __restrict__ LSE2, const float* __restrict__ Delta,
     bf16_t* __restrict__ dK, bf16_t* __restrict__ dV, const int* __restrict__ doc, AttnMeta meta, int T, int Nh,
     int Nkv, float scale, float scale_log2) {
-  constexpr int BNK = 128, BQ = 32;
+  constexpr bool DO_DV = MODE != 1, DO_DK = MODE != 0;
+  constexpr int BNK = 128, BQ = 64;
   constexpr int KSTEPS = D / 16, DBLK = D / 32, LD = D + 8, TS = TLds<BQ>::STRIDE;
-  // LDS: Qs | dOs (row-major [32][D+8]) | Qt | dOt (transposed [D][48]) | lse[32] delta[32] docq[32]
-  __shared__ __attribute__((aligned(16))) bf16_t smem[2 * BQ * LD + 2 * D * TS + 6 * BQ];
+  // LDS images of the current 64-row query tile:
+  //   Qs  row-major  (always: A operand of S = Q K^T)      dOs row-major  (dK: A operand of dP = dO V^T)
+  //   Qt  transposed (dK: A operand of dK^T += Q^T dS)     dOt transposed (dV: A operand of dV^T += dO^T P)
+  constexpr int N_RM = DO_DK ? 2 : 1, N_TR = (DO_DK ? 1 : 0) + (DO_DV ? 1 : 0);
+  __shared__ __attribute__((aligned(16))) bf16_t smem[N_RM * BQ * LD + N_TR * D * TS + 6 * BQ];
   bf16_t* Qs = smem;
-  bf16_t* dOs = Qs + BQ * LD;
-  bf16_t* Qt = dOs + BQ * LD;
-  bf16_t* dOt = Qt + D * TS;
-  float* lse_s = reinterpret_cast<float*>(dOt + D * TS);
+  bf16_t* dOs = Qs + BQ * LD;                       // valid only when DO_DK
+  bf16_t* Qt = smem + N_RM * BQ * LD;               // valid only when DO_DK
+  bf16_t* dOt = Qt + (DO_DK ? D * TS : 0);          // valid only when DO_DV
+  float* lse_s = reinterpret_cast<float*>(smem + N_RM * BQ * LD + N_TR * D * TS);
   float* delta_s = lse_s + BQ;
   int* docq = reinterpret_cast<int*>(delta_s + BQ);
 
@@ -72,7 +82,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(
   const int kvrow = wk0 + l31;
   const bool kvalid = kvrow < T;
 
-  bf16x8_t kreg[KSTEPS], vreg[KSTEPS];
+  bf16x8_t kreg[KSTEPS], vreg[DO_DK ? KSTEPS : 1];
   {
     const size_t off = (((size_t)b * T + (kvalid ? kvrow : 0)) * Nkv + hk) * D + 8 * hi;
 #pragma unroll
@@ -80,46 +90,49 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(
       uint4 a = make_uint4(0, 0, 0, 0), c = make_uint4(0, 0, 0, 0);
       if (kvalid) {
         a = *reinterpret_cast<const uint4*>(K + off + 16 * s);
-        c = *reinterpret_cast<const uint4*>(V + off + 16 * s);
+        if (DO_DK) c = *reinterpret_cast<const uint4*>(V + off + 16 * s);
       }
       kreg[s] = as_bf16x8(a);
-      vreg[s] = as_bf16x8(c);
+      if (DO_DK) vreg[s] = as_bf16x8(c);
     }
   }
   const int dkdoc = kvalid ? doc[(size_t)b * T + kvrow] : 0;
-  int wminpos = dkdoc > 0 ? dkdoc : 0x7fffffff, wmax = dkdoc;
-#pragma unroll
-  for (int o = 16; o > 0; o >>= 1) {
-    wminpos = min(wminpos, __shfl_xor(wminpos, o, 64));
-    wmax = max(wmax, __shfl_xor(wmax, o, 64));
-  }
+  int wminpos, wmax;
+  wave_id_range(dkdoc, wminpos, wmax);
+  const bool w_uniform = (wminpos == wmax) && !__any(dkdoc == 0);   // all 32 kv rows in one document
 
+  const int* m_min = meta.tmin + (size_t)b * meta.nt;
   const int* m_max = meta.tmax + (size_t)b * meta.nt;
   const int* m_minpos = meta.tminpos + (size_t)b * meta.nt;
   const int t0 = 2 * kt, t1 = min(2 * kt + 1, meta.nt - 1);
   const int bminpos = min(m_minpos[t0], m_minpos[t1]);
   const int bmax = max(m_max[t0], m_max[t1]);
   const int qhi64 = max(meta.kv_hi[(size_t)b * meta.nt + t0], meta.kv_hi[(size_t)b * meta.nt + t1]);
-  const int qt_lo = k0 / BQ;                                        // first 32-row query tile (q >= kv)
-  const int qt_end = min((qhi64 + 1) * (kTile / BQ), (T + BQ - 1) / BQ);  // exclusive
+  const int qt_lo = k0 / BQ;                                  // first 64-row query tile (q >= kv)
+  const int qt_end = min(qhi64 + 1, meta.nt);                 // exclusive
   const int nqt = max(qt_end - qt_lo, 0);
-  const int n_it = nqt * G;                                         // flattened (head-in-group, q tile)
+  const int n_it = nqt * G;                                   // flattened (head-in-group, q tile)
   auto advance = [&](int it) {
     while (it < n_it) {
-      const int t64 = (qt_lo + it % nqt) * BQ / kTile;
+      const int t64 = qt_lo + it % nqt;
       if (tile_may_interact(m_minpos[t64], m_max[t64], bminpos, bmax)) break;
       ++it;
     }
     return it;
   };
 
-  f32x16_t dkacc[DBLK], dvacc[DBLK];
+  f32x16_t dkacc[DO_DK ? DBLK : 1], dvacc[DO_DV ? DBLK : 1];
 #pragma unroll
   for (int i = 0; i < DBLK; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) dkacc[i][r] = dvacc[i][r] = 0.f;
+    for (int r = 0; r < 16; ++r) {
+      if (DO_DK) dkacc[i][r] = 0.f;
+      if (DO_DV) dvacc[i][r] = 0.f;
+    }
 
-  TransposeStage<BQ, D, 256> qst, dost;
+  const TLdsReader<BQ> trd(l31, hi);
+  const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  TransposeStage<BQ, D, 256> qst, dost;   // one register image serves both LDS images of a tile
   float lse_st = 0.f, delta_st = 0.f;
   int doc_st = 0;
   const size_t qld = (size_t)Nh * D;
@@ -131,21 +144,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(
     dost.load(dO + base, qld, T - qb, tid);
     if (tid < BQ) {
       const bool ok = qb + tid < T;
-      const size_t si = ((size_t)b * Nh + h) * T + qb + tid;
+      const size_t si = ((size_t)b * Nh + h) * T + (ok ? qb + tid : 0);
       lse_st = ok ? LSE2[si] : INFINITY;
       delta_st = ok ? Delta[si] : 0.f;
       doc_st = ok ? doc[(size_t)b * T + qb + tid] : 0;
     }
-  };
-  // write both images (row-major and transposed) of a staged 32 x D tile
-  auto stage_store = [&](const TransposeStage<BQ, D, 256>& st, bf16_t* rm, bf16_t* tr) {
-    constexpr int CPR = D / 8;
-    if (tid < (BQ / 4) * CPR) {
-      const int r4 = tid / CPR, c8 = tid % CPR;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) *reinterpret_cast<uint4*>(rm + (4 * r4 + k) * LD + c8 * 8) = st.v[0][k];
-    }
-    st.store(tr, tid);
   };
 
   int it = advance(0);
@@ -153,8 +156,12 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(
   while (it < n_it) {
     const int itn = advance(it + 1);
     __syncthreads();
-    stage_store(qst, Qs, Qt);
-    stage_store(dost, dOs, dOt);
+    qst.store_rowmajor(Qs, tid);
+    if (DO_DK) {
+      qst.store(Qt, tid);
+      dost.store_rowmajor(dOs, tid);
+    }
+    if (DO_DV) dost.store(dOt, tid);
     if (tid < BQ) {
       lse_s[tid] = lse_st;
       delta_s[tid] = delta_st;
@@ -163,61 +170,79 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(
     __syncthreads();
     if (itn < n_it) issue(itn);
 
-    const int qb = (qt_lo + it % nqt) * BQ;
-    const int t64 = qb / kTile;
-    if (qb + BQ - 1 >= wk0 && tile_may_interact(m_minpos[t64], m_max[t64], wminpos, wmax)) {
-      // ---- S[q, kv] = Q K^T ; dP[q, kv] = dO V^T     (rows = q in registers, column = this lane's kv)
-      f32x16_t sacc, dpacc;
+    const int t64 = qt_lo + it % nqt;
+    const int qb = t64 * BQ;
+    if (uniform(qb + BQ - 1 >= wk0 && tile_may_interact(m_minpos[t64], m_max[t64], wminpos, wmax))) {
+      const bool q_uniform = w_uniform && m_min[t64] == m_max[t64] && m_max[t64] == wmax;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) sacc[r] = dpacc[r] = 0.f;
-      const bf16_t* qp = Qs + l31 * LD + 8 * hi;
-      const bf16_t* dop = dOs + l31 * LD + 8 * hi;
+      for (int qs = 0; qs < 2; ++qs) {
+        const int qsb = qb + 32 * qs;
+        if (uniform(qsb + 31 >= wk0)) {                       // else: every q of this half precedes the kv rows
+          const bool need_mask = uniform(!(q_uniform && qsb >= wk0 + 31));
+          // ---- S[q, kv] = Q K^T (; dP[q, kv] = dO V^T)   rows = q in registers, column = this lane's kv
+          const bf16_t* qp = Qs + (32 * qs + l31) * LD + 8 * hi;
+          f32x16_t sacc = mfma32(as_bf16x8(*reinterpret_cast<const uint4*>(qp)), kreg[0], zero16);
 #pragma unroll
-      for (int s = 0; s < KSTEPS; ++s) {
-        sacc = mfma32(as_bf16x8(*reinterpret_cast<const uint4*>(qp + 16 * s)), kreg[s], sacc);
-        dpacc = mfma32(as_bf16x8(*reinterpret_cast<const uint4*>(dop + 16 * s)), vreg[s], dpacc);
-      }
-      float p[16], ds[16];
+          for (int s = 1; s < KSTEPS; ++s)
+            sacc = mfma32(as_bf16x8(*reinterpret_cast<const uint4*>(qp + 16 * s)), kreg[s], sacc);
+          f32x16_t dpacc = zero16;
+          if (DO_DK) {
+            const bf16_t* dop = dOs + (32 * qs + l31) * LD + 8 * hi;
 #pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4) {
-        const float4 l4 = *reinterpret_cast<const float4*>(lse_s + 8 * r4 + 4 * hi);
-        const float4 d4 = *reinterpret_cast<const float4*>(delta_s + 8 * r4 + 4 * hi);
-        const int4 q4 = *reinterpret_cast<const int4*>(docq + 8 * r4 + 4 * hi);
-        const float le[4] = {l4.x, l4.y, l4.z, l4.w}, de[4] = {d4.x, d4.y, d4.z, d4.w};
-        const int qd[4] = {q4.x, q4.y, q4.z, q4.w};
+            for (int s = 0; s < KSTEPS; ++s)
+              dpacc = mfma32(as_bf16x8(*reinterpret_cast<const uint4*>(dop + 16 * s)), vreg[s], dpacc);
+          }
+          float p[16];
+          auto probs = [&](auto masked) {
+            constexpr bool MASK = decltype(masked)::value;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int r = 4 * r4 + e;
-          const int qi = qb + 8 * r4 + 4 * hi + e;
-          const bool ok = (kvrow <= qi) && (qd[e] == dkdoc) && (dkdoc > 0);
-          const float pv = ok ? fast_exp2(sacc[r] * scale_log2 - le[e]) : 0.f;
-          p[r] = pv;
-          ds[r] = pv * (dpacc[r] - de[e]);
-        }
-      }
-      bf16x8_t pb[2], dsb[2];
+            for (int r4 = 0; r4 < 4; ++r4) {
+              const int o = 32 * qs + 8 * r4 + 4 * hi;
+              const float4 l4 = *reinterpret_cast<const float4*>(lse_s + o);
+              const float le[4] = {l4.x, l4.y, l4.z, l4.w};
+              int qd[4] = {0, 0, 0, 0};
+              if (MASK) {
+                const int4 q4 = *reinterpret_cast<const int4*>(docq + o);
+                qd[0] = q4.x; qd[1] = q4.y; qd[2] = q4.z; qd[3] = q4.w;
+              }
 #pragma unroll
-      for (int sp = 0; sp < 2; ++sp) {
-        u32x4_t t = {pack2bf(p[8 * sp + 0], p[8 * sp + 1]), pack2bf(p[8 * sp + 2], p[8 * sp + 3]),
-                     pack2bf(p[8 * sp + 4], p[8 * sp + 5]), pack2bf(p[8 * sp + 6], p[8 * sp + 7])};
-        pb[sp] = __builtin_bit_cast(bf16x8_t, t);
-        u32x4_t u = {pack2bf(ds[8 * sp + 0], ds[8 * sp + 1]), pack2bf(ds[8 * sp + 2], ds[8 * sp + 3]),
-                     pack2bf(ds[8 * sp + 4], ds[8 * sp + 5]), pack2bf(ds[8 * sp + 6], ds[8 * sp + 7])};
-        dsb[sp] = __builtin_bit_cast(bf16x8_t, u);
-      }
-      // ---- dV^T[d, kv] += dO^T[d, q] P[q, kv] ;  dK^T[d, kv] += Q^T[d, q] dS[q, kv]
+              for (int e = 0; e < 4; ++e) {
+                float pv = fast_exp2(sacc[4 * r4 + e] * scale_log2 - le[e]);
+                if (MASK) pv = ((kvrow <= qb + o + e) & (qd[e] == dkdoc) & (dkdoc > 0)) ? pv : 0.f;
+                p[4 * r4 + e] = pv;
+              }
+            }
+          };
+          if (need_mask) probs(std::true_type{}); else probs(std::false_type{});
+          if (DO_DV) {
 #pragma unroll
-      for (int db = 0; db < DBLK; ++db) {
-        const int d = 32 * db + l31;
+            for (int sp = 0; sp < 2; ++sp) {
+              const u32x4_t t = {pack2bf(p[8 * sp + 0], p[8 * sp + 1]), pack2bf(p[8 * sp + 2], p[8 * sp + 3]),
+                                 pack2bf(p[8 * sp + 4], p[8 * sp + 5]), pack2bf(p[8 * sp + 6], p[8 * sp + 7])};
+              const bf16x8_t pb = __builtin_bit_cast(bf16x8_t, t);
 #pragma unroll
-        for (int sp = 0; sp < 2; ++sp) {
-          const int g0 = 4 * sp + hi;
-          const uint2 a0 = *reinterpret_cast<const uint2*>(dOt + TLds<BQ>::off(d, g0));
-          const uint2 a1 = *reinterpret_cast<const uint2*>(dOt + TLds<BQ>::off(d, g0 + 2));
-          dvacc[db] = mfma32(as_bf16x8(a0, a1), pb[sp], dvacc[db]);
-          const uint2 c0 = *reinterpret_cast<const uint2*>(Qt + TLds<BQ>::off(d, g0));
-          const uint2 c1 = *reinterpret_cast<const uint2*>(Qt + TLds<BQ>::off(d, g0 + 2));
-          dkacc[db] = mfma32(as_bf16x8(c0, c1), dsb[sp], dkacc[db]);
+              for (int db = 0; db < DBLK; ++db)     // dV^T[d, kv] += dO^T[d, q] P[q, kv]
+                dvacc[db] = mfma32(trd.operand(dOt, db, 8 * qs + 4 * sp), pb, dvacc[db]);
+            }
+          }
+          if (DO_DK) {
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+              const float4 d4 = *reinterpret_cast<const float4*>(delta_s + 32 * qs + 8 * r4 + 4 * hi);
+              const float de[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+              for (int e = 0; e < 4; ++e) p[4 * r4 + e] *= dpacc[4 * r4 + e] - de[e];   // p becomes dS
+            }
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) {
+              const u32x4_t u = {pack2bf(p[8 * sp + 0], p[8 * sp + 1]), pack2bf(p[8 * sp + 2], p[8 * sp + 3]),
+                                 pack2bf(p[8 * sp + 4], p[8 * sp + 5]), pack2bf(p[8 * sp + 6], p[8 * sp + 7])};
+              const bf16x8_t dsb = __builtin_bit_cast(bf16x8_t, u);
+#pragma unroll
+              for (int db = 0; db < DBLK; ++db)     // dK^T[d, kv] += Q^T[d, q] dS[q, kv]
+                dkacc[db] = mfma32(trd.operand(Qt, db, 8 * qs + 4 * sp), dsb, dkacc[db]);
+            }
+          }
         }
       }
     }
@@ -231,12 +256,16 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(
 #pragma unroll
       for (int r4 = 0; r4 < 4; ++r4) {
         uint2 o;
-        o.x = pack2bf(dkacc[db][4 * r4 + 0] * scale, dkacc[db][4 * r4 + 1] * scale);
-        o.y = pack2bf(dkacc[db][4 * r4 + 2] * scale, dkacc[db][4 * r4 + 3] * scale);
-        *reinterpret_cast<uint2*>(dK + off + 32 * db + 8 * r4 + 4 * hi) = o;
-        o.x = pack2bf(dvacc[db][4 * r4 + 0], dvacc[db][4 * r4 + 1]);
-        o.y = pack2bf(dvacc[db][4 * r4 + 2], dvacc[db][4 * r4 + 3]);
-        *reinterpret_cast<uint2*>(dV + off + 32 * db + 8 * r4 + 4 * hi) = o;
+        if (DO_DK) {
+          o.x = pack2bf(dkacc[db][4 * r4 + 0] * scale, dkacc[db][4 * r4 + 1] * scale);
+          o.y = pack2bf(dkacc[db][4 * r4 + 2] * scale, dkacc[db][4 * r4 + 3] * scale);
+          *reinterpret_cast<uint2*>(dK + off + 32 * db + 8 * r4 + 4 * hi) = o;
+        }
+        if (DO_DV) {
+          o.x = pack2bf(dvacc[db][4 * r4 + 0], dvacc[db][4 * r4 + 1]);
+          o.y = pack2bf(dvacc[db][4 * r4 + 2], dvacc[db][4 * r4 + 3]);
+          *reinterpret_cast<uint2*>(dV + off + 32 * db + 8 * r4 + 4 * hi) = o;
+        }
       }
     }
   }
@@ -246,7 +275,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(
 // dQ
 // ------------------------------------------------------------------------------------------------
 template <int D>
-__global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(
     const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
     const bf16_t* __restrict__ dO, const float* __restrict__ LSE2, const float* __restrict__ Delta,
     bf16_t* __restrict__ dQ, const int* __restrict__ doc, AttnMeta meta, int T, int Nh, int Nkv, float scale,
@@ -285,13 +314,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(
   const int dq = qvalid ? doc[(size_t)b * T + qrow] : 0;
   const float lse2 = qvalid ? LSE2[((size_t)b * Nh + h) * T + qrow] : INFINITY;
   const float delta = qvalid ? Delta[((size_t)b * Nh + h) * T + qrow] : 0.f;
-  int wminpos = dq > 0 ? dq : 0x7fffffff, wmax = dq;
-#pragma unroll
-  for (int o = 16; o > 0; o >>= 1) {
-    wminpos = min(wminpos, __shfl_xor(wminpos, o, 64));
-    wmax = max(wmax, __shfl_xor(wmax, o, 64));
-  }
+  int wminpos, wmax;
+  wave_id_range(dq, wminpos, wmax);
+  const bool w_has_zero = __any(dq == 0);
 
+  const int* m_min = meta.tmin + (size_t)b * meta.nt;
   const int* m_max = meta.tmax + (size_t)b * meta.nt;
   const int* m_minpos = meta.tminpos + (size_t)b * meta.nt;
   const int t0 = 2 * qt, t1 = min(2 * qt + 1, meta.nt - 1);
@@ -311,6 +338,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) dqacc[i][r] = 0.f;
 
+  const TLdsReader<BN> trd(l31, hi);
+  const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   TransposeStage<BN, D, 256> kst;   // K: written row-major AND transposed from the same registers
   RowMajorStage<BN, D, 256> vst;
   int dstage = 0;
@@ -327,75 +356,60 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(
   while (j <= j_hi) {
     const int jn = advance(j + 1);
     __syncthreads();
-    {
-      constexpr int CPR = D / 8, UNITS = (BN / 4) * CPR;
-#pragma unroll
-      for (int i = 0; i < TransposeStage<BN, D, 256>::N; ++i) {
-        const int u = tid + i * 256;
-        if (u < UNITS) {
-          const int r4 = u / CPR, c8 = u % CPR;
-#pragma unroll
-          for (int k = 0; k < 4; ++k) *reinterpret_cast<uint4*>(Ks + (4 * r4 + k) * LD + c8 * 8) = kst.v[i][k];
-        }
-      }
-      kst.store(Kt, tid);
-      vst.store(Vs, tid);
-      if (tid < BN) docs[tid] = dstage;
-    }
+    kst.store_rowmajor(Ks, tid);
+    kst.store(Kt, tid);
+    vst.store(Vs, tid);
+    if (tid < BN) docs[tid] = dstage;
     __syncthreads();
     if (jn <= j_hi) issue(jn);
 
     const int k0 = j * BN;
-    if (k0 <= wq0 + 31 && tile_may_interact(wminpos, wmax, m_minpos[j], m_max[j])) {
-      f32x16_t sacc[2], dpacc[2];
+    if (uniform(k0 <= wq0 + 31 && tile_may_interact(wminpos, wmax, m_minpos[j], m_max[j]))) {
+      const bool need_mask = uniform(!(m_min[j] == m_max[j] && m_max[j] == wminpos && wminpos == wmax &&
+                                       !w_has_zero && (k0 + BN - 1 <= wq0)));
 #pragma unroll
       for (int blk = 0; blk < 2; ++blk) {
+        if (uniform(k0 + 32 * blk <= wq0 + 31)) {             // else: this 32-row KV block is above the diagonal
+          const bf16_t* kp = Ks + (32 * blk + l31) * LD + 8 * hi;
+          const bf16_t* vp = Vs + (32 * blk + l31) * LD + 8 * hi;
+          f32x16_t sacc = mfma32(as_bf16x8(*reinterpret_cast<const uint4*>(kp)), qreg[0], zero16);
+          f32x16_t dpacc = mfma32(as_bf16x8(*reinterpret_cast<const uint4*>(vp)), doreg[0], zero16);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sacc[blk][r] = dpacc[blk][r] = 0.f;
-        const bf16_t* kp = Ks + (32 * blk + l31) * LD + 8 * hi;
-        const bf16_t* vp = Vs + (32 * blk + l31) * LD + 8 * hi;
-#pragma unroll
-        for (int s = 0; s < KSTEPS; ++s) {
-          sacc[blk] = mfma32(as_bf16x8(*reinterpret_cast<const uint4*>(kp + 16 * s)), qreg[s], sacc[blk]);
-          dpacc[blk] = mfma32(as_bf16x8(*reinterpret_cast<const uint4*>(vp + 16 * s)), doreg[s], dpacc[blk]);
-        }
-      }
-      bf16x8_t dsb[2][2];
-#pragma unroll
-      for (int blk = 0; blk < 2; ++blk) {
-        float ds[16];
-#pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {
-          const int4 dk = *reinterpret_cast<const int4*>(docs + 32 * blk + 8 * r4 + 4 * hi);
-          const int dkk[4] = {dk.x, dk.y, dk.z, dk.w};
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int r = 4 * r4 + e;
-            const int kv = k0 + 32 * blk + 8 * r4 + 4 * hi + e;
-            const bool ok = (kv <= qrow) && (dkk[e] == dq) && (dq > 0);
-            const float pv = ok ? fast_exp2(sacc[blk][r] * scale_log2 - lse2) : 0.f;
-            ds[r] = pv * (dpacc[blk][r] - delta);
+          for (int s = 1; s < KSTEPS; ++s) {
+            sacc = mfma32(as_bf16x8(*reinterpret_cast<const uint4*>(kp + 16 * s)), qreg[s], sacc);
+            dpacc = mfma32(as_bf16x8(*reinterpret_cast<const uint4*>(vp + 16 * s)), doreg[s], dpacc);
           }
-        }
+          float ds[16];
+          auto dscore = [&](auto masked) {
+            constexpr bool MASK = decltype(masked)::value;
 #pragma unroll
-        for (int sp = 0; sp < 2; ++sp) {
-          u32x4_t u = {pack2bf(ds[8 * sp + 0], ds[8 * sp + 1]), pack2bf(ds[8 * sp + 2], ds[8 * sp + 3]),
-                       pack2bf(ds[8 * sp + 4], ds[8 * sp + 5]), pack2bf(ds[8 * sp + 6], ds[8 * sp + 7])};
-          dsb[blk][sp] = __builtin_bit_cast(bf16x8_t, u);
-        }
-      }
-      // ---- dQ^T[d, q] += K^T[d, kv] dS^T[kv, q]
+            for (int r4 = 0; r4 < 4; ++r4) {
+              int dkk[4] = {0, 0, 0, 0};
+              if (MASK) {
+                const int4 dk = *reinterpret_cast<const int4*>(docs + 32 * blk + 8 * r4 + 4 * hi);
+                dkk[0] = dk.x; dkk[1] = dk.y; dkk[2] = dk.z; dkk[3] = dk.w;
+              }
 #pragma unroll
-      for (int db = 0; db < DBLK; ++db) {
-        const int d = 32 * db + l31;
-#pragma unroll
-        for (int blk = 0; blk < 2; ++blk) {
+              for (int e = 0; e < 4; ++e) {
+                const int r = 4 * r4 + e;
+                float pv = fast_exp2(sacc[r] * scale_log2 - lse2);
+                if (MASK) {
+                  const int kv = k0 + 32 * blk + 8 * r4 + 4 * hi + e;
+                  pv = ((kv <= qrow) & (dkk[e] == dq) & (dq > 0)) ? pv : 0.f;
+                }
+                ds[r] = pv * (dpacc[r] - delta);
+              }
+            }
+          };
+          if (need_mask) dscore(std::true_type{}); else dscore(std::false_type{});
 #pragma unroll
           for (int sp = 0; sp < 2; ++sp) {
-            const int g0 = 8 * blk + 4 * sp + hi;
-            const uint2 a0 = *reinterpret_cast<const uint2*>(Kt + TLds<BN>::off(d, g0));
-            const uint2 a1 = *reinterpret_cast<const uint2*>(Kt + TLds<BN>::off(d, g0 + 2));
-            dqacc[db] = mfma32(as_bf16x8(a0, a1), dsb[blk][sp], dqacc[db]);
+            const u32x4_t u = {pack2bf(ds[8 * sp + 0], ds[8 * sp + 1]), pack2bf(ds[8 * sp + 2], ds[8 * sp + 3]),
+                               pack2bf(ds[8 * sp + 4], ds[8 * sp + 5]), pack2bf(ds[8 * sp + 6], ds[8 * sp + 7])};
+            const bf16x8_t dsb = __builtin_bit_cast(bf16x8_t, u);
+#pragma unroll
+            for (int db = 0; db < DBLK; ++db)       // dQ^T[d, q] += K^T[d, kv] dS^T[kv, q]
+              dqacc[db] = mfma32(trd.operand(Kt, db, 8 * blk + 4 * sp), dsb, dqacc[db]);
           }
         }
       }
@@ -436,24 +450,23 @@ int tn_attn_bwd(const void* q, const void* k, const void* v, const void* o, cons
   const float sl2 = scale * 1.4426950408889634f;
   const size_t rows = (size_t)B * T * Nh;
   dim3 gq((T + 127) / 128, Nh, B), gk((T + 127) / 128, Nkv, B), block(256);
+  const bf16_t *Q = (const bf16_t*)q, *K = (const bf16_t*)k, *V = (const bf16_t*)v, *dO = (const bf16_t*)dout;
   if (D == 128) {
-    hipLaunchKernelGGL((attn_delta_kernel<128>), dim3((rows * 16 + 255) / 256), block, 0, st, (const bf16_t*)o,
-                       (const bf16_t*)dout, delta, B, T, Nh);
-    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<128>), gk, block, 0, st, (const bf16_t*)q, (const bf16_t*)k,
-                       (const bf16_t*)v, (const bf16_t*)dout, lse2, delta, (bf16_t*)dk, (bf16_t*)dv, doc, m, T, Nh,
-                       Nkv, scale, sl2);
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<128>), gq, block, 0, st, (const bf16_t*)q, (const bf16_t*)k,
-                       (const bf16_t*)v, (const bf16_t*)dout, lse2, delta, (bf16_t*)dq, doc, m, T, Nh, Nkv, scale,
-                       sl2);
+    hipLaunchKernelGGL((attn_delta_kernel<128>), dim3((rows * 16 + 255) / 256), block, 0, st, (const bf16_t*)o, dO,
+                       delta, B, T, Nh);
+    hipLaunchKernelGGL((attn_bwd_kv_kernel<128, 0>), gk, block, 0, st, Q, K, V, dO, lse2, delta, (bf16_t*)dk,
+                       (bf16_t*)dv, doc, m, T, Nh, Nkv, scale, sl2);
+    hipLaunchKernelGGL((attn_bwd_kv_kernel<128, 1>), gk, block, 0, st, Q, K, V, dO, lse2, delta, (bf16_t*)dk,
+                       (bf16_t*)dv, doc, m, T, Nh, Nkv, scale, sl2);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<128>), gq, block, 0, st, Q, K, V, dO, lse2, delta, (bf16_t*)dq, doc, m,
+                       T, Nh, Nkv, scale, sl2);
   } else {
-    hipLaunchKernelGGL((attn_delta_kernel<64>), dim3((rows * 8 + 255) / 256), block, 0, st, (const bf16_t*)o,
-                       (const bf16_t*)dout, delta, B, T, Nh);
-    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<64>), gk, block, 0, st, (const bf16_t*)q, (const bf16_t*)k,
-                       (const bf16_t*)v, (const bf16_t*)dout, lse2, delta, (bf16_t*)dk, (bf16_t*)dv, doc, m, T, Nh,
-                       Nkv, scale, sl2);
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<64>), gq, block, 0, st, (const bf16_t*)q, (const bf16_t*)k,
-                       (const bf16_t*)v, (const bf16_t*)dout, lse2, delta, (bf16_t*)dq, doc, m, T, Nh, Nkv, scale,
-                       sl2);
+    hipLaunchKernelGGL((attn_delta_kernel<64>), dim3((rows * 8 + 255) / 256), block, 0, st, (const bf16_t*)o, dO,
+                       delta, B, T, Nh);
+    hipLaunchKernelGGL((attn_bwd_kv_kernel<64, 2>), gk, block, 0, st, Q, K, V, dO, lse2, delta, (bf16_t*)dk,
+                       (bf16_t*)dv, doc, m, T, Nh, Nkv, scale, sl2);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<64>), gq, block, 0, st, Q, K, V, dO, lse2, delta, (bf16_t*)dq, doc, m, T,
+                       Nh, Nkv, scale, sl2);
   }
   TN_LAUNCH_CHECK();
   return TN_OK;

@@ -13,6 +13,8 @@
 //   result  C[i][j]: lane holds column j = lane & 31, register r holds row
 //     i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
 #pragma once
+#include <type_traits>
+
 #include "common.h"
 
 namespace tn {
@@ -56,6 +58,24 @@ __device__ __forceinline__ bool tile_may_interact(int qminpos, int qmax, int kmi
   return !(qminpos == 0x7fffffff || kminpos == 0x7fffffff || kmax < qminpos || kminpos > qmax);
 }
 
+// Positive-id range of a wave's 32 rows (both 32-lane halves hold the same rows), returned in SGPRs so that
+// every tile decision derived from it is a scalar branch and not an exec-mask region.
+__device__ __forceinline__ void wave_id_range(int id, int& minpos, int& mx) {
+  int a = id > 0 ? id : 0x7fffffff, b = id;
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) {
+    a = min(a, __shfl_xor(a, o, 64));
+    b = max(b, __shfl_xor(b, o, 64));
+  }
+  minpos = __builtin_amdgcn_readfirstlane(a);
+  mx = __builtin_amdgcn_readfirstlane(b);
+}
+
+// A wave-uniform predicate as a real scalar (SGPR) bool: `if (uniform(c))` compiles to s_cbranch_scc and both
+// arms stay free of exec-mask bookkeeping.  (hipcc otherwise turns a mask-typed bool that it cannot prove
+// uniform into one s_and_saveexec region PER ELEMENT of the unrolled softmax loops.)
+__device__ __forceinline__ bool uniform(bool c) { return __builtin_amdgcn_readfirstlane((int)c) != 0; }
+
 // Transposed LDS image [D rows][R source rows] of an [R][D] bf16 tile: element (d, s) lives at
 //   d * STRIDE + 4 * ((s >> 2) ^ swz(d)) + (s & 3),  swz(d) = (d >> 3) & (R/4 - 1)
 // Written as 8-byte (4 source rows) groups, read as 8-byte groups by the MFMA operand loads:
@@ -67,6 +87,44 @@ struct TLds {
   static __device__ __forceinline__ int off(int d, int g) { return d * STRIDE + 4 * ((g ^ (d >> 3)) & (R / 4 - 1)); }
 };
 
+// MFMA-operand reads of a TLds<R> image cost ZERO address VALU inside the tile loops: for lane (l31, hi),
+// row d = 32*db + l31 and group g = ghi + glo (ghi a multiple of 4, glo in {hi, hi + 2}) the swizzle splits as
+//   off(d, g) = [l31*STRIDE + 4*(glo ^ (l31 >> 3))]  +  [32*db*STRIDE + 4*(ghi ^ 4*db)]
+//                 lane part: two VGPRs, set once          compile-time: folded into the ds_read offset field
+template <int R>
+struct TLdsReader {
+  int a0, a2;
+  __device__ __forceinline__ TLdsReader(int l31, int hi) {
+    const int lx = l31 >> 3;
+    a0 = l31 * TLds<R>::STRIDE + 4 * (hi ^ lx);
+    a2 = l31 * TLds<R>::STRIDE + 4 * ((hi + 2) ^ lx);
+  }
+  static __device__ __forceinline__ constexpr int c(int db, int ghi) {
+    return 32 * db * TLds<R>::STRIDE + 4 * (ghi ^ (4 * db));
+  }
+  // 8 contraction slots (groups ghi+hi and ghi+hi+2) of row 32*db + l31
+  __device__ __forceinline__ bf16x8_t operand(const bf16_t* img, int db, int ghi) const {
+    const uint2 lo = *reinterpret_cast<const uint2*>(img + a0 + c(db, ghi));
+    const uint2 hi2 = *reinterpret_cast<const uint2*>(img + a2 + c(db, ghi));
+    return as_bf16x8(lo, hi2);
+  }
+};
+
+// Wave-uniform buffer descriptor over the first `rows_valid` rows of a [rows][ld] bf16 tile starting at
+// `base`: loads past the last valid row return 0 in hardware (no exec-mask branches around tile edges).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const bf16_t* base, size_t ld, int rows_valid, int D) {
+  const uint64_t p = reinterpret_cast<uint64_t>(base);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)p);
+  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(p >> 32));
+  const uint32_t bytes = rows_valid > 0 ? (uint32_t)(((size_t)(rows_valid - 1) * ld + D) * 2) : 0u;
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), 0,
+                                           __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+__device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
+  const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 // Stage a [R rows][D] bf16 tile, source row stride `ld` elements, rows >= rows_valid zero-filled.
 //  * row-major image  dst_rm[r * (D + 8) + d]          (16-byte writes)
 //  * transposed image dst_t  via TLds<R>               (8-byte writes of 4 consecutive source rows)
@@ -75,14 +133,15 @@ template <int R, int D, int NT>
 struct RowMajorStage {
   static constexpr int CPR = D / 8;                       // 16-byte chunks per row
   static constexpr int N = (R * CPR + NT - 1) / NT;       // chunks per thread
+  static constexpr bool EXACT = (R * CPR) % NT == 0;
   uint4 v[N];
   __device__ __forceinline__ void load(const bf16_t* src, size_t ld, int rows_valid, int tid) {
+    const __amdgpu_buffer_rsrc_t rs = tile_rsrc(src, ld, rows_valid < R ? rows_valid : R, D);
 #pragma unroll
     for (int i = 0; i < N; ++i) {
       const int c = tid + i * NT;
       const int r = c / CPR, cc = c % CPR;
-      v[i] = make_uint4(0, 0, 0, 0);
-      if (c < R * CPR && r < rows_valid) v[i] = *reinterpret_cast<const uint4*>(src + (size_t)r * ld + cc * 8);
+      v[i] = buf_load16(rs, (EXACT || c < R * CPR) ? (uint32_t)((r * ld + cc * 8) * 2) : 0xffffffffu);
     }
   }
   __device__ __forceinline__ void store(bf16_t* dst, int tid) const {
@@ -90,7 +149,7 @@ struct RowMajorStage {
     for (int i = 0; i < N; ++i) {
       const int c = tid + i * NT;
       const int r = c / CPR, cc = c % CPR;
-      if (c < R * CPR) *reinterpret_cast<uint4*>(dst + r * (D + 8) + cc * 8) = v[i];
+      if (EXACT || c < R * CPR) *reinterpret_cast<uint4*>(dst + r * (D + 8) + cc * 8) = v[i];
     }
   }
 };
@@ -100,17 +159,28 @@ struct TransposeStage {
   static constexpr int CPR = D / 8;
   static constexpr int UNITS = (R / 4) * CPR;             // one unit = 4 rows x 8 columns
   static constexpr int N = (UNITS + NT - 1) / NT;
+  static constexpr bool EXACT = UNITS % NT == 0;
   uint4 v[N][4];
   __device__ __forceinline__ void load(const bf16_t* src, size_t ld, int rows_valid, int tid) {
+    const __amdgpu_buffer_rsrc_t rs = tile_rsrc(src, ld, rows_valid < R ? rows_valid : R, D);
 #pragma unroll
     for (int i = 0; i < N; ++i) {
       const int u = tid + i * NT;
       const int r4 = u / CPR, c8 = u % CPR;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int r = 4 * r4 + k;
-        v[i][k] = make_uint4(0, 0, 0, 0);
-        if (u < UNITS && r < rows_valid) v[i][k] = *reinterpret_cast<const uint4*>(src + (size_t)r * ld + c8 * 8);
+      for (int k = 0; k < 4; ++k)
+        v[i][k] = buf_load16(rs, (EXACT || u < UNITS) ? (uint32_t)(((4 * r4 + k) * ld + c8 * 8) * 2) : 0xffffffffu);
+    }
+  }
+  // row-major image of the same registers (the dK/dV and dQ kernels need both images of one tile)
+  __device__ __forceinline__ void store_rowmajor(bf16_t* dst, int tid) const {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const int u = tid + i * NT;
+      const int r4 = u / CPR, c8 = u % CPR;
+      if (EXACT || u < UNITS) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) *reinterpret_cast<uint4*>(dst + (4 * r4 + k) * (D + 8) + c8 * 8) = v[i][k];
       }
     }
   }
@@ -119,7 +189,7 @@ struct TransposeStage {
     for (int i = 0; i < N; ++i) {
       const int u = tid + i * NT;
       const int r4 = u / CPR, c8 = u % CPR;
-      if (u < UNITS) {
+      if (EXACT || u < UNITS) {
         const uint32_t w[4][4] = {{v[i][0].x, v[i][0].y, v[i][0].z, v[i][0].w},
                                   {v[i][1].x, v[i][1].y, v[i][1].z, v[i][1].w},
                                   {v[i][2].x, v[i][2].y, v[i][2].z, v[i][2].w},
@@ -129,11 +199,11 @@ struct TransposeStage {
           const int wi = dd >> 1;
           uint2 o;
           if (dd & 1) {
-            o.x = (w[0][wi] >> 16) | (w[1][wi] & 0xffff0000u);
-            o.y = (w[2][wi] >> 16) | (w[3][wi] & 0xffff0000u);
+            o.x = __builtin_amdgcn_perm(w[1][wi], w[0][wi], 0x07060302u);
+            o.y = __builtin_amdgcn_perm(w[3][wi], w[2][wi], 0x07060302u);
           } else {
-            o.x = (w[0][wi] & 0xffffu) | (w[1][wi] << 16);
-            o.y = (w[2][wi] & 0xffffu) | (w[3][wi] << 16);
+            o.x = __builtin_amdgcn_perm(w[1][wi], w[0][wi], 0x05040100u);
+            o.y = __builtin_amdgcn_perm(w[3][wi], w[2][wi], 0x05040100u);
           }
           *reinterpret_cast<uint2*>(dst + TLds<R>::off(c8 * 8 + dd, r4)) = o;
         }

@@ -103,13 +103,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
     }
   }
   const int dq = qvalid ? doc[(size_t)b * T + qrow] : 0;
-  // wave-level id range of the 32 query rows (both 32-lane halves hold the same rows)
-  int wminpos = dq > 0 ? dq : 0x7fffffff, wmax = dq;
-#pragma unroll
-  for (int o = 16; o > 0; o >>= 1) {
-    wminpos = min(wminpos, __shfl_xor(wminpos, o, 64));
-    wmax = max(wmax, __shfl_xor(wmax, o, 64));
-  }
+  int wminpos, wmax;   // wave-level id range of the 32 query rows, in SGPRs
+  wave_id_range(dq, wminpos, wmax);
   const bool w_has_zero = __any(dq == 0);
 
   // ---- block-level tile range from the metadata of the two 64-row halves of the query tile
@@ -133,6 +128,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
 #pragma unroll
     for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
   float m_run = -1e30f, l_run = 0.f;
+  const TLdsReader<BN> vrd(l31, hi);
+  const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
   RowMajorStage<BN, D, 256> kst;
   TransposeStage<BN, D, 256> vst;
@@ -158,43 +155,48 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
 
     const int k0 = j * BN;
     const int kminpos = m_minpos[j], kmax = m_max[j];
-    if (k0 <= wq0 + 31 && tile_may_interact(wminpos, wmax, kminpos, kmax)) {
-      const bool need_mask =
-          !(m_min[j] == kmax && kmax == wminpos && wminpos == wmax && !w_has_zero && (k0 + BN - 1 <= wq0));
+    if (uniform(k0 <= wq0 + 31 && tile_may_interact(wminpos, wmax, kminpos, kmax))) {
+      const bool need_mask = uniform(
+          !(m_min[j] == kmax && kmax == wminpos && wminpos == wmax && !w_has_zero && (k0 + BN - 1 <= wq0)));
       // ---- S^T[kv, q] = K[kv, :] . Q[q, :]
       f32x16_t sacc[2];
 #pragma unroll
       for (int blk = 0; blk < 2; ++blk) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sacc[blk][r] = 0.f;
         const bf16_t* kp = Ks + (32 * blk + l31) * KLD + 8 * hi;
+        sacc[blk] = mfma32(as_bf16x8(*reinterpret_cast<const uint4*>(kp)), qreg[0], zero16);
 #pragma unroll
-        for (int s = 0; s < KSTEPS; ++s)
+        for (int s = 1; s < KSTEPS; ++s)
           sacc[blk] = mfma32(as_bf16x8(*reinterpret_cast<const uint4*>(kp + 16 * s)), qreg[s], sacc[blk]);
       }
       // ---- scale, mask, online softmax (lane-local: this lane's query column)
       float mx = -INFINITY;
+      auto scale_mask = [&](auto masked) {
+        constexpr bool MASK = decltype(masked)::value;
 #pragma unroll
-      for (int blk = 0; blk < 2; ++blk) {
+        for (int blk = 0; blk < 2; ++blk) {
 #pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {
-          int4 dk = make_int4(0, 0, 0, 0);
-          if (need_mask) dk = *reinterpret_cast<const int4*>(docs + 32 * blk + 8 * r4 + 4 * hi);
-          const int dkk[4] = {dk.x, dk.y, dk.z, dk.w};
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int r = 4 * r4 + e;
-            float s = sacc[blk][r] * scale_log2;
-            if (need_mask) {
-              const int kv = k0 + 32 * blk + 8 * r4 + 4 * hi + e;
-              const bool ok = (kv <= qrow) && (dkk[e] == dq) && (dq > 0);
-              s = ok ? s : -INFINITY;
+          for (int r4 = 0; r4 < 4; ++r4) {
+            int dkk[4] = {0, 0, 0, 0};
+            if (MASK) {
+              const int4 dk = *reinterpret_cast<const int4*>(docs + 32 * blk + 8 * r4 + 4 * hi);
+              dkk[0] = dk.x; dkk[1] = dk.y; dkk[2] = dk.z; dkk[3] = dk.w;
             }
-            sacc[blk][r] = s;
-            mx = fmaxf(mx, s);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int r = 4 * r4 + e;
+              float s = sacc[blk][r] * scale_log2;
+              if (MASK) {
+                const int kv = k0 + 32 * blk + 8 * r4 + 4 * hi + e;
+                const bool ok = (kv <= qrow) & (dkk[e] == dq) & (dq > 0);
+                s = ok ? s : -INFINITY;
+              }
+              sacc[blk][r] = s;
+              mx = fmaxf(mx, s);
+            }
           }
         }
-      }
+      };
+      if (need_mask) scale_mask(std::true_type{}); else scale_mask(std::false_type{});
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float m_new = fmaxf(m_run, mx);
       const float alpha = fast_exp2(m_run - m_new);
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
         }
       }
       l_run = l_run * alpha + psum;
-      if (!__all(alpha == 1.f)) {
+      if (uniform(!__all(alpha == 1.f))) {
 #pragma unroll
         for (int i = 0; i < DBLK; ++i)
 #pragma unroll
@@ -225,16 +227,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
       // ---- O^T[d, q] += V^T[d, kv] P^T[kv, q]
 #pragma unroll
       for (int db = 0; db < DBLK; ++db) {
-        const int d = 32 * db + l31;
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk) {
 #pragma unroll
-          for (int sp = 0; sp < 2; ++sp) {
-            const int g0 = 8 * blk + 4 * sp + hi;
-            const uint2 a0 = *reinterpret_cast<const uint2*>(Vt + TLds<BN>::off(d, g0));
-            const uint2 a1 = *reinterpret_cast<const uint2*>(Vt + TLds<BN>::off(d, g0 + 2));
-            oacc[db] = mfma32(as_bf16x8(a0, a1), pb[blk][sp], oacc[db]);
-          }
+          for (int sp = 0; sp < 2; ++sp)
+            oacc[db] = mfma32(vrd.operand(Vt, db, 8 * blk + 4 * sp), pb[blk][sp], oacc[db]);
         }
       }
     }

@@ -23,20 +23,18 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 
-// round-to-nearest-even, NaN preserved (same rounding as torch's float->bfloat16)
-__device__ __forceinline__ bf16_t f2bf(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
-}
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+
+// round-to-nearest-even (same as torch's float->bfloat16); lowers to v_cvt_pk_bf16_f32 on gfx950
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
 
 // raw v_exp_f32 (2^x, ~1 ulp, flushes denormal results): the softmax inner loops must not pay for the
 // denormal fix-up sequence libm's exp2f adds
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
-  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+  bf16x2_t v = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(uint32_t, v);
 }
 
 template <typename T> struct Elem;

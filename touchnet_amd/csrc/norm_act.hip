@@ -87,20 +87,39 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const T* __restrict__ 
 //   dh = rstd * (g - xhat * mean(g*xhat)) (+ dres: gradient arriving on the residual stream)
 //   dw_partial[block][c] = sum over the block's rows of dy * xhat      (deterministic 2-stage)
 // ------------------------------------------------------------------------------------------
+// block-wide sum of two values at once (one barrier pair); `sm` holds >= 2 * blockDim.x/64 floats
+__device__ __forceinline__ void block_sum2(float& a, float& b, float* sm) {
+  a = wave_sum(a);
+  b = wave_sum(b);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if (lane == 0) {
+    sm[2 * w] = a;
+    sm[2 * w + 1] = b;
+  }
+  __syncthreads();
+  a = b = 0.f;
+  for (int i = 0; i < nw; ++i) {
+    a += sm[2 * i];
+    b += sm[2 * i + 1];
+  }
+}
+
+// One 256-thread block walks rows (grid-stride); thread t owns 16-byte vectors t, t+256, ... of every row,
+// so its slice of dw accumulates in registers across rows and is written once per block.
 template <typename T, int MAXV>
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ h,
                                                           const T* __restrict__ w, const float* __restrict__ rstd_in,
                                                           const T* __restrict__ dres, T* __restrict__ dh,
                                                           float* __restrict__ dw_partial, int rows, int H) {
   constexpr int N = Vec16<T>::N;
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* sm = reinterpret_cast<float*>(smem_raw);  // [kRowWaves][H]
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  __shared__ float sm[8];
+  const int tid = threadIdx.x;
   const int nvec = H / N;
   float wf[MAXV][N], dwacc[MAXV][N];
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
-    const int v = i * 64 + lane;
+    const int v = i * 256 + tid;
 #pragma unroll
     for (int j = 0; j < N; ++j) dwacc[i][j] = 0.f;
     if (v < nvec) {
@@ -109,14 +128,14 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const T* __restrict__ 
       wv.unpack(wf[i]);
     }
   }
-  for (int row = blockIdx.x * kRowWaves + wid; row < rows; row += gridDim.x * kRowWaves) {
+  for (int row = blockIdx.x; row < rows; row += gridDim.x) {
     const size_t base = (size_t)row * H;
     const float rstd = rstd_in[row];
     float g[MAXV][N], xh[MAXV][N];
-    float dot = 0.f;
+    float dot = 0.f, unused = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
-      const int v = i * 64 + lane;
+      const int v = i * 256 + tid;
       if (v < nvec) {
         Vec16<T> a, b;
         float dyf[N];
@@ -136,10 +155,11 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const T* __restrict__ 
         }
       }
     }
-    dot = wave_sum(dot) / (float)H;
+    block_sum2(dot, unused, sm);
+    dot /= (float)H;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
-      const int v = i * 64 + lane;
+      const int v = i * 256 + tid;
       if (v < nvec) {
         float o[N];
 #pragma unroll
@@ -158,32 +178,38 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const T* __restrict__ 
       }
     }
   }
-  // block-level dw: waves -> LDS -> one partial row per block
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
-    const int v = i * 64 + lane;
+    const int v = i * 256 + tid;
     if (v < nvec) {
 #pragma unroll
-      for (int j = 0; j < N; ++j) sm[wid * H + v * N + j] = dwacc[i][j];
+      for (int j = 0; j < N; ++j) dw_partial[(size_t)blockIdx.x * H + v * N + j] = dwacc[i][j];
     }
-  }
-  __syncthreads();
-  for (int c = threadIdx.x; c < H; c += blockDim.x) {
-    float s = 0.f;
-#pragma unroll
-    for (int k = 0; k < kRowWaves; ++k) s += sm[k * H + c];
-    dw_partial[(size_t)blockIdx.x * H + c] = s;
   }
 }
 
-// out[c] = sum_p partial[p][c]  (second stage of every weight/bias gradient)
+// out[c] = sum_p partial[p][c]  (second stage of every weight/bias gradient).
+// 64 columns per block, 4 row groups (one per wave) summed through LDS: coalesced 256-byte row segments.
 template <typename T>
-__global__ void colsum_partials_kernel(const float* __restrict__ partial, T* __restrict__ out, int P, int H) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= H) return;
-  float s = 0.f;
-  for (int p = 0; p < P; ++p) s += partial[(size_t)p * H + c];
-  Elem<T>::st(out + c, s);
+__global__ __launch_bounds__(256) void colsum_partials_kernel(const float* __restrict__ partial, T* __restrict__ out,
+                                                              int P, int H) {
+  __shared__ float sm[4][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cx;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < H) {
+    int p = ry;
+    for (; p + 12 < P; p += 16) {
+      s0 += partial[(size_t)p * H + c];
+      s1 += partial[(size_t)(p + 4) * H + c];
+      s2 += partial[(size_t)(p + 8) * H + c];
+      s3 += partial[(size_t)(p + 12) * H + c];
+    }
+    for (; p < P; p += 4) s0 += partial[(size_t)p * H + c];
+  }
+  sm[ry][cx] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (ry == 0 && c < H) Elem<T>::st(out + c, (sm[0][cx] + sm[1][cx]) + (sm[2][cx] + sm[3][cx]));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -271,14 +297,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
                                                             float* __restrict__ dw_partial,
                                                             float* __restrict__ db_partial, int rows, int H) {
   constexpr int N = Vec16<T>::N;
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* sm = reinterpret_cast<float*>(smem_raw);  // [2][kRowWaves][H]
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  __shared__ float sm[8];
+  const int tid = threadIdx.x;
   const int nvec = H / N;
   float wf[MAXV][N], dwacc[MAXV][N], dbacc[MAXV][N];
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
-    const int v = i * 64 + lane;
+    const int v = i * 256 + tid;
 #pragma unroll
     for (int j = 0; j < N; ++j) dwacc[i][j] = dbacc[i][j] = 0.f;
     if (v < nvec) {
@@ -287,14 +312,14 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
       wv.unpack(wf[i]);
     }
   }
-  for (int row = blockIdx.x * kRowWaves + wid; row < rows; row += gridDim.x * kRowWaves) {
+  for (int row = blockIdx.x; row < rows; row += gridDim.x) {
     const size_t base = (size_t)row * H;
     const float mean = mean_in[row], rstd = rstd_in[row];
     float g[MAXV][N], xh[MAXV][N];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
-      const int v = i * 64 + lane;
+      const int v = i * 256 + tid;
       if (v < nvec) {
         Vec16<T> a, b;
         float dyf[N];
@@ -313,11 +338,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
         }
       }
     }
-    s1 = wave_sum(s1) / (float)H;
-    s2 = wave_sum(s2) / (float)H;
+    block_sum2(s1, s2, sm);
+    s1 /= (float)H;
+    s2 /= (float)H;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
-      const int v = i * 64 + lane;
+      const int v = i * 256 + tid;
       if (v < nvec) {
         float o[N];
 #pragma unroll
@@ -338,25 +364,14 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
   }
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
-    const int v = i * 64 + lane;
+    const int v = i * 256 + tid;
     if (v < nvec) {
 #pragma unroll
       for (int j = 0; j < N; ++j) {
-        sm[wid * H + v * N + j] = dwacc[i][j];
-        sm[(kRowWaves + wid) * H + v * N + j] = dbacc[i][j];
+        dw_partial[(size_t)blockIdx.x * H + v * N + j] = dwacc[i][j];
+        db_partial[(size_t)blockIdx.x * H + v * N + j] = dbacc[i][j];
       }
     }
-  }
-  __syncthreads();
-  for (int c = threadIdx.x; c < H; c += blockDim.x) {
-    float a = 0.f, b = 0.f;
-#pragma unroll
-    for (int k = 0; k < kRowWaves; ++k) {
-      a += sm[k * H + c];
-      b += sm[(kRowWaves + k) * H + c];
-    }
-    dw_partial[(size_t)blockIdx.x * H + c] = a;
-    db_partial[(size_t)blockIdx.x * H + c] = b;
   }
 }
 
@@ -570,9 +585,11 @@ static int rmsnorm_fwd_t(const void* x, const void* res_in, const void* w, void*
   return TN_OK;
 }
 
-static inline int norm_bwd_blocks(int rows) {
-  int b = (rows + kRowWaves - 1) / kRowWaves;
-  return b < 512 ? b : 512;
+static inline int norm_bwd_blocks(int rows) { return rows < 1024 ? rows : 1024; }
+
+static inline int pick_maxv_block(int H, int N) {   // vectors per thread when 256 threads share a row
+  const int per = (H / N + 255) / 256;
+  return per <= 1 ? 1 : (per <= 2 ? 2 : (per <= 4 ? 4 : -1));
 }
 
 template <typename T>
@@ -580,18 +597,12 @@ static int rmsnorm_bwd_t(const void* dy, const void* h, const void* w, const flo
                          void* dw, float* ws, int rows, int H, hipStream_t st) {
   constexpr int N = Vec16<T>::N;
   if (H % N || rows <= 0) return TN_EINVAL;
-  const int mv = pick_maxv(H, N);
+  const int mv = pick_maxv_block(H, N);
   const int nb = norm_bwd_blocks(rows);
-  const size_t smem = (size_t)kRowWaves * H * sizeof(float);
-  if (smem > 160 * 1024) return TN_EINVAL;
-  TN_DISPATCH_MAXV(mv, if (smem > 48 * 1024) hipFuncSetAttribute(
-                           reinterpret_cast<const void*>(&rmsnorm_bwd_kernel<T, MAXV>),
-                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-                   hipLaunchKernelGGL((rmsnorm_bwd_kernel<T, MAXV>), dim3(nb), dim3(256), smem, st,
-                                          (const T*)dy, (const T*)h, (const T*)w, rstd, (const T*)dres, (T*)dh, ws,
-                                          rows, H));
+  TN_DISPATCH_MAXV(mv, hipLaunchKernelGGL((rmsnorm_bwd_kernel<T, MAXV>), dim3(nb), dim3(256), 0, st, (const T*)dy,
+                                          (const T*)h, (const T*)w, rstd, (const T*)dres, (T*)dh, ws, rows, H));
   TN_LAUNCH_CHECK();
-  hipLaunchKernelGGL((colsum_partials_kernel<T>), dim3((H + 255) / 256), dim3(256), 0, st, ws, (T*)dw, nb, H);
+  hipLaunchKernelGGL((colsum_partials_kernel<T>), dim3((H + 63) / 64), dim3(256), 0, st, ws, (T*)dw, nb, H);
   TN_LAUNCH_CHECK();
   return TN_OK;
 }
@@ -616,20 +627,15 @@ static int layernorm_bwd_t(const void* dy, const void* h, const void* w, const f
                            hipStream_t st) {
   constexpr int N = Vec16<T>::N;
   if (H % N || rows <= 0) return TN_EINVAL;
-  const int mv = pick_maxv(H, N);
+  const int mv = pick_maxv_block(H, N);
   const int nb = norm_bwd_blocks(rows);
-  const size_t smem = (size_t)2 * kRowWaves * H * sizeof(float);
-  if (smem > 160 * 1024) return TN_EINVAL;
   float* ws_b = ws + (size_t)nb * H;
-  TN_DISPATCH_MAXV(mv, if (smem > 48 * 1024) hipFuncSetAttribute(
-                           reinterpret_cast<const void*>(&layernorm_bwd_kernel<T, MAXV>),
-                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-                   hipLaunchKernelGGL((layernorm_bwd_kernel<T, MAXV>), dim3(nb), dim3(256), smem, st,
-                                          (const T*)dy, (const T*)h, (const T*)w, mean, rstd, (const T*)dres, (T*)dh,
-                                          ws, ws_b, rows, H));
+  TN_DISPATCH_MAXV(mv, hipLaunchKernelGGL((layernorm_bwd_kernel<T, MAXV>), dim3(nb), dim3(256), 0, st, (const T*)dy,
+                                          (const T*)h, (const T*)w, mean, rstd, (const T*)dres, (T*)dh, ws, ws_b,
+                                          rows, H));
   TN_LAUNCH_CHECK();
-  hipLaunchKernelGGL((colsum_partials_kernel<T>), dim3((H + 255) / 256), dim3(256), 0, st, ws, (T*)dw, nb, H);
-  hipLaunchKernelGGL((colsum_partials_kernel<T>), dim3((H + 255) / 256), dim3(256), 0, st, ws_b, (T*)db, nb, H);
+  hipLaunchKernelGGL((colsum_partials_kernel<T>), dim3((H + 63) / 64), dim3(256), 0, st, ws, (T*)dw, nb, H);
+  hipLaunchKernelGGL((colsum_partials_kernel<T>), dim3((H + 63) / 64), dim3(256), 0, st, ws_b, (T*)db, nb, H);
   TN_LAUNCH_CHECK();
   return TN_OK;
 }

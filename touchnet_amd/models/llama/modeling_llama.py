@@ -144,8 +144,15 @@ class PackedCausalLM(nn.Module):
         if config.tie_word_embeddings:
             self.lm_head.weight = self.model.embed_tokens.weight
 
+    def tie_weights(self):
+        """`to_empty()` from the meta device re-creates every Parameter, which silently un-ties
+        lm_head / embed_tokens; re-tie (HF does the same in its post-load hook)."""
+        if self.config.tie_word_embeddings:
+            self.lm_head.weight = self.model.embed_tokens.weight
+
     def post_init(self):
         """HF-style init (normal(0, initializer_range) for Linear/Embedding, ones for norms)."""
+        self.tie_weights()
         std = self.config.initializer_range
         for m in self.modules():
             if isinstance(m, nn.Linear):
