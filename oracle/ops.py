@@ -75,3 +75,9 @@ def packed_cross_entropy(pred, labels, sentence_lens, num_sentence, ignore_index
     acc = _loss.accuracy(pred.detach(), labels, ignore_index)
     nvalid = (labels != ignore_index).sum().float()
     return ps, torch.stack([ps.detach(), pt.detach(), acc.float(), nvalid])
+
+
+def fused_linear_cross_entropy(hidden, weight, labels, sentence_lens, num_sentence, ignore_index=-100,
+                               chunk_tokens=16384):
+    return packed_cross_entropy(torch.nn.functional.linear(hidden, weight), labels, sentence_lens, num_sentence,
+                                ignore_index)

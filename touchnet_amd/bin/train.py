@@ -20,7 +20,6 @@ from typing import Optional
 import torch
 import torch.distributed as dist
 
-from touchnet_amd.loss.cross_entropy import fused_linear_cross_entropy
 from touchnet_amd.models.helper_func import apply_fsdp
 from touchnet_amd.utils.distributed import dist_sum
 from touchnet_amd.utils.optimizer import FusedAdamW, linear_warmup_linear_decay
@@ -46,7 +45,7 @@ class TrainConfig:
 
 class Trainer:
     def __init__(self, job: TrainConfig, model_config, device: torch.device, dp_mesh=None,
-                 spec: Optional[TrainSpec] = None):
+                 spec: Optional[TrainSpec] = None, optimizer_factory=None):
         self.job, self.device, self.dp_mesh = job, device, dp_mesh
         self.spec = spec or get_train_spec(job.training_model_name)
         self.dp_group = dp_mesh.get_group() if dp_mesh is not None else None
@@ -75,9 +74,12 @@ class Trainer:
             if device.type == "cuda":
                 model.to(getattr(torch, job.training_mixed_precision_param))
         self.model = model
-        self.optimizer = FusedAdamW(model.parameters(), lr=job.lr_scheduler_lr,
-                                    weight_decay=job.optimizer_weight_decay, max_norm=job.training_max_norm,
-                                    process_group=self.dp_group if self.dp_world > 1 else None)
+        if optimizer_factory is not None:          # (CPU tests drive the host logic with a torch optimizer)
+            self.optimizer = optimizer_factory(model.parameters())
+        else:
+            self.optimizer = FusedAdamW(model.parameters(), lr=job.lr_scheduler_lr,
+                                        weight_decay=job.optimizer_weight_decay, max_norm=job.training_max_norm,
+                                        process_group=self.dp_group if self.dp_world > 1 else None)
         self.step = 0
 
     # ------------------------------------------------------------------ data
@@ -96,11 +98,10 @@ class Trainer:
         data = dict(data)
         labels, ns, sl = data.pop("labels"), data.pop("num_sentence"), data.pop("sentence_lens")
         data.pop("shift_labels", None)
-        if self.job.training_enable_fused_ce:
-            out = self.model(**data, return_hidden=True)
-            lm = getattr(self.model, "language_model", self.model)
-            return fused_linear_cross_entropy(out.hidden_states, lm.lm_head.weight, labels, sl, ns,
-                                              chunk_tokens=self.job.training_ce_chunk_tokens)
+        if self.job.training_enable_fused_ce:                       # `pred.loss` branch (train.py:443-445)
+            pred = self.model(**data, labels=labels, sentence_lens=sl, num_sentence=ns,
+                              ce_chunk_tokens=self.job.training_ce_chunk_tokens)
+            return pred.loss, pred.loss_per_token, pred.acc
         pred = self.model(**data)
         loss, per_token = self.spec.loss_fn(pred.logits, labels, sl, ns)
         acc = self.spec.acc_fn(pred.logits, labels) if self.spec.acc_fn else None

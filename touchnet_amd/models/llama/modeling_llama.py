@@ -165,9 +165,17 @@ class PackedCausalLM(nn.Module):
                 nn.init.ones_(m.weight)
 
     def forward(self, input_ids=None, inputs_embeds=None, position_ids=None, attention_mask=None,
-                return_hidden: bool = False, **unused):
+                labels=None, sentence_lens=None, num_sentence=None, ce_chunk_tokens: int = 16384, **unused):
+        """Without `labels`: returns `.logits` (the reference's default path, loss_fn runs in the trainer).
+        With `labels` (+ `sentence_lens`, `num_sentence`): lm_head and the packed CE run fused INSIDE the
+        model — the role liger's fused-linear-CE plays in the reference (`pred.loss`, train.py:443-445), but
+        with the per-sentence normalisation kept — and `.loss` / `.loss_per_token` / `.acc` are returned
+        with `.logits = None`.  Being inside forward keeps lm_head under FSDP2's unshard/reshard hooks."""
         h = self.model(input_ids=input_ids, inputs_embeds=inputs_embeds, position_ids=position_ids,
                        attention_mask=attention_mask)
-        if return_hidden:
-            return SimpleNamespace(logits=None, hidden_states=h)
-        return SimpleNamespace(logits=self.lm_head(h), hidden_states=None)
+        if labels is None:
+            return SimpleNamespace(logits=self.lm_head(h), loss=None)
+        from touchnet_amd.loss.cross_entropy import fused_linear_cross_entropy
+        loss, per_token, acc = fused_linear_cross_entropy(h, self.lm_head.weight, labels, sentence_lens, num_sentence,
+                                                          chunk_tokens=ce_chunk_tokens)
+        return SimpleNamespace(logits=None, loss=loss, loss_per_token=per_token, acc=acc)

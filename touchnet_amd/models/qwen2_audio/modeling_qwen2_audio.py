@@ -181,7 +181,7 @@ class Qwen2AudioPackedForConditionalGeneration(nn.Module):
                 m.reset_parameters()
 
     def forward(self, input_ids=None, input_features=None, audio_output_lengths=None, audio_positions=None,
-                attention_mask=None, position_ids=None, return_hidden: bool = False, **unused):
+                attention_mask=None, position_ids=None, **loss_kwargs):
         """input_ids [B, T] packed, AUDIO placeholder tokens where audio features go;
         input_features [n_audio, n_mels, Tm]; audio_output_lengths int64 [n_audio] (valid tokens per audio,
         `((L-1)//2+1-2)//2+1`, processing_qwen2_audio.py:79-82); audio_positions int64 [sum(lengths)] flat
@@ -203,4 +203,4 @@ class Qwen2AudioPackedForConditionalGeneration(nn.Module):
                                  f"({audio_positions.numel()}) mismatch")
             emb = emb.reshape(B * T, H).index_copy(0, audio_positions, feats.to(emb.dtype)).view(B, T, H)
         return self.language_model(inputs_embeds=emb, position_ids=position_ids, attention_mask=attention_mask,
-                                   return_hidden=return_hidden)
+                                   **loss_kwargs)

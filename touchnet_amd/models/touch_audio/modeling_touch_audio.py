@@ -54,7 +54,7 @@ class TouchAudioForCausalLM(nn.Module):
         nn.init.normal_(self.projector.weight, mean=0.0, std=self.config.text_config.initializer_range)
 
     def forward(self, input_ids=None, input_features=None, attention_mask=None, position_ids=None,
-                inputs_embeds=None, return_hidden: bool = False, **unused):
+                inputs_embeds=None, **loss_kwargs):
         if inputs_embeds is None:
             emb = self.language_model.model.embed_tokens(input_ids)             # [B, T, H]
             B, T, H = emb.shape
@@ -65,4 +65,4 @@ class TouchAudioForCausalLM(nn.Module):
         if self.check_nan and torch.isnan(inputs_embeds).any():
             raise ValueError("NaN in data.")
         return self.language_model(inputs_embeds=inputs_embeds, position_ids=position_ids,
-                                   attention_mask=attention_mask, return_hidden=return_hidden)
+                                   attention_mask=attention_mask, **loss_kwargs)

@@ -11,7 +11,7 @@ from touchnet_amd.models import llama, qwen2_audio, touch_audio
 from touchnet_amd.models.helper_func import apply_fsdp
 from touchnet_amd.utils.metrics import accuracy
 from touchnet_amd.utils.optimizer import FusedAdamW, linear_warmup_linear_decay
-from touchnet_amd.utils.train_spec import TrainSpec, _train_specs, register_train_spec
+from touchnet_amd.utils.train_spec import TrainSpec, _train_specs, get_train_spec, register_train_spec  # noqa: F401
 
 
 def _parallelize(model, dp_mesh, job):
