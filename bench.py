@@ -254,7 +254,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-rooflines", action="store_true")
     ap.add_argument("--unfused-ce", action="store_true")
+    ap.add_argument("--no-gemm-tuning", action="store_true", help="library-default GEMM algorithm selection")
     args = ap.parse_args()
+
+    from touchnet_amd.utils import gemm_tuning
+    tuned = (not args.no_gemm_tuning) and gemm_tuning.enable()
 
     import touchnet_amd.specs  # noqa: F401  (registers the TrainSpecs)
     from touchnet_amd.bin.train import Trainer
@@ -314,7 +318,8 @@ def main():
             "config": {"workload": wl.name, "model": wl.job.training_model_name, "global_batch": wl.B * world,
                        "seq_len": wl.T, "parallelism": f"fsdp2-dp{world}" if world > 1 else "single-gpu",
                        "params": trainer.num_params, "flop_per_token": fpt,
-                       "fused_linear_ce": wl.job.training_enable_fused_ce},
+                       "fused_linear_ce": wl.job.training_enable_fused_ce,
+                       "gemm_algorithms": "TunableOp replay (touchnet_amd/tuning)" if tuned else "library default"},
             "step_mfu": round(mfu, 4),
             "mfu_convention": "6*N_wo_emb + 12*L*H*Dh*T per token (touchnet/models/*/__init__.py), no causal/packing "
                               "discount, no recompute credit, tokens = all B*T slots incl. pad",
