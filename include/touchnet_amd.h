@@ -90,6 +90,21 @@ int tn_attn_bwd(const void* q, const void* k, const void* v, const void* o, cons
                 float* delta, void* dq, void* dk, void* dv, const int* doc, const int* meta, int B, int T, int Nh,
                 int Nkv, int D, float scale, void* stream);
 
+/* Sequence-sharded query side — context parallelism (replaces torch's experimental ring-attention CP that the
+ * reference enters at touchnet/utils/distributed.py:292-346 / touchnet/bin/train.py:354-389, which intercepts
+ * SDPA only and cannot carry the document mask).  q/o/dout/dq are [B, rows_per_batch, Nh, D] and lse2/delta
+ * [B, Nh, rows_per_batch]: segment i = local rows [row0_i, row0_i+rows_i) holding GLOBAL positions
+ * [off_i, off_i+rows_i) (head/tail load balancing = 2 segments per rank); `segs` = host int[6]
+ * {row0_a, rows_a, off_a, row0_b, rows_b, off_b}.  k/v/doc/meta are global ([B, T, ...], all-gathered by the
+ * caller); dk/dv come back as this rank's partial sums over [B, T, Nkv, D] for the caller to reduce-scatter. */
+int tn_attn_fwd_seg(const void* q, const void* k, const void* v, void* o, float* lse2, const int* doc,
+                    const int* meta, int B, int T, int Nh, int Nkv, int D, float scale, int nseg,
+                    const int* host_segs, int rows_per_batch, void* stream);
+int tn_attn_bwd_seg(const void* q, const void* k, const void* v, const void* o, const void* dout,
+                    const float* lse2, float* delta, void* dq, void* dk, void* dv, const int* doc, const int* meta,
+                    int B, int T, int Nh, int Nkv, int D, float scale, int nseg, const int* host_segs,
+                    int rows_per_batch, void* stream);
+
 /* ---- audio frontend on device — touchnet/data/functions.py:117-134 (kaldi fbank),
  *      :159-190 (whisper log-mel), :258-286 (stack / stride / normalise).
  * fbank:  wav fp32 [n_samples] in [-1,1) -> feat fp32 [tn_fbank_frames(n_samples), n_mels]

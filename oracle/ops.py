@@ -81,3 +81,19 @@ def fused_linear_cross_entropy(hidden, weight, labels, sentence_lens, num_senten
                                chunk_tokens=16384):
     return packed_cross_entropy(torch.nn.functional.linear(hidden, weight), labels, sentence_lens, num_sentence,
                                 ignore_index)
+
+
+def packed_attention_sharded(q_local, k_full, v_full, mask, shard, scale=None):
+    """Local query rows (global positions per `shard.segs`) against the full K/V — the CP building block."""
+    scale = q_local.shape[-1] ** -0.5 if scale is None else scale
+    pos = torch.cat([torch.arange(off, off + rows) for (_, rows, off) in shard.segs]).to(q_local.device)
+    allow = mask.allow[:, pos, :]                                  # [B, R, T]
+    B, R, Nh, D = q_local.shape
+    g = Nh // k_full.shape[2]
+    k = k_full.transpose(1, 2).repeat_interleave(g, dim=1)
+    v = v_full.transpose(1, 2).repeat_interleave(g, dim=1)
+    s = torch.matmul(q_local.transpose(1, 2), k.transpose(2, 3)) * scale
+    s = s.masked_fill(~allow[:, None], torch.finfo(s.dtype).min)
+    p = torch.softmax(s, dim=-1, dtype=torch.float32).to(q_local.dtype)
+    p = p * allow.any(-1)[:, None, :, None].to(p.dtype)
+    return torch.matmul(p, v).transpose(1, 2).contiguous()

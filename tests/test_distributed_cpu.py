@@ -129,3 +129,92 @@ def test_fsdp2_step_two_ranks_gloo(world):
         results = dict(ret)
     for r in range(world):
         assert results[r][0] == "ok", results[r][1]
+
+
+# --------------------------------------------------------------------------------------------------------
+# context parallel: 2 ranks share one packed batch along the sequence dimension
+# --------------------------------------------------------------------------------------------------------
+CP_CFG = dict(TINY, num_hidden_layers=1)
+
+
+def _cp_reference():
+    import oracle.ops as oops
+    from touchnet_amd.data.synthetic import text_batch
+    from touchnet_amd.models.backend import use_ops
+    from touchnet_amd.models.llama import DecoderConfig, PackedCausalLM
+    torch.manual_seed(11)
+    model = PackedCausalLM(DecoderConfig.from_dict(CP_CFG))
+    model.post_init()
+    batch = text_batch(16, 1, 512, seed=5, max_len=90)
+    with use_ops(oops):
+        out = model(input_ids=batch["input_ids"], position_ids=batch["position_ids"],
+                    attention_mask=batch["attention_mask"], labels=batch["labels"],
+                    sentence_lens=batch["sentence_lens"], num_sentence=batch["num_sentence"])
+        out.loss.backward()
+    return ({k: v.detach().clone() for k, v in model.state_dict().items()},
+            {n: p.grad.clone() for n, p in model.named_parameters()}, float(out.loss), batch)
+
+
+def _cp_worker(rank, world, port, ref_state, ref_grads, ref_loss, batch, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import oracle.ops as oops
+    import touchnet_amd.specs  # noqa: F401
+    from torch.distributed.device_mesh import init_device_mesh
+    from touchnet_amd.bin.train import TrainConfig, Trainer
+    from touchnet_amd.models.backend import use_ops
+    from touchnet_amd.models.llama import DecoderConfig
+    from touchnet_amd.utils.distributed import init_distributed
+    try:
+        init_distributed("cpu")
+        mesh = init_device_mesh("cpu", (1, world), mesh_dim_names=("dp", "cp"))
+        flat = mesh["dp", "cp"]._flatten("dp_cp")
+        job = TrainConfig(training_model_name="llama_mi355", training_enable_fused_ce=True,
+                          training_mixed_precision_param="float32")
+        with use_ops(oops):
+            tr = Trainer(job, DecoderConfig.from_dict(CP_CFG), torch.device("cpu"), dp_mesh=mesh["dp"],
+                         cp_mesh=mesh["cp"], fsdp_mesh=flat, optimizer_factory=lambda ps: TorchAdamW(ps))
+            with torch.no_grad():
+                for name, p in tr.model.named_parameters():
+                    full = ref_state[name]
+                    local = p._local_tensor if hasattr(p, "_local_tensor") else p
+                    local.copy_(full.chunk(world, dim=0)[rank] if local.shape != full.shape else full)
+            data = tr.next_batch(batch)
+            assert data["input_ids"].shape[1] == 512 // world and data["attention_mask"].shape[1] == 512
+            # head/tail load balancing: rank r holds chunks r and 2cp-1-r
+            Tc = 512 // (2 * world)
+            exp = torch.cat([batch["input_ids"][:, rank * Tc:(rank + 1) * Tc],
+                             batch["input_ids"][:, (2 * world - 1 - rank) * Tc:(2 * world - rank) * Tc]], dim=1)
+            assert torch.equal(data["input_ids"], exp)
+            tr.optimizer.zero_grad()
+            loss, _, _ = tr.forward_loss(data)
+            total = loss.detach().clone()
+            dist.all_reduce(total)                                       # loss parts of the cp ranks add up
+            assert float(total) == pytest.approx(ref_loss, rel=1e-5)
+            loss.backward()
+            worst = 0.0
+            for name, p in tr.model.named_parameters():
+                g = p.grad.full_tensor() if hasattr(p.grad, "full_tensor") else p.grad
+                # FSDP AVERAGES over the dp_cp mesh: (1/cp) * sum of the shard gradients = ref / cp
+                worst = max(worst, float((g * world - ref_grads[name]).abs().max()))
+            assert worst < 3e-5, worst
+        ret[rank] = ("ok", float(total), worst)
+    except Exception as e:
+        import traceback
+        ret[rank] = ("fail", traceback.format_exc(), repr(e))
+    finally:
+        if dist.is_initialized():
+            dist.barrier()
+            dist.destroy_process_group()
+
+
+def test_context_parallel_two_ranks_gloo():
+    ref_state, ref_grads, ref_loss, batch = _cp_reference()
+    world = 2
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_cp_worker, args=(world, _free_port(), ref_state, ref_grads, ref_loss, batch, ret), nprocs=world,
+                 join=True)
+        results = dict(ret)
+    for r in range(world):
+        assert results[r][0] == "ok", results[r][1]

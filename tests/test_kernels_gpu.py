@@ -357,3 +357,112 @@ def test_frontend_kaldi_fbank():
         assert y.shape == ref.shape
         np.testing.assert_allclose(y, ref, atol=2e-3)
     assert F.kaldi_fbank(torch.zeros(399, device=DEV), 80).shape == (0, 80)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# BASELINE-size checks through size-independent properties (the oracle cannot finish these sizes in seconds)
+# ---------------------------------------------------------------------------------------------------------
+def test_attention_full_size_packed_equals_per_document():
+    """T = 8192, Qwen2-Audio head shape: attention over the packed row == attention over each document run on
+    its own (the pack-vs-pad equivalence tests/touchnet/utils/test_pack_loss.py asserts for the loss), forward
+    and backward, plus exact zeros on pad rows."""
+    F = _f()
+    B, T, Nh, Nkv, D = 1, 8192, 8, 8, 128
+    doc = _docs(B, T, 77, 1400, 300)
+    g = torch.Generator().manual_seed(8)
+    q, k, v, do = [torch.randn(B, T, n, D, generator=g).bfloat16().to(DEV) for n in (Nh, Nkv, Nkv, Nh)]
+    qg, kg, vg = [t.clone().requires_grad_() for t in (q, k, v)]
+    out = F.packed_attention(qg, kg, vg, F.build_packed_mask(doc.to(DEV)))
+    out.backward(do)
+    ids = doc[0].numpy()
+    for d in np.unique(ids[ids > 0])[:4]:
+        idx = np.nonzero(ids == d)[0]
+        s, e = int(idx[0]), int(idx[-1]) + 1
+        q1, k1, v1 = [t[:, s:e].clone().requires_grad_() for t in (q, k, v)]
+        o1 = F.packed_attention(q1, k1, v1, F.causal_mask(1, e - s, DEV))
+        o1.backward(do[:, s:e])
+        _close(out[:, s:e], o1, 1e-2, 1e-2, f"O doc {d}")
+        _close(qg.grad[:, s:e], q1.grad, 2e-2, 2e-2, f"dQ doc {d}")
+        _close(kg.grad[:, s:e], k1.grad, 2e-2, 2e-2, f"dK doc {d}")
+        _close(vg.grad[:, s:e], v1.grad, 2e-2, 2e-2, f"dV doc {d}")
+    pad = torch.from_numpy(ids == 0)
+    assert float(out[0][pad].float().abs().max()) == 0.0 and float(qg.grad[0][pad].float().abs().max()) == 0.0
+    assert float(kg.grad[0][pad].float().abs().max()) == 0.0
+
+
+def test_attention_deterministic():
+    F = _f()
+    B, T, Nh, D = 2, 1024, 4, 128
+    doc = _docs(B, T, 5, 300, 40).to(DEV)
+    g = torch.Generator().manual_seed(1)
+    q, k, v, do = [torch.randn(B, T, Nh, D, generator=g).bfloat16().to(DEV) for _ in range(4)]
+    res = []
+    for _ in range(2):
+        qg, kg, vg = [t.clone().requires_grad_() for t in (q, k, v)]
+        o = F.packed_attention(qg, kg, vg, F.build_packed_mask(doc))
+        o.backward(do)
+        res.append((o.detach(), qg.grad, kg.grad, vg.grad))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)          # bit-identical: no atomics anywhere (recompute under AC is safe)
+
+
+def test_ce_full_vocab_properties():
+    """V = 156032 (Qwen2-Audio): loss is additive over a split of the packed row (the CP / sequence-shard
+    property of test_pack_loss.py) and the fused lm_head+CE equals lm_head followed by CE."""
+    F = _f()
+    V, H, n = 156032, 256, 96
+    g = torch.Generator().manual_seed(4)
+    h = torch.randn(1, n, H, generator=g).bfloat16().to(DEV)
+    w = (torch.randn(V, H, generator=g) * 0.05).bfloat16().to(DEV)
+    labels = torch.randint(0, V, (1, n), generator=g).to(DEV)
+    labels[0, ::3] = -100
+    sl = torch.randint(1, 20, (1, n), generator=g).to(DEV)
+    logits = torch.nn.functional.linear(h, w)
+    full, st_full = F.packed_cross_entropy(logits, labels, sl, 9)
+    a, _ = F.packed_cross_entropy(logits[:, :40], labels[:, :40], sl[:, :40], 9)
+    b, _ = F.packed_cross_entropy(logits[:, 40:], labels[:, 40:], sl[:, 40:], 9)
+    assert float(a + b) == pytest.approx(float(full), rel=1e-5)
+    hg, wg = h.clone().requires_grad_(), w.clone().requires_grad_()
+    l1, st1 = F.fused_linear_cross_entropy(hg, wg, labels, sl, 9, -100, 32)       # 3 chunks
+    l1.backward()
+    h2, w2 = h.clone().requires_grad_(), w.clone().requires_grad_()
+    l2, st2 = F.packed_cross_entropy(torch.nn.functional.linear(h2, w2), labels, sl, 9)
+    l2.backward()
+    assert float(l1) == pytest.approx(float(l2), rel=1e-5) and float(st1[2]) == float(st2[2])
+    _close(hg.grad, h2.grad, 2e-4, 2e-2, "dh")
+    _close(wg.grad, w2.grad, 2e-4, 3e-2, "dW")
+
+
+@pytest.mark.parametrize("cp,T,Nh,Nkv,D,maxdoc", [(2, 1024, 4, 2, 128, 300), (4, 2048, 2, 2, 64, 2048),
+                                                  (2, 512, 4, 4, 128, 40)])
+def test_sharded_attention_emulated_context_parallel(cp, T, Nh, Nkv, D, maxdoc):
+    """Context-parallel kernels on ONE GPU: every emulated rank runs its head/tail query shard against the full
+    K/V; local outputs / dQ must equal the rows of the full-sequence kernel, partial dK/dV must SUM to the full
+    dK/dV (what the reduce-scatter does)."""
+    F = _f()
+    B = 2
+    doc = _docs(B, T, 3 + cp, maxdoc, 30).to(DEV)
+    g = torch.Generator().manual_seed(T + cp)
+    q = torch.randn(B, T, Nh, D, generator=g).bfloat16().to(DEV)
+    k = torch.randn(B, T, Nkv, D, generator=g).bfloat16().to(DEV)
+    v = torch.randn(B, T, Nkv, D, generator=g).bfloat16().to(DEV)
+    do = torch.randn(B, T, Nh, D, generator=g).bfloat16().to(DEV)
+    mask = F.build_packed_mask(doc)
+    qf, kf, vf = [t.clone().requires_grad_() for t in (q, k, v)]
+    of = F.packed_attention(qf, kf, vf, mask)
+    of.backward(do)
+    Tc = T // (2 * cp)
+    dk_sum, dv_sum = torch.zeros_like(k, dtype=torch.float32), torch.zeros_like(v, dtype=torch.float32)
+    for r in range(cp):
+        pos = torch.cat([torch.arange(r * Tc, (r + 1) * Tc), torch.arange((2 * cp - 1 - r) * Tc, (2 * cp - r) * Tc)])
+        shard = F.SeqShard(((0, Tc, r * Tc), (Tc, Tc, (2 * cp - 1 - r) * Tc)), 2 * Tc)
+        ql = q[:, pos].clone().requires_grad_()
+        kl, vl = k.clone().requires_grad_(), v.clone().requires_grad_()
+        ol = F.packed_attention_sharded(ql, kl, vl, mask, shard)
+        ol.backward(do[:, pos].contiguous())
+        assert torch.equal(ol, of[:, pos]), f"rank {r}: forward differs from the full kernel"
+        _close(ql.grad, qf.grad[:, pos], 1e-6, 0, f"rank {r} dQ")
+        dk_sum += kl.grad.float()
+        dv_sum += vl.grad.float()
+    _close(dk_sum, kf.grad, 3e-2, 2e-2, "sum of partial dK")
+    _close(dv_sum, vf.grad, 3e-2, 2e-2, "sum of partial dV")

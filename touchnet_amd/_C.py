@@ -37,6 +37,9 @@ PROTOTYPES = {
     "tn_attn_build_meta": [_vp, _vp, _i, _i, _vp],
     "tn_attn_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp],
     "tn_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp],
+    "tn_attn_fwd_seg": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _i, _vp],
+    "tn_attn_bwd_seg": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp,
+                        _i, _vp],
     "tn_fbank_frames": [_i],
     "tn_kaldi_fbank": [_vp, _vp, _i, _i, _vp],
     "tn_log_mel": [_vp, _vp, _vp, _vp, _i, _i, _vp],

@@ -45,11 +45,20 @@ class TrainConfig:
 
 class Trainer:
     def __init__(self, job: TrainConfig, model_config, device: torch.device, dp_mesh=None,
-                 spec: Optional[TrainSpec] = None, optimizer_factory=None):
+                 spec: Optional[TrainSpec] = None, optimizer_factory=None, cp_mesh=None, fsdp_mesh=None):
+        """`dp_mesh`: 1-D data-parallel mesh (rows are split over it).  `cp_mesh`: 1-D context-parallel mesh (the
+        sequence dim is split over it); with CP, parameters are sharded over `fsdp_mesh` = dp x cp flattened
+        (the reference's `dp_shard_cp`, touchnet/utils/distributed.py:150-157) and the loss parts of the cp
+        ranks add up (train.py:485-494 reduces over `dp_cp`)."""
         self.job, self.device, self.dp_mesh = job, device, dp_mesh
         self.spec = spec or get_train_spec(job.training_model_name)
         self.dp_group = dp_mesh.get_group() if dp_mesh is not None else None
         self.dp_world = dp_mesh.size() if dp_mesh is not None else 1
+        self.cp_group = cp_mesh.get_group() if cp_mesh is not None and cp_mesh.size() > 1 else None
+        self.cp = None
+        if fsdp_mesh is None:
+            fsdp_mesh = dp_mesh
+        shard_world = fsdp_mesh.size() if fsdp_mesh is not None else 1
         if self.spec.additional_pre_init_fn:
             self.spec.additional_pre_init_fn(job)                      # train.py:121-122
         torch.manual_seed(job.training_seed)
@@ -58,8 +67,8 @@ class Trainer:
         self.model_config = model_config
         self.num_params = self.spec.get_num_params_fn(model)
         self.num_params_wo_emb = self.spec.get_num_params_fn(model, exclude_embedding=True)
-        if dp_mesh is not None and self.dp_world > 1:
-            model = self.spec.parallelize_fn(model, dp_mesh, job)      # fp32 shards, bf16 compute
+        if fsdp_mesh is not None and shard_world > 1:
+            model = self.spec.parallelize_fn(model, fsdp_mesh, job)    # fp32 shards, bf16 compute
             model.to_empty(device=device)
             with torch.no_grad():
                 model.post_init()
@@ -79,7 +88,7 @@ class Trainer:
         else:
             self.optimizer = FusedAdamW(model.parameters(), lr=job.lr_scheduler_lr,
                                         weight_decay=job.optimizer_weight_decay, max_norm=job.training_max_norm,
-                                        process_group=self.dp_group if self.dp_world > 1 else None)
+                                        process_group=fsdp_mesh.get_group() if shard_world > 1 else None)
         self.step = 0
 
     # ------------------------------------------------------------------ data
@@ -91,6 +100,15 @@ class Trainer:
         ns = ns.to(self.device, torch.float32) if isinstance(ns, torch.Tensor) else torch.tensor(
             float(ns), dtype=torch.float32, device=self.device)
         out["num_sentence"] = dist_sum(ns.reshape(1), self.dp_group)   # global over dp (train.py:339-343)
+        if self.cp_group is not None:                                   # train.py:354-389: shard buffers on dim 1
+            from touchnet_amd.utils.context_parallel import ContextParallel
+            T = out["labels"].shape[1]
+            if self.cp is None or self.cp.T != T:
+                self.cp = ContextParallel(self.cp_group, T)
+            for k in ("input_ids", "labels", "position_ids", "sentence_lens", "input_features", "inputs_embeds"):
+                if isinstance(out.get(k), torch.Tensor):
+                    out[k] = self.cp.shard(out[k], dim=1)
+            out["context_parallel"] = self.cp                           # attention_mask (doc ids) stays global
         return out
 
     # ------------------------------------------------------------------ step

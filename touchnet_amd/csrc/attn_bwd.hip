@@ -55,8 +55,8 @@ template <int D, int MODE>
 __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(
     const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
     const bf16_t* __restrict__ dO, const float* __restrict__ LSE2, const float* __restrict__ Delta,
-    bf16_t* __restrict__ dK, bf16_t* __restrict__ dV, const int* __restrict__ doc, AttnMeta meta, int T, int Nh,
-    int Nkv, float scale, float scale_log2) {
+    bf16_t* __restrict__ dK, bf16_t* __restrict__ dV, const int* __restrict__ doc, AttnMeta meta, QView qv, int T,
+    int Nh, int Nkv, float scale, float scale_log2) {
   constexpr bool DO_DV = MODE != 1, DO_DK = MODE != 0;
   constexpr int BNK = 128, BQ = 64;
   constexpr int KSTEPS = D / 16, DBLK = D / 32, LD = D + 8, TS = TLds<BQ>::STRIDE;
@@ -108,13 +108,30 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(
   const int bminpos = min(m_minpos[t0], m_minpos[t1]);
   const int bmax = max(m_max[t0], m_max[t1]);
   const int qhi64 = max(meta.kv_hi[(size_t)b * meta.nt + t0], meta.kv_hi[(size_t)b * meta.nt + t1]);
-  const int qt_lo = k0 / BQ;                                  // first 64-row query tile (q >= kv)
+  const int qt_lo = k0 / BQ;                                  // first 64-row query tile (q >= kv), global index
   const int qt_end = min(qhi64 + 1, meta.nt);                 // exclusive
-  const int nqt = max(qt_end - qt_lo, 0);
+  // query tiles this launch owns: per segment, the global 64-tile range clipped to [qt_lo, qt_end)
+  int seg_lo[2], seg_n[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int first = qv.off[s] / BQ, cnt = qv.tiles(s, BQ);
+    seg_lo[s] = max(qt_lo, first);
+    seg_n[s] = max(min(qt_end, first + cnt) - seg_lo[s], 0);
+  }
+  const int nqt = seg_n[0] + seg_n[1];
   const int n_it = nqt * G;                                   // flattened (head-in-group, q tile)
+  auto tile_of = [&](int it, int& t64, int& lrow0, int& left) {   // global tile, local first row, rows left
+    const int idx = it % nqt;
+    const int s = idx >= seg_n[0] ? 1 : 0;
+    t64 = seg_lo[s] + idx - (s ? seg_n[0] : 0);
+    const int lt = t64 - qv.off[s] / BQ;
+    lrow0 = qv.row0[s] + lt * BQ;
+    left = min(qv.rows[s] - lt * BQ, T - t64 * BQ);
+  };
   auto advance = [&](int it) {
     while (it < n_it) {
-      const int t64 = qt_lo + it % nqt;
+      int t64, l0, left;
+      tile_of(it, t64, l0, left);
       if (tile_may_interact(m_minpos[t64], m_max[t64], bminpos, bmax)) break;
       ++it;
     }
@@ -137,17 +154,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(
   int doc_st = 0;
   const size_t qld = (size_t)Nh * D;
   auto issue = [&](int it) {
-    const int g = it / nqt, qb = (qt_lo + it % nqt) * BQ;
-    const int h = hk * G + g;
-    const size_t base = (((size_t)b * T + qb) * Nh + h) * D;
-    qst.load(Q + base, qld, T - qb, tid);
-    dost.load(dO + base, qld, T - qb, tid);
+    int t64, lrow0, left;
+    tile_of(it, t64, lrow0, left);
+    const int h = hk * G + it / nqt;
+    const size_t base = (((size_t)b * qv.rpb + lrow0) * Nh + h) * D;
+    qst.load(Q + base, qld, left, tid);
+    dost.load(dO + base, qld, left, tid);
     if (tid < BQ) {
-      const bool ok = qb + tid < T;
-      const size_t si = ((size_t)b * Nh + h) * T + (ok ? qb + tid : 0);
+      const bool ok = tid < left;
+      const size_t si = ((size_t)b * Nh + h) * qv.rpb + lrow0 + (ok ? tid : 0);
       lse_st = ok ? LSE2[si] : INFINITY;
       delta_st = ok ? Delta[si] : 0.f;
-      doc_st = ok ? doc[(size_t)b * T + qb + tid] : 0;
+      doc_st = ok ? doc[(size_t)b * T + t64 * BQ + tid] : 0;
     }
   };
 
@@ -170,7 +188,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(
     __syncthreads();
     if (itn < n_it) issue(itn);
 
-    const int t64 = qt_lo + it % nqt;
+    int t64, lrow0_unused, left_unused;
+    tile_of(it, t64, lrow0_unused, left_unused);
     const int qb = t64 * BQ;
     if (uniform(qb + BQ - 1 >= wk0 && tile_may_interact(m_minpos[t64], m_max[t64], wminpos, wmax))) {
       const bool q_uniform = w_uniform && m_min[t64] == m_max[t64] && m_max[t64] == wmax;
@@ -278,8 +297,8 @@ template <int D>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(
     const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
     const bf16_t* __restrict__ dO, const float* __restrict__ LSE2, const float* __restrict__ Delta,
-    bf16_t* __restrict__ dQ, const int* __restrict__ doc, AttnMeta meta, int T, int Nh, int Nkv, float scale,
-    float scale_log2) {
+    bf16_t* __restrict__ dQ, const int* __restrict__ doc, AttnMeta meta, QView qv, int T, int Nh, int Nkv,
+    float scale, float scale_log2) {
   constexpr int BM = 128, BN = 64;
   constexpr int KSTEPS = D / 16, DBLK = D / 32, LD = D + 8, TS = TLds<BN>::STRIDE;
   __shared__ __attribute__((aligned(16))) bf16_t smem[2 * BN * LD + D * TS + 2 * BN];
@@ -290,16 +309,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hi = lane >> 5;
-  const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int h = blockIdx.y, b = blockIdx.z;
   const int hk = h / (Nh / Nkv);
-  const int q0 = qt * BM;
-  const int wq0 = q0 + 32 * wave;
-  const int qrow = wq0 + l31;
-  const bool qvalid = qrow < T;
+  int lq0, q0, qleft;
+  qv.tile(blockIdx.x, BM, lq0, q0, qleft);
+  const int wq0 = q0 + 32 * wave;          // global position of the wave's first query row
+  const int qrow = wq0 + l31;              // global position
+  const int lrow = lq0 + 32 * wave + l31;  // row in the local Q / dO / dQ / LSE / delta buffers
+  const bool qvalid = (32 * wave + l31 < qleft) && (qrow < T);
 
   bf16x8_t qreg[KSTEPS], doreg[KSTEPS];
   {
-    const size_t off = (((size_t)b * T + (qvalid ? qrow : 0)) * Nh + h) * D + 8 * hi;
+    const size_t off = (((size_t)b * qv.rpb + (qvalid ? lrow : 0)) * Nh + h) * D + 8 * hi;
 #pragma unroll
     for (int s = 0; s < KSTEPS; ++s) {
       uint4 a = make_uint4(0, 0, 0, 0), c = make_uint4(0, 0, 0, 0);
@@ -312,8 +333,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(
     }
   }
   const int dq = qvalid ? doc[(size_t)b * T + qrow] : 0;
-  const float lse2 = qvalid ? LSE2[((size_t)b * Nh + h) * T + qrow] : INFINITY;
-  const float delta = qvalid ? Delta[((size_t)b * Nh + h) * T + qrow] : 0.f;
+  const float lse2 = qvalid ? LSE2[((size_t)b * Nh + h) * qv.rpb + lrow] : INFINITY;
+  const float delta = qvalid ? Delta[((size_t)b * Nh + h) * qv.rpb + lrow] : 0.f;
   int wminpos, wmax;
   wave_id_range(dq, wminpos, wmax);
   const bool w_has_zero = __any(dq == 0);
@@ -321,7 +342,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(
   const int* m_min = meta.tmin + (size_t)b * meta.nt;
   const int* m_max = meta.tmax + (size_t)b * meta.nt;
   const int* m_minpos = meta.tminpos + (size_t)b * meta.nt;
-  const int t0 = 2 * qt, t1 = min(2 * qt + 1, meta.nt - 1);
+  const int t0 = q0 / kTile, t1 = min(t0 + 1, meta.nt - 1);
   const int bminpos = min(m_minpos[t0], m_minpos[t1]);
   const int bmax = max(m_max[t0], m_max[t1]);
   const int j_hi = t1;
@@ -418,7 +439,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(
   }
 
   if (qvalid) {
-    bf16_t* op = dQ + (((size_t)b * T + qrow) * Nh + h) * D;
+    bf16_t* op = dQ + (((size_t)b * qv.rpb + lrow) * Nh + h) * D;
 #pragma unroll
     for (int db = 0; db < DBLK; ++db) {
 #pragma unroll
@@ -438,38 +459,62 @@ using namespace tn;
 
 extern "C" {
 
-// delta: float [B, Nh, T] scratch (also an output of this call).  dq/dk/dv are fully overwritten.
-int tn_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse2,
-                float* delta, void* dq, void* dk, void* dv, const int* doc, const int* meta, int B, int T, int Nh,
-                int Nkv, int D, float scale, void* stream) {
+static int attn_bwd_launch(const void* q, const void* k, const void* v, const void* o, const void* dout,
+                           const float* lse2, float* delta, void* dq, void* dk, void* dv, const int* doc,
+                           const int* meta, int B, int T, int Nh, int Nkv, int D, float scale, QView qv,
+                           void* stream) {
   if (B <= 0 || T <= 0 || Nh <= 0 || Nkv <= 0 || Nh % Nkv) return TN_EINVAL;
   if (D != 64 && D != 128) return TN_EINVAL;
+  for (int s = 0; s < qv.nseg; ++s)
+    if (qv.off[s] % 128 || qv.row0[s] % 128 || (s + 1 < qv.nseg && qv.rows[s] % 128)) return TN_EINVAL;
   const int nt = (T + kTile - 1) / kTile, n = B * nt;
   AttnMeta m = {meta, meta + n, meta + 2 * n, meta + 3 * n, meta + 4 * n, nt};
   hipStream_t st = (hipStream_t)stream;
   const float sl2 = scale * 1.4426950408889634f;
-  const size_t rows = (size_t)B * T * Nh;
-  dim3 gq((T + 127) / 128, Nh, B), gk((T + 127) / 128, Nkv, B), block(256);
+  const size_t rows = (size_t)B * qv.rpb * Nh;
+  dim3 gq(qv.tiles(0, 128) + qv.tiles(1, 128), Nh, B), gk((T + 127) / 128, Nkv, B), block(256);
   const bf16_t *Q = (const bf16_t*)q, *K = (const bf16_t*)k, *V = (const bf16_t*)v, *dO = (const bf16_t*)dout;
   if (D == 128) {
     hipLaunchKernelGGL((attn_delta_kernel<128>), dim3((rows * 16 + 255) / 256), block, 0, st, (const bf16_t*)o, dO,
-                       delta, B, T, Nh);
+                       delta, B, qv.rpb, Nh);
     hipLaunchKernelGGL((attn_bwd_kv_kernel<128, 0>), gk, block, 0, st, Q, K, V, dO, lse2, delta, (bf16_t*)dk,
-                       (bf16_t*)dv, doc, m, T, Nh, Nkv, scale, sl2);
+                       (bf16_t*)dv, doc, m, qv, T, Nh, Nkv, scale, sl2);
     hipLaunchKernelGGL((attn_bwd_kv_kernel<128, 1>), gk, block, 0, st, Q, K, V, dO, lse2, delta, (bf16_t*)dk,
-                       (bf16_t*)dv, doc, m, T, Nh, Nkv, scale, sl2);
+                       (bf16_t*)dv, doc, m, qv, T, Nh, Nkv, scale, sl2);
     hipLaunchKernelGGL((attn_bwd_dq_kernel<128>), gq, block, 0, st, Q, K, V, dO, lse2, delta, (bf16_t*)dq, doc, m,
-                       T, Nh, Nkv, scale, sl2);
+                       qv, T, Nh, Nkv, scale, sl2);
   } else {
     hipLaunchKernelGGL((attn_delta_kernel<64>), dim3((rows * 8 + 255) / 256), block, 0, st, (const bf16_t*)o, dO,
-                       delta, B, T, Nh);
+                       delta, B, qv.rpb, Nh);
     hipLaunchKernelGGL((attn_bwd_kv_kernel<64, 2>), gk, block, 0, st, Q, K, V, dO, lse2, delta, (bf16_t*)dk,
-                       (bf16_t*)dv, doc, m, T, Nh, Nkv, scale, sl2);
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<64>), gq, block, 0, st, Q, K, V, dO, lse2, delta, (bf16_t*)dq, doc, m, T,
-                       Nh, Nkv, scale, sl2);
+                       (bf16_t*)dv, doc, m, qv, T, Nh, Nkv, scale, sl2);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<64>), gq, block, 0, st, Q, K, V, dO, lse2, delta, (bf16_t*)dq, doc, m,
+                       qv, T, Nh, Nkv, scale, sl2);
   }
   TN_LAUNCH_CHECK();
   return TN_OK;
+}
+
+// delta: float [B, Nh, T] scratch (also an output of this call).  dq/dk/dv are fully overwritten.
+int tn_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse2,
+                float* delta, void* dq, void* dk, void* dv, const int* doc, const int* meta, int B, int T, int Nh,
+                int Nkv, int D, float scale, void* stream) {
+  const QView qv = {1, {0, 0}, {T, 0}, {0, 0}, T};
+  return attn_bwd_launch(q, k, v, o, dout, lse2, delta, dq, dk, dv, doc, meta, B, T, Nh, Nkv, D, scale, qv, stream);
+}
+
+// Sequence-sharded query side (context parallel), see tn_attn_fwd_seg.  q/o/dout/dq [B, rows_per_batch, Nh, D],
+// lse2/delta [B, Nh, rows_per_batch]; k/v and the outputs dk/dv are GLOBAL [B, T, Nkv, D]: dk/dv receive this
+// rank's partial sums over its own query rows (rows no local query can see are written as zeros) and are
+// reduce-scattered over the CP group by the caller.
+int tn_attn_bwd_seg(const void* q, const void* k, const void* v, const void* o, const void* dout,
+                    const float* lse2, float* delta, void* dq, void* dk, void* dv, const int* doc, const int* meta,
+                    int B, int T, int Nh, int Nkv, int D, float scale, int nseg, const int* segs, int rows_per_batch,
+                    void* stream) {
+  if (nseg < 1 || nseg > 2) return TN_EINVAL;
+  const QView qv = {nseg, {segs[0], nseg > 1 ? segs[3] : 0}, {segs[1], nseg > 1 ? segs[4] : 0},
+                    {segs[2], nseg > 1 ? segs[5] : 0}, rows_per_batch};
+  return attn_bwd_launch(q, k, v, o, dout, lse2, delta, dq, dk, dv, doc, meta, B, T, Nh, Nkv, D, scale, qv, stream);
 }
 
 }  // extern "C"

@@ -52,6 +52,28 @@ struct AttnMeta {
   int nt;
 };
 
+// Which rows of the (possibly sequence-sharded) query-side buffers a launch covers.  Q / O / dO / dQ are
+// [B, rpb, Nh, D] and LSE / delta are [B, Nh, rpb]; segment s = local rows [row0, row0 + rows) holding GLOBAL
+// positions [off, off + rows) of the packed row (K / V / doc ids / metadata are always global, [B, T, ...]).
+// Plain attention: one segment {0, T, 0}, rpb = T.  Context parallel with head/tail load balancing
+// (touchnet/utils/distributed.py:292-315 -> torch's round-robin CP sharding): two segments per rank.
+// Segment offsets and all but the last segment's length must be multiples of 128.
+struct QView {
+  int nseg;
+  int row0[2], rows[2], off[2];
+  int rpb;
+  __host__ __device__ int tiles(int s, int bm) const { return s < nseg ? (rows[s] + bm - 1) / bm : 0; }
+  // tile `idx` of size bm over all segments -> local first row, global first position, rows left in segment
+  __device__ __forceinline__ void tile(int idx, int bm, int& l0, int& g0, int& left) const {
+    const int n0 = tiles(0, bm);
+    const int s = idx >= n0 ? 1 : 0;
+    const int lt = idx - (s ? n0 : 0);
+    l0 = row0[s] + lt * bm;
+    g0 = off[s] + lt * bm;
+    left = rows[s] - lt * bm;
+  }
+};
+
 // Can any (q, kv) pair with q in a set having positive-id range [qminpos, qmax] and kv in tile j be
 // allowed?  Conservative on purpose: false only when the id ranges are disjoint.
 __device__ __forceinline__ bool tile_may_interact(int qminpos, int qmax, int kminpos, int kmax) {

@@ -72,7 +72,8 @@ template <int D>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                        const bf16_t* __restrict__ V, bf16_t* __restrict__ O,
                                                        float* __restrict__ LSE2, const int* __restrict__ doc,
-                                                       AttnMeta meta, int T, int Nh, int Nkv, float scale_log2) {
+                                                       AttnMeta meta, QView qv, int T, int Nh, int Nkv,
+                                                       float scale_log2) {
   constexpr int BM = 128, BN = 64;
   constexpr int KSTEPS = D / 16;   // MFMA k-steps over the head dim
   constexpr int DBLK = D / 32;     // 32-wide output blocks over the head dim
@@ -84,17 +85,19 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hi = lane >> 5;
-  const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int h = blockIdx.y, b = blockIdx.z;
   const int hk = h / (Nh / Nkv);
-  const int q0 = qt * BM;
-  const int wq0 = q0 + 32 * wave;
-  const int qrow = wq0 + l31;
-  const bool qvalid = qrow < T;
+  int lq0, q0, qleft;                      // local first row / global first position / rows left in the segment
+  qv.tile(blockIdx.x, BM, lq0, q0, qleft);
+  const int wq0 = q0 + 32 * wave;          // GLOBAL position of the wave's first query row
+  const int qrow = wq0 + l31;              // global position: what the causal / document predicate compares
+  const int lrow = lq0 + 32 * wave + l31;  // row in the local Q / O / LSE buffers
+  const bool qvalid = (32 * wave + l31 < qleft) && (qrow < T);
 
   // ---- this lane's query row: MFMA B operand for every k-step, and its document id
   bf16x8_t qreg[KSTEPS];
   {
-    const bf16_t* qp = Q + (((size_t)b * T + (qvalid ? qrow : 0)) * Nh + h) * D + 8 * hi;
+    const bf16_t* qp = Q + (((size_t)b * qv.rpb + (qvalid ? lrow : 0)) * Nh + h) * D + 8 * hi;
 #pragma unroll
     for (int s = 0; s < KSTEPS; ++s) {
       uint4 v = make_uint4(0, 0, 0, 0);
@@ -111,7 +114,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
   const int* m_min = meta.tmin + (size_t)b * meta.nt;
   const int* m_max = meta.tmax + (size_t)b * meta.nt;
   const int* m_minpos = meta.tminpos + (size_t)b * meta.nt;
-  const int t0 = 2 * qt, t1 = min(2 * qt + 1, meta.nt - 1);
+  const int t0 = q0 / kTile, t1 = min(t0 + 1, meta.nt - 1);
   const int bminpos = min(m_minpos[t0], m_minpos[t1]);
   const int bmax = max(m_max[t0], m_max[t1]);
   const int j_hi = t1;
@@ -242,7 +245,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
   if (qvalid) {
-    bf16_t* op = O + (((size_t)b * T + qrow) * Nh + h) * D;
+    bf16_t* op = O + (((size_t)b * qv.rpb + lrow) * Nh + h) * D;
 #pragma unroll
     for (int db = 0; db < DBLK; ++db) {
 #pragma unroll
@@ -253,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
         *reinterpret_cast<uint2*>(op + 32 * db + 8 * r4 + 4 * hi) = o;
       }
     }
-    if (hi == 0) LSE2[((size_t)b * Nh + h) * T + qrow] = l_tot > 0.f ? m_run + log2f(l_tot) : INFINITY;
+    if (hi == 0) LSE2[((size_t)b * Nh + h) * qv.rpb + lrow] = l_tot > 0.f ? m_run + log2f(l_tot) : INFINITY;
   }
 }
 
@@ -279,24 +282,44 @@ int tn_attn_build_meta(const int* doc, int* meta, int B, int T, void* stream) {
   return TN_OK;
 }
 
-int tn_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse2, const int* doc, const int* meta,
-                int B, int T, int Nh, int Nkv, int D, float scale, void* stream) {
+static int attn_fwd_launch(const void* q, const void* k, const void* v, void* o, float* lse2, const int* doc,
+                           const int* meta, int B, int T, int Nh, int Nkv, int D, float scale, QView qv,
+                           void* stream) {
   if (B <= 0 || T <= 0 || Nh <= 0 || Nkv <= 0 || Nh % Nkv) return TN_EINVAL;
+  for (int s = 0; s < qv.nseg; ++s)
+    if (qv.off[s] % 128 || qv.row0[s] % 128 || (s + 1 < qv.nseg && qv.rows[s] % 128)) return TN_EINVAL;
   const int nt = (T + kTile - 1) / kTile, n = B * nt;
   AttnMeta m = {meta, meta + n, meta + 2 * n, meta + 3 * n, meta + 4 * n, nt};
-  dim3 grid((T + 127) / 128, Nh, B), block(256);
+  dim3 grid(qv.tiles(0, 128) + qv.tiles(1, 128), Nh, B), block(256);
   const float sl2 = scale * 1.4426950408889634f;
   hipStream_t st = (hipStream_t)stream;
   if (D == 128)
     hipLaunchKernelGGL((attn_fwd_kernel<128>), grid, block, 0, st, (const bf16_t*)q, (const bf16_t*)k,
-                       (const bf16_t*)v, (bf16_t*)o, lse2, doc, m, T, Nh, Nkv, sl2);
+                       (const bf16_t*)v, (bf16_t*)o, lse2, doc, m, qv, T, Nh, Nkv, sl2);
   else if (D == 64)
     hipLaunchKernelGGL((attn_fwd_kernel<64>), grid, block, 0, st, (const bf16_t*)q, (const bf16_t*)k,
-                       (const bf16_t*)v, (bf16_t*)o, lse2, doc, m, T, Nh, Nkv, sl2);
+                       (const bf16_t*)v, (bf16_t*)o, lse2, doc, m, qv, T, Nh, Nkv, sl2);
   else
     return TN_EINVAL;
   TN_LAUNCH_CHECK();
   return TN_OK;
+}
+
+int tn_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse2, const int* doc, const int* meta,
+                int B, int T, int Nh, int Nkv, int D, float scale, void* stream) {
+  const QView qv = {1, {0, 0}, {T, 0}, {0, 0}, T};
+  return attn_fwd_launch(q, k, v, o, lse2, doc, meta, B, T, Nh, Nkv, D, scale, qv, stream);
+}
+
+// Sequence-sharded query side (context parallel): q / o are [B, rows_per_batch, Nh, D], lse2 [B, Nh, rows_per_batch];
+// segs = host int[6] {row0_a, rows_a, off_a, row0_b, rows_b, off_b}; k / v / doc / meta stay global ([B, T, ...]).
+int tn_attn_fwd_seg(const void* q, const void* k, const void* v, void* o, float* lse2, const int* doc,
+                    const int* meta, int B, int T, int Nh, int Nkv, int D, float scale, int nseg, const int* segs,
+                    int rows_per_batch, void* stream) {
+  if (nseg < 1 || nseg > 2) return TN_EINVAL;
+  const QView qv = {nseg, {segs[0], nseg > 1 ? segs[3] : 0}, {segs[1], nseg > 1 ? segs[4] : 0},
+                    {segs[2], nseg > 1 ? segs[5] : 0}, rows_per_batch};
+  return attn_fwd_launch(q, k, v, o, lse2, doc, meta, B, T, Nh, Nkv, D, scale, qv, stream);
 }
 
 }  // extern "C"

@@ -284,6 +284,62 @@ def packed_attention(q, k, v, mask: PackedMask, scale: Optional[float] = None):
     return _PackedAttention.apply(q, k, v, mask, scale)
 
 
+@dataclass(frozen=True)
+class SeqShard:
+    """Which global positions of the packed row the local query-side rows hold (context parallelism).
+    `segs` = up to two (row0, rows, global_offset) triples; buffers are [B, rows_per_batch, ...]."""
+    segs: tuple
+    rows_per_batch: int
+
+    def host_array(self):
+        import ctypes
+        flat = [v for seg in self.segs for v in seg] + [0] * (6 - 3 * len(self.segs))
+        return (ctypes.c_int * 6)(*flat)
+
+
+class _ShardedAttention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k_full, v_full, mask: PackedMask, shard: SeqShard, scale):
+        q, k, v = _c(q), _c(k_full), _c(v_full)
+        if q.dtype != torch.bfloat16:
+            raise _C.KernelError("packed_attention_sharded: bf16 only")
+        B, R, Nh, D = q.shape
+        T, Nkv = k.shape[1], k.shape[2]
+        if (B, T) != (mask.B, mask.T) or R != shard.rows_per_batch:
+            raise _C.KernelError(f"mask {(mask.B, mask.T)} / shard {shard.rows_per_batch} vs q {(B, R)} k {(B, T)}")
+        o = torch.empty_like(q)
+        lse2 = torch.empty(B, Nh, R, dtype=torch.float32, device=q.device)
+        segs = shard.host_array()
+        _C.check(_C.lib().tn_attn_fwd_seg(_p(q), _p(k), _p(v), _p(o), _p(lse2), _p(mask.doc), _p(mask.meta), B, T, Nh,
+                                          Nkv, D, float(scale), len(shard.segs), segs, R, _cur()), "tn_attn_fwd_seg")
+        ctx.save_for_backward(q, k, v, o, lse2)
+        ctx.mask, ctx.shard, ctx.scale = mask, shard, float(scale)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, o, lse2 = ctx.saved_tensors
+        do = _c(do)
+        B, R, Nh, D = q.shape
+        T, Nkv = k.shape[1], k.shape[2]
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        delta = torch.empty_like(lse2)
+        m, sh = ctx.mask, ctx.shard
+        _C.check(_C.lib().tn_attn_bwd_seg(_p(q), _p(k), _p(v), _p(o), _p(do), _p(lse2), _p(delta), _p(dq), _p(dk),
+                                          _p(dv), _p(m.doc), _p(m.meta), B, T, Nh, Nkv, D, ctx.scale, len(sh.segs),
+                                          sh.host_array(), R, _cur()), "tn_attn_bwd_seg")
+        return dq, dk, dv, None, None, None
+
+
+def packed_attention_sharded(q_local, k_full, v_full, mask: PackedMask, shard: SeqShard,
+                             scale: Optional[float] = None):
+    """Context-parallel building block: local query rows (per `shard`) against the full, all-gathered K/V.
+    The gradient w.r.t. k_full / v_full is this rank's PARTIAL sum (to be reduce-scattered by the caller)."""
+    if scale is None:
+        scale = q_local.shape[-1] ** -0.5
+    return _ShardedAttention.apply(q_local, k_full, v_full, mask, shard, scale)
+
+
 # ------------------------------------------------------------------------------------ loss
 def _num_sentence_dev(num_sentence, device):
     if isinstance(num_sentence, torch.Tensor):

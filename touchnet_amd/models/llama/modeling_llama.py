@@ -66,7 +66,12 @@ class Attention(nn.Module):
         k = self.k_proj(x).view(B, T, self.num_kv_heads, self.head_dim)
         v = self.v_proj(x).view(B, T, self.num_kv_heads, self.head_dim)
         q, k = ops().apply_rope(q, k, cos, sin)
-        a = ops().packed_attention(q, k, v, mask, self.scaling)
+        cp = getattr(mask, "cp", None)
+        if cp is not None:            # context parallel: local queries vs all-gathered K/V (utils/context_parallel.py)
+            a = ops().packed_attention_sharded(q, cp.gather_seq(k), cp.gather_seq(v), mask, cp.seq_shard(),
+                                               self.scaling)
+        else:
+            a = ops().packed_attention(q, k, v, mask, self.scaling)
         return self.o_proj(a.view(B, T, self.num_heads * self.head_dim))
 
 
@@ -111,7 +116,11 @@ class DecoderModel(nn.Module):
         self.norm = RMSNorm(config.hidden_size, config.rms_norm_eps)
         self.rotary_emb = RotaryEmbedding(config)
 
-    def forward(self, input_ids=None, inputs_embeds=None, position_ids=None, attention_mask=None):
+    def forward(self, input_ids=None, inputs_embeds=None, position_ids=None, attention_mask=None,
+                context_parallel=None):
+        """With `context_parallel` (utils.context_parallel.ContextParallel): input_ids / inputs_embeds /
+        position_ids are this rank's sequence shard [B, T/cp], `attention_mask` stays the GLOBAL [B, T]
+        document-id tensor (it is tiny and every rank needs the tile metadata of the keys it attends to)."""
         if inputs_embeds is None:
             inputs_embeds = self.embed_tokens(input_ids)
         B, T, _ = inputs_embeds.shape
@@ -123,6 +132,8 @@ class DecoderModel(nn.Module):
             mask = ops().causal_mask(B, T, inputs_embeds.device)
         elif isinstance(mask, torch.Tensor):               # the packers' document ids, [B, T] ints
             mask = ops().build_packed_mask(mask)
+        if context_parallel is not None:
+            mask.cp = context_parallel
         delta, residual = inputs_embeds, None
         for layer in self.layers:
             delta, residual = layer(delta, residual, cos, sin, mask)
@@ -165,14 +176,15 @@ class PackedCausalLM(nn.Module):
                 nn.init.ones_(m.weight)
 
     def forward(self, input_ids=None, inputs_embeds=None, position_ids=None, attention_mask=None,
-                labels=None, sentence_lens=None, num_sentence=None, ce_chunk_tokens: int = 16384, **unused):
+                labels=None, sentence_lens=None, num_sentence=None, ce_chunk_tokens: int = 16384,
+                context_parallel=None, **unused):
         """Without `labels`: returns `.logits` (the reference's default path, loss_fn runs in the trainer).
         With `labels` (+ `sentence_lens`, `num_sentence`): lm_head and the packed CE run fused INSIDE the
         model — the role liger's fused-linear-CE plays in the reference (`pred.loss`, train.py:443-445), but
         with the per-sentence normalisation kept — and `.loss` / `.loss_per_token` / `.acc` are returned
         with `.logits = None`.  Being inside forward keeps lm_head under FSDP2's unshard/reshard hooks."""
         h = self.model(input_ids=input_ids, inputs_embeds=inputs_embeds, position_ids=position_ids,
-                       attention_mask=attention_mask)
+                       attention_mask=attention_mask, context_parallel=context_parallel)
         if labels is None:
             return SimpleNamespace(logits=self.lm_head(h), loss=None)
         from touchnet_amd.loss.cross_entropy import fused_linear_cross_entropy

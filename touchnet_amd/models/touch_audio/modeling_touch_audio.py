@@ -54,7 +54,7 @@ class TouchAudioForCausalLM(nn.Module):
         nn.init.normal_(self.projector.weight, mean=0.0, std=self.config.text_config.initializer_range)
 
     def forward(self, input_ids=None, input_features=None, attention_mask=None, position_ids=None,
-                inputs_embeds=None, **loss_kwargs):
+                inputs_embeds=None, **loss_kwargs):   # loss_kwargs: labels / sentence_lens / num_sentence / context_parallel
         if inputs_embeds is None:
             emb = self.language_model.model.embed_tokens(input_ids)             # [B, T, H]
             B, T, H = emb.shape
