@@ -289,7 +289,8 @@ def test_packed_attention_online_softmax_rescale():
     q = (torch.randn(B, T, Nh, D, generator=g) * 0.3).bfloat16()
     k = (torch.randn(B, T, Nh, D, generator=g) * 0.3).bfloat16()
     v = torch.randn(B, T, Nh, D, generator=g).bfloat16()
-    k[0, 300, 0] = q[0, 350, 0] * 40        # spike: row 350 sees its max jump at KV tile 4
+    k[0, 300, 0] = q[0, 350, 0] * 40        # spike: row 350 sees its max jump at KV tile 4 (forces the rescale)
+    k[0, 200, 0] = q[0, 260, 0] * 3         # mild growth (< 2^8): exercises the deferred-rescale path
     doc = torch.ones(B, T, dtype=torch.int64)
     ref = onn.attention(q.float().transpose(1, 2), k.float().transpose(1, 2), v.float().transpose(1, 2),
                         onn.doc_causal_allow(doc), D ** -0.5)

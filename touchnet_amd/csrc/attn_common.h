@@ -109,6 +109,14 @@ struct TLds {
   static __device__ __forceinline__ int off(int d, int g) { return d * STRIDE + 4 * ((g ^ (d >> 3)) & (R / 4 - 1)); }
 };
 
+// 8-byte LDS accesses of the transposed images.  hipcc's SI load/store optimizer pairs neighbouring ones into
+// ds_read2_b64 / ds_write2_b64 (32-bank rules, contiguous 16-lane groups), under which the TLds swizzle shows
+// SQ_LDS_BANK_CONFLICT = 23-36 % of SQ_LDS_IDX_ACTIVE.  Forcing single ds_read_b64 (volatile LDS pointers) removes
+// the conflicts but serialises the accesses and measured 2-8 % SLOWER end to end (fwd causal 2.01 -> 2.04 ms, bwd
+// 7.27 -> 7.83 ms), so the paired form stays: LDS is not the limiter of these kernels (profiles/r01_*pmc*).
+__device__ __forceinline__ uint64_t lds_load64(const bf16_t* p) { return *reinterpret_cast<const uint64_t*>(p); }
+__device__ __forceinline__ void lds_store64(bf16_t* p, uint64_t v) { *reinterpret_cast<uint64_t*>(p) = v; }
+
 // MFMA-operand reads of a TLds<R> image cost ZERO address VALU inside the tile loops: for lane (l31, hi),
 // row d = 32*db + l31 and group g = ghi + glo (ghi a multiple of 4, glo in {hi, hi + 2}) the swizzle splits as
 //   off(d, g) = [l31*STRIDE + 4*(glo ^ (l31 >> 3))]  +  [32*db*STRIDE + 4*(ghi ^ 4*db)]
@@ -126,9 +134,10 @@ struct TLdsReader {
   }
   // 8 contraction slots (groups ghi+hi and ghi+hi+2) of row 32*db + l31
   __device__ __forceinline__ bf16x8_t operand(const bf16_t* img, int db, int ghi) const {
-    const uint2 lo = *reinterpret_cast<const uint2*>(img + a0 + c(db, ghi));
-    const uint2 hi2 = *reinterpret_cast<const uint2*>(img + a2 + c(db, ghi));
-    return as_bf16x8(lo, hi2);
+    const uint64_t lo = lds_load64(img + a0 + c(db, ghi));
+    const uint64_t hi2 = lds_load64(img + a2 + c(db, ghi));
+    u32x4_t t = {(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi2, (uint32_t)(hi2 >> 32)};
+    return __builtin_bit_cast(bf16x8_t, t);
   }
 };
 
@@ -227,7 +236,7 @@ struct TransposeStage {
             o.x = __builtin_amdgcn_perm(w[1][wi], w[0][wi], 0x05040100u);
             o.y = __builtin_amdgcn_perm(w[3][wi], w[2][wi], 0x05040100u);
           }
-          *reinterpret_cast<uint2*>(dst + TLds<R>::off(c8 * 8 + dd, r4)) = o;
+          lds_store64(dst + TLds<R>::off(c8 * 8 + dd, r4), (uint64_t)o.x | ((uint64_t)o.y << 32));
         }
       }
     }

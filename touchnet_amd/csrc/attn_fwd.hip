@@ -78,10 +78,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
   constexpr int KSTEPS = D / 16;   // MFMA k-steps over the head dim
   constexpr int DBLK = D / 32;     // 32-wide output blocks over the head dim
   constexpr int KLD = D + 8;       // row-major K image leading dim (elements)
-  __shared__ __attribute__((aligned(16))) bf16_t smem[BN * KLD + D * TLds<BN>::STRIDE + 2 * BN];
-  bf16_t* Ks = smem;
-  bf16_t* Vt = smem + BN * KLD;
-  int* docs = reinterpret_cast<int*>(smem + BN * KLD + D * TLds<BN>::STRIDE);
+  // two LDS buffers {K row-major | V^T swizzled | doc ids}: tile j+1 is written while tile j is being consumed,
+  // ONE barrier per KV tile (2 x 38 KB at D=128 -> still two workgroups per CU)
+  constexpr int BUF = BN * KLD + D * TLds<BN>::STRIDE + 2 * BN;
+  __shared__ __attribute__((aligned(16))) bf16_t smem[2 * BUF];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hi = lane >> 5;
@@ -145,17 +145,26 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
     vst.load(V + base, kvld, T - k0, tid);
     if (tid < BN) dstage = (k0 + tid < T) ? doc[(size_t)b * T + k0 + tid] : 0;
   };
-  if (j <= j_hi) issue(j);
+  auto stage_store = [&](int buf) {
+    bf16_t* base = smem + buf * BUF;
+    kst.store(base, tid);
+    vst.store(base + BN * KLD, tid);
+    if (tid < BN) reinterpret_cast<int*>(base + BN * KLD + D * TLds<BN>::STRIDE)[tid] = dstage;
+  };
+  int jn = j_hi + 1;
+  if (j <= j_hi) {
+    issue(j);
+    stage_store(0);
+    jn = advance(j + 1);
+    if (jn <= j_hi) issue(jn);          // tile j+1 flies under the compute of tile j
+  }
+  __syncthreads();
+  int cur = 0;
 
   while (j <= j_hi) {
-    const int jn = advance(j + 1);
-    __syncthreads();  // everyone finished reading the previous tile
-    kst.store(Ks, tid);
-    vst.store(Vt, tid);
-    if (tid < BN) docs[tid] = dstage;
-    __syncthreads();
-    if (jn <= j_hi) issue(jn);  // next tile's HBM loads fly under this tile's MFMAs
-
+    const bf16_t* Ks = smem + cur * BUF;
+    const bf16_t* Vt = Ks + BN * KLD;
+    const int* docs = reinterpret_cast<const int*>(Vt + D * TLds<BN>::STRIDE);
     const int k0 = j * BN;
     const int kminpos = m_minpos[j], kmax = m_max[j];
     if (uniform(k0 <= wq0 + 31 && tile_may_interact(wminpos, wmax, kminpos, kmax))) {
@@ -171,39 +180,44 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
         for (int s = 1; s < KSTEPS; ++s)
           sacc[blk] = mfma32(as_bf16x8(*reinterpret_cast<const uint4*>(kp + 16 * s)), qreg[s], sacc[blk]);
       }
-      // ---- scale, mask, online softmax (lane-local: this lane's query column)
+      // ---- mask, online softmax (lane-local: this lane's query column).  Scores stay RAW in the accumulator;
+      // the softmax scale rides in the exponent's fma: p = exp2(s * c - m), m tracked in the scaled domain.
       float mx = -INFINITY;
-      auto scale_mask = [&](auto masked) {
-        constexpr bool MASK = decltype(masked)::value;
+      if (need_mask) {
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk) {
 #pragma unroll
           for (int r4 = 0; r4 < 4; ++r4) {
-            int dkk[4] = {0, 0, 0, 0};
-            if (MASK) {
-              const int4 dk = *reinterpret_cast<const int4*>(docs + 32 * blk + 8 * r4 + 4 * hi);
-              dkk[0] = dk.x; dkk[1] = dk.y; dkk[2] = dk.z; dkk[3] = dk.w;
-            }
+            const int4 dk = *reinterpret_cast<const int4*>(docs + 32 * blk + 8 * r4 + 4 * hi);
+            const int dkk[4] = {dk.x, dk.y, dk.z, dk.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              const int r = 4 * r4 + e;
-              float s = sacc[blk][r] * scale_log2;
-              if (MASK) {
-                const int kv = k0 + 32 * blk + 8 * r4 + 4 * hi + e;
-                const bool ok = (kv <= qrow) & (dkk[e] == dq) & (dq > 0);
-                s = ok ? s : -INFINITY;
-              }
-              sacc[blk][r] = s;
-              mx = fmaxf(mx, s);
+              const int kv = k0 + 32 * blk + 8 * r4 + 4 * hi + e;
+              const bool ok = (kv <= qrow) & (dkk[e] == dq) & (dq > 0);
+              sacc[blk][4 * r4 + e] = ok ? sacc[blk][4 * r4 + e] : -INFINITY;
             }
           }
         }
-      };
-      if (need_mask) scale_mask(std::true_type{}); else scale_mask(std::false_type{});
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m_run, mx);
-      const float alpha = fast_exp2(m_run - m_new);
-      m_run = m_new;
+      }
+#pragma unroll
+      for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) mx = fmaxf(mx, fmaxf(sacc[blk][r], sacc[blk][r + 1]));   // v_max3_f32
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * scale_log2;
+      // Deferred rescale (threshold 8 in the log2 domain): while no row's running max grows by more than 2^8 the
+      // old reference max stays, P <= 256 is exact enough in bf16 and the 16*DBLK-register O rescale is skipped.
+      float alpha = 1.f;
+      if (uniform(!__all(mx - m_run <= 8.f))) {
+        const float m_new = fmaxf(m_run, mx);
+        alpha = fast_exp2(m_run - m_new);
+        m_run = m_new;
+        l_run *= alpha;
+#pragma unroll
+        for (int i = 0; i < DBLK; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+      }
+      const float neg_m = -m_run;
       float psum = 0.f;
       bf16x8_t pb[2][2];
 #pragma unroll
@@ -213,20 +227,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
           float p[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
-            p[e] = fast_exp2(sacc[blk][8 * sp + e] - m_new);
+            p[e] = fast_exp2(fmaf(sacc[blk][8 * sp + e], scale_log2, neg_m));
             psum += p[e];
           }
           u32x4_t t = {pack2bf(p[0], p[1]), pack2bf(p[2], p[3]), pack2bf(p[4], p[5]), pack2bf(p[6], p[7])};
           pb[blk][sp] = __builtin_bit_cast(bf16x8_t, t);
         }
       }
-      l_run = l_run * alpha + psum;
-      if (uniform(!__all(alpha == 1.f))) {
-#pragma unroll
-        for (int i = 0; i < DBLK; ++i)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
-      }
+      l_run += psum;
       // ---- O^T[d, q] += V^T[d, kv] P^T[kv, q]
 #pragma unroll
       for (int db = 0; db < DBLK; ++db) {
@@ -238,7 +246,20 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
         }
       }
     }
-    j = jn;
+    // ---- hand-over: tile jn (already in registers) -> the other buffer, then prefetch the tile after it.
+    // WAR-safe: the other buffer was last read in the previous iteration, which every wave left through the
+    // barrier below; RAW-safe: it is read only after this iteration's barrier.
+    if (jn <= j_hi) {
+      stage_store(cur ^ 1);
+      const int jnn = advance(jn + 1);
+      if (jnn <= j_hi) issue(jnn);
+      j = jn;
+      jn = jnn;
+    } else {
+      j = jn;
+    }
+    __syncthreads();
+    cur ^= 1;
   }
 
   // ---- epilogue: normalise, store O (4 consecutive head-dim elements = 8 bytes per store) and LSE2
