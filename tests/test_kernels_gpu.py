@@ -249,6 +249,7 @@ ATT_CASES = [
     (1, 1500, 2, 2, 64, 1500, 0),      # whisper-tower length, plain causal (single doc)
     (2, 384, 8, 4, 128, 7, 5),         # many tiny docs
     (1, 1024, 4, 4, 128, 300, 100),
+    (1, 640, 14, 2, 128, 200, 17),     # Kimi-Audio head geometry (28 q heads / 4 kv heads: GQA 7:1), halved
 ]
 
 
