@@ -28,24 +28,23 @@ def post_init(model: PackedCausalLM, init_device: torch.device):
 
 
 def get_num_flop_per_token(num_params: int, model_config, seq_len: int) -> int:
-    """6*N + 12*L*H*Dh*T, the reference's MFU convention (touchnet/models/llama/__init__.py:39-54):
-    no causal / packing sparsity discount, no recompute credit."""
-    cfg = getattr(model_config, "text_config", model_config)
-    l, h = cfg.num_hidden_layers, cfg.num_attention_heads
-    q = cfg.hidden_size // cfg.num_attention_heads
-    return 6 * num_params + 12 * l * h * q * seq_len
+    """Reference MFU convention (touchnet/models/llama/__init__.py:39-54): dense-parameter term 6*N plus the
+    attention-score term 12 * layers * heads * head_dim * T — 2 matmuls forward + 4 backward, x2 for
+    multiply-add, NO discount for causal / packing sparsity, NO credit for recomputation."""
+    text = getattr(model_config, "text_config", model_config)
+    head_dim = text.hidden_size // text.num_attention_heads
+    attention_term = 12 * text.num_hidden_layers * text.num_attention_heads * head_dim * seq_len
+    return 6 * num_params + attention_term
 
 
 def get_num_params(model: torch.nn.Module, exclude_embedding: bool = False) -> int:
-    """touchnet/models/llama/__init__.py:57-67 (embedding = nn.Embedding children of the base model)."""
+    """Parameter count as touchnet/models/llama/__init__.py:57-67 defines it (tied weights once; with
+    `exclude_embedding` the nn.Embedding children of the base model are left out — that is N_wo_emb of the MFU)."""
     lm = getattr(model, "language_model", model)
-    seen, total = set(), 0
-    for p in model.parameters():
-        if id(p) not in seen:
-            seen.add(id(p))
-            total += p.numel()
-    if exclude_embedding:
-        sub = getattr(lm, getattr(lm, "base_model_prefix", "model"))
-        total -= sum(sum(p.numel() for p in m.parameters()) for m in sub.children()
-                     if isinstance(m, torch.nn.Embedding))
-    return total
+    unique = {id(p): p.numel() for p in model.parameters()}
+    total = sum(unique.values())
+    if not exclude_embedding:
+        return total
+    base = getattr(lm, getattr(lm, "base_model_prefix", "model"))
+    emb = [m for m in base.children() if isinstance(m, torch.nn.Embedding)]
+    return total - sum(p.numel() for m in emb for p in m.parameters())
