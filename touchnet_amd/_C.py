@@ -40,6 +40,7 @@ PROTOTYPES = {
     "tn_attn_fwd_seg": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _i, _vp],
     "tn_attn_bwd_seg": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp,
                         _i, _vp],
+    "tn_attn_fwd_ablate": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp],
     "tn_fbank_frames": [_i],
     "tn_kaldi_fbank": [_vp, _vp, _i, _i, _vp],
     "tn_log_mel": [_vp, _vp, _vp, _vp, _i, _i, _vp],

@@ -68,13 +68,15 @@ __global__ void attn_meta_range_kernel(const int* __restrict__ tmax, const int* 
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int D>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+// ABL (ablation, timing experiments only — results are wrong for ABL != 0; reached through tn_attn_fwd_ablate):
+//   1 no in-loop global loads / LDS stores   2 no softmax VALU   3 no P.V MFMAs   4 no QK^T MFMAs   5 no barrier
+template <int D, int ABL = 0, int NW = 4>
+__global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                        const bf16_t* __restrict__ V, bf16_t* __restrict__ O,
                                                        float* __restrict__ LSE2, const int* __restrict__ doc,
                                                        AttnMeta meta, QView qv, int T, int Nh, int Nkv,
                                                        float scale_log2) {
-  constexpr int BM = 128, BN = 64;
+  constexpr int BM = 32 * NW, BN = 64, NT = 64 * NW;   // NW waves x 32 query rows
   constexpr int KSTEPS = D / 16;   // MFMA k-steps over the head dim
   constexpr int DBLK = D / 32;     // 32-wide output blocks over the head dim
   constexpr int KLD = D + 8;       // row-major K image leading dim (elements)
@@ -114,11 +116,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
   const int* m_min = meta.tmin + (size_t)b * meta.nt;
   const int* m_max = meta.tmax + (size_t)b * meta.nt;
   const int* m_minpos = meta.tminpos + (size_t)b * meta.nt;
-  const int t0 = q0 / kTile, t1 = min(t0 + 1, meta.nt - 1);
-  const int bminpos = min(m_minpos[t0], m_minpos[t1]);
-  const int bmax = max(m_max[t0], m_max[t1]);
+  const int t0 = q0 / kTile, t1 = min(t0 + BM / kTile - 1, meta.nt - 1);
+  int bminpos = 0x7fffffff, bmax = 0, j = meta.nt;
+  for (int t = t0; t <= t1; ++t) {
+    bminpos = min(bminpos, m_minpos[t]);
+    bmax = max(bmax, m_max[t]);
+    j = min(j, meta.q_lo[(size_t)b * meta.nt + t]);
+  }
   const int j_hi = t1;
-  int j = min(meta.q_lo[(size_t)b * meta.nt + t0], meta.q_lo[(size_t)b * meta.nt + t1]);
   auto advance = [&](int jj) {
     while (jj <= j_hi && !tile_may_interact(bminpos, bmax, m_minpos[jj], m_max[jj])) ++jj;
     return jj;
@@ -134,8 +139,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
   const TLdsReader<BN> vrd(l31, hi);
   const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
-  RowMajorStage<BN, D, 256> kst;
-  TransposeStage<BN, D, 256> vst;
+  RowMajorStage<BN, D, NT> kst;
+  TransposeStage<BN, D, NT> vst;
   int dstage = 0;
   const size_t kvld = (size_t)Nkv * D;
   auto issue = [&](int jj) {
@@ -177,7 +182,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
         const bf16_t* kp = Ks + (32 * blk + l31) * KLD + 8 * hi;
         sacc[blk] = mfma32(as_bf16x8(*reinterpret_cast<const uint4*>(kp)), qreg[0], zero16);
 #pragma unroll
-        for (int s = 1; s < KSTEPS; ++s)
+        for (int s = 1; s < (ABL == 4 ? 1 : KSTEPS); ++s)
           sacc[blk] = mfma32(as_bf16x8(*reinterpret_cast<const uint4*>(kp + 16 * s)), qreg[s], sacc[blk]);
       }
       // ---- mask, online softmax (lane-local: this lane's query column).  Scores stay RAW in the accumulator;
@@ -204,6 +209,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
 #pragma unroll
         for (int r = 0; r < 16; r += 2) mx = fmaxf(mx, fmaxf(sacc[blk][r], sacc[blk][r + 1]));   // v_max3_f32
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * scale_log2;
+      if (ABL == 2) mx = m_run;
       // Deferred rescale (threshold 8 in the log2 domain): while no row's running max grows by more than 2^8 the
       // old reference max stays, P <= 256 is exact enough in bf16 and the 16*DBLK-register O rescale is skipped.
       float alpha = 1.f;
@@ -227,8 +233,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
           float p[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
-            p[e] = fast_exp2(fmaf(sacc[blk][8 * sp + e], scale_log2, neg_m));
-            psum += p[e];
+            p[e] = ABL == 2 ? sacc[blk][8 * sp + e] : fast_exp2(fmaf(sacc[blk][8 * sp + e], scale_log2, neg_m));
+            if (ABL != 2) psum += p[e];
           }
           u32x4_t t = {pack2bf(p[0], p[1]), pack2bf(p[2], p[3]), pack2bf(p[4], p[5]), pack2bf(p[6], p[7])};
           pb[blk][sp] = __builtin_bit_cast(bf16x8_t, t);
@@ -241,8 +247,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk) {
 #pragma unroll
-          for (int sp = 0; sp < 2; ++sp)
+          for (int sp = 0; sp < 2; ++sp) {
+            if (ABL == 3 && (db | blk | sp)) {
+              asm volatile("" ::"v"(pb[blk][sp]));      // keep P live so its producers are not dead code
+              continue;
+            }
             oacc[db] = mfma32(vrd.operand(Vt, db, 8 * blk + 4 * sp), pb[blk][sp], oacc[db]);
+          }
         }
       }
     }
@@ -250,15 +261,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
     // WAR-safe: the other buffer was last read in the previous iteration, which every wave left through the
     // barrier below; RAW-safe: it is read only after this iteration's barrier.
     if (jn <= j_hi) {
-      stage_store(cur ^ 1);
+      if (ABL != 1) stage_store(cur ^ 1);
       const int jnn = advance(jn + 1);
-      if (jnn <= j_hi) issue(jnn);
+      if (jnn <= j_hi && ABL != 1) issue(jnn);
       j = jn;
       jn = jnn;
     } else {
       j = jn;
     }
-    __syncthreads();
+    if (ABL != 5) __syncthreads();
     cur ^= 1;
   }
 
@@ -284,6 +295,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
 }  // namespace tn
 
 using namespace tn;
+
+template <int ABL, int NW = 4>
+static int attn_fwd_launch_abl(const void* q, const void* k, const void* v, void* o, float* lse2, const int* doc,
+                               AttnMeta m, QView qv, int B, int T, int Nh, int Nkv, float sl2, hipStream_t st) {
+  dim3 grid(qv.tiles(0, 32 * NW) + qv.tiles(1, 32 * NW), Nh, B), block(64 * NW);
+  hipLaunchKernelGGL((attn_fwd_kernel<128, ABL, NW>), grid, block, 0, st, (const bf16_t*)q, (const bf16_t*)k,
+                     (const bf16_t*)v, (bf16_t*)o, lse2, doc, m, qv, T, Nh, Nkv, sl2);
+  TN_LAUNCH_CHECK();
+  return TN_OK;
+}
 
 extern "C" {
 
@@ -330,6 +351,26 @@ int tn_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse
                 int B, int T, int Nh, int Nkv, int D, float scale, void* stream) {
   const QView qv = {1, {0, 0}, {T, 0}, {0, 0}, T};
   return attn_fwd_launch(q, k, v, o, lse2, doc, meta, B, T, Nh, Nkv, D, scale, qv, stream);
+}
+
+// Timing experiments only (D = 128): the forward with one piece removed, see ABL above.  Output is garbage.
+int tn_attn_fwd_ablate(const void* q, const void* k, const void* v, void* o, float* lse2, const int* doc,
+                       const int* meta, int B, int T, int Nh, int Nkv, float scale, int ablation, void* stream) {
+  const int nt = (T + kTile - 1) / kTile, n = B * nt;
+  AttnMeta m = {meta, meta + n, meta + 2 * n, meta + 3 * n, meta + 4 * n, nt};
+  const QView qv = {1, {0, 0}, {T, 0}, {0, 0}, T};
+  const float sl2 = scale * 1.4426950408889634f;
+  hipStream_t st = (hipStream_t)stream;
+  switch (ablation) {
+    case 0: return attn_fwd_launch_abl<0>(q, k, v, o, lse2, doc, m, qv, B, T, Nh, Nkv, sl2, st);
+    case 1: return attn_fwd_launch_abl<1>(q, k, v, o, lse2, doc, m, qv, B, T, Nh, Nkv, sl2, st);
+    case 2: return attn_fwd_launch_abl<2>(q, k, v, o, lse2, doc, m, qv, B, T, Nh, Nkv, sl2, st);
+    case 3: return attn_fwd_launch_abl<3>(q, k, v, o, lse2, doc, m, qv, B, T, Nh, Nkv, sl2, st);
+    case 4: return attn_fwd_launch_abl<4>(q, k, v, o, lse2, doc, m, qv, B, T, Nh, Nkv, sl2, st);
+    case 5: return attn_fwd_launch_abl<5>(q, k, v, o, lse2, doc, m, qv, B, T, Nh, Nkv, sl2, st);
+    case 6: return attn_fwd_launch_abl<0, 8>(q, k, v, o, lse2, doc, m, qv, B, T, Nh, Nkv, sl2, st);   // 8 waves
+    default: return TN_EINVAL;
+  }
 }
 
 // Sequence-sharded query side (context parallel): q / o are [B, rows_per_batch, Nh, D], lse2 [B, Nh, rows_per_batch];
