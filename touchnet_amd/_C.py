@@ -12,7 +12,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_lib", "libtouchnet_amd.so")
+# TN_AMD_LIB: kernel-development hook (scripts/build_variant.sh builds -D variants of the same library)
+LIB_PATH = os.environ.get("TN_AMD_LIB") or os.path.join(_HERE, "_lib", "libtouchnet_amd.so")
 
 _vp, _i, _f, _ll = C.c_void_p, C.c_int, C.c_float, C.c_longlong
 

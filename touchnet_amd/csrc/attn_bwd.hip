@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hi = lane >> 5;
-  const int kt = blockIdx.x, hk = blockIdx.y, b = blockIdx.z;
+  const int kt = blockIdx.y, hk = blockIdx.x, b = blockIdx.z;   // (see head_of_slot: head in x, heavy tiles first)
   const int G = Nh / Nkv;
   const int k0 = kt * BNK;
   const int wk0 = k0 + 32 * wave;
@@ -309,10 +309,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hi = lane >> 5;
-  const int h = blockIdx.y, b = blockIdx.z;
+  const int h = head_of_slot(blockIdx.x, Nh, Nkv), b = blockIdx.z;
   const int hk = h / (Nh / Nkv);
   int lq0, q0, qleft;
-  qv.tile(blockIdx.x, BM, lq0, q0, qleft);
+  qv.tile(gridDim.y - 1 - blockIdx.y, BM, lq0, q0, qleft);
   const int wq0 = q0 + 32 * wave;          // global position of the wave's first query row
   const int qrow = wq0 + l31;              // global position
   const int lrow = lq0 + 32 * wave + l31;  // row in the local Q / dO / dQ / LSE / delta buffers
@@ -472,7 +472,7 @@ static int attn_bwd_launch(const void* q, const void* k, const void* v, const vo
   hipStream_t st = (hipStream_t)stream;
   const float sl2 = scale * 1.4426950408889634f;
   const size_t rows = (size_t)B * qv.rpb * Nh;
-  dim3 gq(qv.tiles(0, 128) + qv.tiles(1, 128), Nh, B), gk((T + 127) / 128, Nkv, B), block(256);
+  dim3 gq(Nh, qv.tiles(0, 128) + qv.tiles(1, 128), B), gk(Nkv, (T + 127) / 128, B), block(256);
   const bf16_t *Q = (const bf16_t*)q, *K = (const bf16_t*)k, *V = (const bf16_t*)v, *dO = (const bf16_t*)dout;
   if (D == 128) {
     hipLaunchKernelGGL((attn_delta_kernel<128>), dim3((rows * 16 + 255) / 256), block, 0, st, (const bf16_t*)o, dO,

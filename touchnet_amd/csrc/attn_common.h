@@ -24,6 +24,12 @@ typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
 __device__ __forceinline__ f32x16_t mfma32(bf16x8_t a, bf16x8_t b, f32x16_t c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
+// max of three without the NaN-quieting canonicalisation fmaxf() implies (inputs here are never signalling NaNs)
+__device__ __forceinline__ float max3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
 __device__ __forceinline__ bf16x8_t as_bf16x8(uint4 v) {
   u32x4_t t = {v.x, v.y, v.z, v.w};
   return __builtin_bit_cast(bf16x8_t, t);
@@ -73,6 +79,19 @@ struct QView {
     left = rows[s] - lt * bm;
   }
 };
+
+// Workgroup -> (head, tile) mapping shared by the attention kernels.  Launch grids are (heads, tiles, batch):
+//  * blockIdx.x = head slot.  Workgroups go to XCDs round-robin by linear id (MI355X_MICROARCH.md "Workgroup
+//    dispatch"), so with the TILE index in x (the first version) XCD k received tiles {k, k+8, ..}: under a causal
+//    mask XCD 7 had 21 % (256-row tiles) more work than the average and every XCD's L2 fetched the K/V of every
+//    head.  With the head in x all tiles of a head run on ONE XCD: balanced work, K/V of a head read into one L2.
+//    GQA: slot x -> head (x % Nkv) * G + x / Nkv, so that the G query heads of a kv head share its XCD(s).
+//  * blockIdx.y = tile rank, heaviest first (q tiles: last rows first; kv tiles of dK/dV: first rows first), so
+//    that the tail of the launch is made of the light workgroups.
+__device__ __forceinline__ int head_of_slot(int x, int Nh, int Nkv) {
+  const int G = Nh / Nkv;
+  return (x % Nkv) * G + x / Nkv;
+}
 
 // Can any (q, kv) pair with q in a set having positive-id range [qminpos, qmax] and kv in tile j be
 // allowed?  Conservative on purpose: false only when the id ranges are disjoint.

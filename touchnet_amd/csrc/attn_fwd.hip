@@ -19,6 +19,8 @@
 // Per KV tile and wave:  S^T = K Q^T (A = K from LDS, B = Q in registers) so that every lane owns ONE
 // query column: softmax statistics are lane-local (one cross-half shuffle), P never leaves registers and
 // feeds O^T += V^T P^T directly as the B operand (A = V^T from a transposed, swizzled LDS image).
+#include <stdlib.h>
+
 #include "attn_common.h"
 
 namespace tn {
@@ -87,10 +89,10 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(const bf16_t* __re
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hi = lane >> 5;
-  const int h = blockIdx.y, b = blockIdx.z;
+  const int h = head_of_slot(blockIdx.x, Nh, Nkv), b = blockIdx.z;
   const int hk = h / (Nh / Nkv);
   int lq0, q0, qleft;                      // local first row / global first position / rows left in the segment
-  qv.tile(blockIdx.x, BM, lq0, q0, qleft);
+  qv.tile(gridDim.y - 1 - blockIdx.y, BM, lq0, q0, qleft);
   const int wq0 = q0 + 32 * wave;          // GLOBAL position of the wave's first query row
   const int qrow = wq0 + l31;              // global position: what the causal / document predicate compares
   const int lrow = lq0 + 32 * wave + l31;  // row in the local Q / O / LSE buffers
@@ -296,10 +298,24 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(const bf16_t* __re
 
 using namespace tn;
 
+int tn_attn_fwd_pp_launch(const void* q, const void* k, const void* v, void* o, float* lse2, const int* doc,
+                          AttnMeta m, QView qv, int B, int T, int Nh, int Nkv, int D, float sl2, hipStream_t st);
+
+// Schedule selection: 0 = 4 waves x 32 rows, independent workgroups (default: fastest on packed batches of short
+// documents, where a workgroup meets only a handful of KV tiles); 1 = ping-pong (attn_fwd_pp.hip: 256-row
+// workgroups, ~15 % faster on long documents / plain causal, slower on short ones).  TN_ATTN_FWD_SCHEDULE selects.
+static int fwd_schedule() {
+  static int mode = [] {
+    const char* e = getenv("TN_ATTN_FWD_SCHEDULE");
+    return e ? atoi(e) : 0;
+  }();
+  return mode;
+}
+
 template <int ABL, int NW = 4>
 static int attn_fwd_launch_abl(const void* q, const void* k, const void* v, void* o, float* lse2, const int* doc,
                                AttnMeta m, QView qv, int B, int T, int Nh, int Nkv, float sl2, hipStream_t st) {
-  dim3 grid(qv.tiles(0, 32 * NW) + qv.tiles(1, 32 * NW), Nh, B), block(64 * NW);
+  dim3 grid(Nh, qv.tiles(0, 32 * NW) + qv.tiles(1, 32 * NW), B), block(64 * NW);
   hipLaunchKernelGGL((attn_fwd_kernel<128, ABL, NW>), grid, block, 0, st, (const bf16_t*)q, (const bf16_t*)k,
                      (const bf16_t*)v, (bf16_t*)o, lse2, doc, m, qv, T, Nh, Nkv, sl2);
   TN_LAUNCH_CHECK();
@@ -332,9 +348,11 @@ static int attn_fwd_launch(const void* q, const void* k, const void* v, void* o,
     if (qv.off[s] % 128 || qv.row0[s] % 128 || (s + 1 < qv.nseg && qv.rows[s] % 128)) return TN_EINVAL;
   const int nt = (T + kTile - 1) / kTile, n = B * nt;
   AttnMeta m = {meta, meta + n, meta + 2 * n, meta + 3 * n, meta + 4 * n, nt};
-  dim3 grid(qv.tiles(0, 128) + qv.tiles(1, 128), Nh, B), block(256);
   const float sl2 = scale * 1.4426950408889634f;
   hipStream_t st = (hipStream_t)stream;
+  if (fwd_schedule() == 1 && (D == 64 || D == 128) && nt <= 1024)   // (the ping-pong kernel's LDS tile list)
+    return tn_attn_fwd_pp_launch(q, k, v, o, lse2, doc, m, qv, B, T, Nh, Nkv, D, sl2, st);
+  dim3 grid(Nh, qv.tiles(0, 128) + qv.tiles(1, 128), B), block(256);
   if (D == 128)
     hipLaunchKernelGGL((attn_fwd_kernel<128>), grid, block, 0, st, (const bf16_t*)q, (const bf16_t*)k,
                        (const bf16_t*)v, (bf16_t*)o, lse2, doc, m, qv, T, Nh, Nkv, sl2);
