@@ -137,6 +137,14 @@ int tn_adamw_step(float* p, float* m, float* v, const void* g, void* p_shadow_bf
                   long long n, float lr, float beta1, float beta2, float eps, float weight_decay, float max_norm,
                   float bias_corr1, float bias_corr2, int g_dtype, void* stream);
 
+/* ---- bf16 transpose for the weight-gradient GEMMs of the linear layers: dst[c*dst_ld + r] = src[r*src_ld + c].
+ *      Replaces the implicit operand transposes of torch.nn.functional.linear's backward (every nn.Linear of the
+ *      decoder blocks the reference trains, touchnet/bin/train.py:440-470): dW = dY^T X is run with BOTH operands
+ *      contraction-contiguous (the forward GEMM's layout), which hipBLASLt executes ~1.4x faster on MI355X.
+ *      rows, cols, leading dimensions: multiples of 8; base addresses 16-byte aligned (else -22). */
+int tn_transpose_bf16(const void* src, void* dst, int rows, int cols, long long src_ld, long long dst_ld,
+                      void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -468,3 +468,52 @@ def test_sharded_attention_emulated_context_parallel(cp, T, Nh, Nkv, D, maxdoc):
         dv_sum += vl.grad.float()
     _close(dk_sum, kf.grad, 3e-2, 2e-2, "sum of partial dK")
     _close(dv_sum, vf.grad, 3e-2, 2e-2, "sum of partial dV")
+
+
+# ------------------------------------------------------------------------------------ linear layers
+@pytest.mark.parametrize("R,C", [(8, 8), (256, 64), (264, 72), (1000 * 8, 1280), (16384, 4096)])
+def test_transpose_bf16_bit_exact(R, C):
+    """tn_transpose_bf16 is a byte permutation: bit-exact against torch, incl. strided source / destination."""
+    F = _f()
+    x = torch.randn(R, C + 8, device=DEV).to(torch.bfloat16)[:, :C]          # row stride C + 8
+    out = torch.full((C, R + 16), 7.0, dtype=torch.bfloat16, device=DEV)
+    F.transpose_2d(x, out=out[:, :R])
+    assert torch.equal(out[:, :R], x.t())
+    assert torch.equal(out[:, R:], torch.full((C, 16), 7.0, dtype=torch.bfloat16, device=DEV))   # nothing spilled
+    assert torch.equal(F.transpose_2d(x.contiguous()), x.t().contiguous())
+    with pytest.raises(RuntimeError):
+        F.transpose_2d(x[:, :C - 1])                                           # not a multiple of 8 -> -22, loud
+
+
+@pytest.mark.parametrize("M,K,Ns,bias", [(512, 256, (256, 64, 64), True), (2048, 1024, (2816, 2816), False),
+                                         (384, 128, (128,), False), (100, 64, (64, 32), True)])
+def test_linear_group_matches_autograd(M, K, Ns, bias):
+    """Forward = nn.Linear; backward (transposed-operand weight-gradient GEMM over the whole group, addmm-accumulated
+    input gradient) against autograd's own nn.Linear backward in fp32 on the same bf16-rounded inputs.
+    M = 100 is not a multiple of 8: the HIP transposes do not apply and the torch path must give the same."""
+    F = _f()
+    g = torch.Generator(device="cpu").manual_seed(0)
+    x = (torch.randn(2, M // 2, K, generator=g) * 0.5).to(torch.bfloat16)
+    ws = [(torch.randn(N, K, generator=g) * K ** -0.5).to(torch.bfloat16) for N in Ns]
+    bs = [(torch.randn(N, generator=g) * 0.1).to(torch.bfloat16) if bias else None for N in Ns]
+    dys = [torch.randn(2, M // 2, N, generator=g).to(torch.bfloat16) for N in Ns]
+
+    def run(dev, dt, fn):
+        xx = x.to(dev, dt).requires_grad_()
+        ww = [w.to(dev, dt).requires_grad_() for w in ws]
+        bb = [None if b is None else b.to(dev, dt).requires_grad_() for b in bs]
+        ys = fn(xx, list(zip(ww, bb)))
+        torch.autograd.backward(ys, [d.to(dev, dt) for d in dys])
+        return ys, xx.grad, [w.grad for w in ww], [None if b is None else b.grad for b in bb]
+
+    ref = run("cpu", torch.float32, lambda xx, layers: [torch.nn.functional.linear(xx, w, b) for w, b in layers])
+    got = run(DEV, torch.bfloat16, F.linear_group)
+    for a, b in zip(got[0], ref[0]):
+        torch.testing.assert_close(a.float().cpu(), b, rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(got[1].float().cpu(), ref[1], rtol=2e-2, atol=2e-2 * float(ref[1].abs().max()))
+    for a, b in zip(got[2], ref[2]):
+        assert a.shape == b.shape
+        torch.testing.assert_close(a.float().cpu(), b, rtol=2e-2, atol=2e-2 * float(b.abs().max()))
+    for a, b in zip(got[3], ref[3]):
+        if b is not None:
+            torch.testing.assert_close(a.float().cpu(), b, rtol=2e-2, atol=2e-2 * float(b.abs().max()))

@@ -49,6 +49,7 @@ PROTOTYPES = {
     "tn_sumsq_scratch_floats": [],
     "tn_sumsq": [_vp, _vp, _vp, _ll, _i, _vp],
     "tn_adamw_step": [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _f, _f, _f, _f, _i, _vp],
+    "tn_transpose_bf16": [_vp, _vp, _i, _i, _ll, _ll, _vp],
 }
 _RESTYPE = {"tn_version": C.c_char_p}
 

@@ -62,9 +62,13 @@ class Attention(nn.Module):
 
     def forward(self, x, cos, sin, mask):
         B, T, _ = x.shape
-        q = self.q_proj(x).view(B, T, self.num_heads, self.head_dim)
-        k = self.k_proj(x).view(B, T, self.num_kv_heads, self.head_dim)
-        v = self.v_proj(x).view(B, T, self.num_kv_heads, self.head_dim)
+        # one autograd node for the three projections of x: their weight gradients run as ONE GEMM in the forward
+        # layout (functional._LinearGroup); parameters keep the HF names and shapes
+        q, k, v = ops().linear_group(x, [(self.q_proj.weight, self.q_proj.bias), (self.k_proj.weight, self.k_proj.bias),
+                                         (self.v_proj.weight, self.v_proj.bias)])
+        q = q.view(B, T, self.num_heads, self.head_dim)
+        k = k.view(B, T, self.num_kv_heads, self.head_dim)
+        v = v.view(B, T, self.num_kv_heads, self.head_dim)
         q, k = ops().apply_rope(q, k, cos, sin)
         cp = getattr(mask, "cp", None)
         if cp is not None:            # context parallel: local queries vs all-gathered K/V (utils/context_parallel.py)
@@ -72,7 +76,7 @@ class Attention(nn.Module):
                                                self.scaling)
         else:
             a = ops().packed_attention(q, k, v, mask, self.scaling)
-        return self.o_proj(a.view(B, T, self.num_heads * self.head_dim))
+        return ops().linear_group(a.view(B, T, self.num_heads * self.head_dim), [(self.o_proj.weight, None)])[0]
 
 
 class MLP(nn.Module):
@@ -84,7 +88,9 @@ class MLP(nn.Module):
         self.down_proj = nn.Linear(I, H, bias=False)
 
     def forward(self, x):
-        return self.down_proj(ops().swiglu(self.gate_proj(x), self.up_proj(x)))
+        gate, up = ops().linear_group(x, [(self.gate_proj.weight, None), (self.up_proj.weight, None)])
+        # (down_proj: 11008 -> 4096 gains nothing from the transposed weight-gradient layout: plain nn.Linear)
+        return self.down_proj(ops().swiglu(gate, up))
 
 
 class DecoderLayer(nn.Module):
