@@ -30,7 +30,7 @@ def layer_norm(x, weight, bias, eps=1e-5, residual=None):
 swiglu = _nn.swiglu
 
 
-def linear_group(x, layers):
+def linear_group(x, layers, wgrad_tn=True):
     """mirror of touchnet_amd.functional.linear_group: plain nn.Linear math per layer"""
     return [torch.nn.functional.linear(x, w, b) for w, b in layers]
 

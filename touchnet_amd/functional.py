@@ -466,13 +466,17 @@ class _LinearGroup(torch.autograd.Function):
     here dY_i and x are transposed by a HIP kernel (tn_transpose_bf16, ~5 TB/s) and ONE GEMM over the whole group
     ``[sum N_i, M] x [M, K]`` runs in the forward GEMM's layout at 1.4-1.55 PFLOP/s
     (scripts/wgrad_layout_bench.py: q/k/v of a 7B block 1.67 -> 1.27 ms, gate/up 3.14 -> 2.46 ms incl. transposes).
-    The input gradient accumulates over the group inside the GEMM epilogue (addmm, beta = 1)."""
+    The INPUT gradient dX = sum_i dY_i W_i contracts over W_i's slow dimension; with W_i transposed first (33-90 MB,
+    ~0.01-0.04 ms) the same hipBLASLt GEMM runs 8-19 % faster (scripts/gemm_layout_bench.py: 4096^2 0.50 -> 0.43 ms,
+    11008 -> 4096 1.11 -> 0.93 ms); it accumulates over the group inside the GEMM epilogue (addmm, beta = 1).
+    ``wgrad_tn=False`` keeps autograd's weight-gradient layout (down_proj: no gain at N = 4096, K = 11008)."""
 
     @staticmethod
-    def forward(ctx, x, n, *wb):
+    def forward(ctx, x, n, wgrad_tn, *wb):
         ws, bs = wb[:n], wb[n:]
         ctx.save_for_backward(x, *ws)
         ctx.has_bias = [b is not None for b in bs]
+        ctx.wgrad_tn = wgrad_tn
         return tuple(torch.nn.functional.linear(x, w, b) for w, b in zip(ws, bs))
 
     @staticmethod
@@ -484,17 +488,20 @@ class _LinearGroup(torch.autograd.Function):
         M = x2.shape[0]
         dys = [torch.zeros(M, w.shape[0], dtype=x.dtype, device=x.device) if d is None else _c(d).reshape(M, -1)
                for d, w in zip(dys, ws)]
-        need_x, need_w = ctx.needs_input_grad[0], [ctx.needs_input_grad[2 + i] for i in range(n)]
+        need_x, need_w = ctx.needs_input_grad[0], [ctx.needs_input_grad[3 + i] for i in range(n)]
+        Ns = [w.shape[0] for w in ws]
+        hip_ok = x.dtype == torch.bfloat16 and x.is_cuda and _tn_ok(M, K, Ns)
         dx = None
         if need_x:
-            dx = torch.mm(dys[0], ws[0])
-            for d, w in zip(dys[1:], ws[1:]):
+            wv = [transpose_2d(_c(w)).t() for w in ws] if hip_ok else ws           # [N, K] views of W^T storage
+            dx = torch.mm(dys[0], wv[0])
+            for d, w in zip(dys[1:], wv[1:]):
                 dx.addmm_(d, w)
             dx = dx.view(x.shape)
+            del wv
         dws = [None] * n
         if any(need_w):
-            Ns = [w.shape[0] for w in ws]
-            if x.dtype == torch.bfloat16 and x.is_cuda and _tn_ok(M, K, Ns):
+            if hip_ok and ctx.wgrad_tn:
                 xt = transpose_2d(_c(x2))                                          # [K, M]
                 dyt = torch.empty(sum(Ns), M, dtype=x.dtype, device=x.device)      # [sum N, M]
                 o = 0
@@ -506,16 +513,16 @@ class _LinearGroup(torch.autograd.Function):
             else:
                 dws = [torch.mm(d.t(), x2) for d in dys]
             dws = [g if nw else None for g, nw in zip(dws, need_w)]
-        dbs = [d.sum(0) if (hb and ctx.needs_input_grad[2 + n + i]) else None
+        dbs = [d.sum(0) if (hb and ctx.needs_input_grad[3 + n + i]) else None
                for i, (d, hb) in enumerate(zip(dys, ctx.has_bias))]
-        return (dx, None, *dws, *dbs)
+        return (dx, None, None, *dws, *dbs)
 
 
-def linear_group(x, layers):
+def linear_group(x, layers, wgrad_tn: bool = True):
     """``layers``: list of (weight [N_i, K], bias [N_i] | None) sharing the input ``x`` -> list of outputs."""
     ws = [w for w, _ in layers]
     bs = [b for _, b in layers]
-    return list(_LinearGroup.apply(x, len(ws), *ws, *bs))
+    return list(_LinearGroup.apply(x, len(ws), wgrad_tn, *ws, *bs))
 
 
 # ------------------------------------------------------------------------------------ frontend

@@ -89,8 +89,8 @@ class MLP(nn.Module):
 
     def forward(self, x):
         gate, up = ops().linear_group(x, [(self.gate_proj.weight, None), (self.up_proj.weight, None)])
-        # (down_proj: 11008 -> 4096 gains nothing from the transposed weight-gradient layout: plain nn.Linear)
-        return self.down_proj(ops().swiglu(gate, up))
+        # (down_proj, 11008 -> 4096, gains nothing from the transposed weight-gradient layout)
+        return ops().linear_group(ops().swiglu(gate, up), [(self.down_proj.weight, None)], wgrad_tn=False)[0]
 
 
 class DecoderLayer(nn.Module):
