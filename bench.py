@@ -270,7 +270,8 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     device = torch.device("cuda", local)
-    mesh = build_dp_mesh("cuda", world) if world > 1 else None
+    forced = os.environ.get("TN_FORCE_FSDP") == "1"     # (development: FSDP2 over a 1-rank RCCL mesh on one GPU)
+    mesh = build_dp_mesh("cuda", world) if (world > 1 or forced) else None
 
     wl = Workload(args.workload, device, rank, args.batch, args.seqlen)
     wl.job.training_enable_fused_ce = not args.unfused_ce
@@ -316,7 +317,7 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": wl.data_desc + "; random-init weights",
             "config": {"workload": wl.name, "model": wl.job.training_model_name, "global_batch": wl.B * world,
-                       "seq_len": wl.T, "parallelism": f"fsdp2-dp{world}" if world > 1 else "single-gpu",
+                       "seq_len": wl.T, "parallelism": f"fsdp2-dp{world}" if (world > 1 or forced) else "single-gpu",
                        "params": trainer.num_params, "flop_per_token": fpt,
                        "fused_linear_ce": wl.job.training_enable_fused_ce,
                        "gemm_algorithms": "TunableOp replay (touchnet_amd/tuning)" if tuned else "library default"},
@@ -339,7 +340,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(wl)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -14,6 +14,8 @@ families are switched by `training_model_name` exactly like in the reference.
 """
 from __future__ import annotations
 
+import os
+
 from dataclasses import dataclass
 from typing import Optional
 
@@ -59,6 +61,9 @@ class Trainer:
         if fsdp_mesh is None:
             fsdp_mesh = dp_mesh
         shard_world = fsdp_mesh.size() if fsdp_mesh is not None else 1
+        # TN_FORCE_FSDP=1: wrap with FSDP2 even on a 1-rank mesh, so that the sharded path (fully_shard hooks, DTensor
+        # parameters, RCCL all-gather / reduce-scatter, the optimizer on local shards) can be exercised on one GPU
+        sharded = fsdp_mesh is not None and (shard_world > 1 or os.environ.get("TN_FORCE_FSDP") == "1")
         if self.spec.additional_pre_init_fn:
             self.spec.additional_pre_init_fn(job)                      # train.py:121-122
         torch.manual_seed(job.training_seed)
@@ -67,7 +72,7 @@ class Trainer:
         self.model_config = model_config
         self.num_params = self.spec.get_num_params_fn(model)
         self.num_params_wo_emb = self.spec.get_num_params_fn(model, exclude_embedding=True)
-        if fsdp_mesh is not None and shard_world > 1:
+        if sharded:
             model = self.spec.parallelize_fn(model, fsdp_mesh, job)    # fp32 shards, bf16 compute
             model.to_empty(device=device)
             with torch.no_grad():
@@ -88,7 +93,7 @@ class Trainer:
         else:
             self.optimizer = FusedAdamW(model.parameters(), lr=job.lr_scheduler_lr,
                                         weight_decay=job.optimizer_weight_decay, max_norm=job.training_max_norm,
-                                        process_group=fsdp_mesh.get_group() if shard_world > 1 else None)
+                                        process_group=fsdp_mesh.get_group() if sharded else None)
         self.step = 0
 
     # ------------------------------------------------------------------ data

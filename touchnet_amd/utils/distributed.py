@@ -24,7 +24,8 @@ def init_distributed(device_type: str = None, timeout_s: int = 300) -> tuple[int
         device_type = "cuda" if torch.cuda.is_available() else "cpu"
     if device_type == "cuda":
         torch.cuda.set_device(local)
-    if world > 1 and not dist.is_initialized():
+    force = os.environ.get("TN_FORCE_FSDP") == "1"      # 1-rank RCCL group: exercises the sharded path on one GPU
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29512")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC only on this host driver
