@@ -133,6 +133,11 @@ int tn_audiofeat_stack(const float* feat, float* out, int T, int F, int stack, i
  *         if norm_sq is NaN/Inf nothing is written (the reference skips the step, train.py:467-473) */
 int tn_sumsq_scratch_floats(void);
 int tn_sumsq(const void* g, float* scratch, float* norm_sq, long long n, int dtype, void* stream);
+/* multi-tensor step 1 (one launch for all gradient tensors of one dtype): device tables ptrs[t], sizes[t]
+ * (elements), first_chunk[t] = sum_{u<t} ceil(sizes[u] / tn_sumsq_multi_chunk()); partial: nchunks floats */
+long long tn_sumsq_multi_chunk(void);
+int tn_sumsq_multi(const void* const* ptrs, const long long* sizes, const long long* first_chunk, int ntensors,
+                   long long nchunks, float* partial, float* norm_sq, int dtype, void* stream);
 int tn_adamw_step(float* p, float* m, float* v, const void* g, void* p_shadow_bf16, const float* norm_sq,
                   long long n, float lr, float beta1, float beta2, float eps, float weight_decay, float max_norm,
                   float bias_corr1, float bias_corr2, int g_dtype, void* stream);

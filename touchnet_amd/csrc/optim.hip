@@ -46,6 +46,52 @@ __global__ __launch_bounds__(1024) void sumsq_final_kernel(const float* __restri
   if (threadIdx.x == 0) norm_sq[0] += acc;
 }
 
+// Multi-tensor form: ONE launch over all gradient tensors of a dtype.  Workgroup b owns chunk b: it finds its tensor
+// by binary search in the (ascending) first-chunk table and reduces kSumsqChunk elements of it.  The per-tensor
+// form above costs two launches per tensor: 1750 launches of 3-7 us for the 875 tensors of a 7B model.
+constexpr long long kSumsqChunk = 32768;
+
+template <typename T>
+__global__ __launch_bounds__(256) void sumsq_multi_kernel(const void* const* __restrict__ ptrs,
+                                                          const long long* __restrict__ sizes,
+                                                          const long long* __restrict__ first_chunk, int ntensors,
+                                                          float* __restrict__ partial) {
+  constexpr int N = Vec16<T>::N;
+  __shared__ float sm[4];
+  const long long c = blockIdx.x;
+  int lo = 0, hi = ntensors - 1;                     // last t with first_chunk[t] <= c
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (first_chunk[mid] <= c) lo = mid; else hi = mid - 1;
+  }
+  const T* g = static_cast<const T*>(ptrs[lo]);
+  const long long beg = (c - first_chunk[lo]) * kSumsqChunk;
+  const long long end = min(beg + kSumsqChunk, sizes[lo]);
+  float acc = 0.f;
+  if ((reinterpret_cast<uintptr_t>(g) & 15) == 0) {  // (chunk starts are multiples of 32768 elements: aligned with g)
+    const long long nvec = (end - beg) / N;
+    for (long long v = threadIdx.x; v < nvec; v += 256) {
+      Vec16<T> a;
+      float f[N];
+      a.load(g + beg + v * N);
+      a.unpack(f);
+#pragma unroll
+      for (int j = 0; j < N; ++j) acc += f[j] * f[j];
+    }
+    for (long long i = beg + nvec * N + threadIdx.x; i < end; i += 256) {
+      const float f = Elem<T>::ld(g + i);
+      acc += f * f;
+    }
+  } else {
+    for (long long i = beg + threadIdx.x; i < end; i += 256) {
+      const float f = Elem<T>::ld(g + i);
+      acc += f * f;
+    }
+  }
+  acc = block_sum(acc, sm);
+  if (threadIdx.x == 0) partial[c] = acc;
+}
+
 template <typename G> __device__ __forceinline__ void load4(const G* g, size_t i, float (&f)[4]);
 template <> __device__ __forceinline__ void load4<float>(const float* g, size_t i, float (&f)[4]) {
   const float4 t = reinterpret_cast<const float4*>(g)[i];
@@ -135,6 +181,29 @@ int tn_sumsq(const void* g, float* scratch, float* norm_sq, long long n, int dty
     return TN_EINVAL;
   TN_LAUNCH_CHECK();
   hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(1024), 0, st, scratch, norm_sq, nb);
+  TN_LAUNCH_CHECK();
+  return TN_OK;
+}
+
+long long tn_sumsq_multi_chunk(void) { return kSumsqChunk; }
+
+// norm_sq[0] += sum over `ntensors` tensors of sum(g^2).  Device tables: ptrs[t], sizes[t] (elements, > 0),
+// first_chunk[t] = sum_{u<t} ceil(sizes[u] / chunk); `partial`: nchunks floats.  Deterministic (fixed chunking,
+// fixed-order final reduction).
+int tn_sumsq_multi(const void* const* ptrs, const long long* sizes, const long long* first_chunk, int ntensors,
+                   long long nchunks, float* partial, float* norm_sq, int dtype, void* stream) {
+  if (ntensors <= 0 || nchunks <= 0 || nchunks > 0x7fffffffLL) return TN_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == 0)
+    hipLaunchKernelGGL((sumsq_multi_kernel<float>), dim3((unsigned)nchunks), dim3(256), 0, st, ptrs, sizes, first_chunk,
+                       ntensors, partial);
+  else if (dtype == 1)
+    hipLaunchKernelGGL((sumsq_multi_kernel<bf16_t>), dim3((unsigned)nchunks), dim3(256), 0, st, ptrs, sizes,
+                       first_chunk, ntensors, partial);
+  else
+    return TN_EINVAL;
+  TN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(1024), 0, st, partial, norm_sq, (int)nchunks);
   TN_LAUNCH_CHECK();
   return TN_OK;
 }

@@ -41,6 +41,30 @@ class FusedAdamW:
             self.state.append(dict(master=master, m=torch.zeros_like(master), v=torch.zeros_like(master)))
         self.norm_sq = torch.zeros(1, dtype=torch.float32, device=dev)
         self.scratch = torch.empty(_C.lib().tn_sumsq_scratch_floats(), dtype=torch.float32, device=dev)
+        self._partial, self._keep = None, None
+
+    def _sumsq(self, grads):
+        """norm_sq += sum(g^2) over all gradients: one multi-tensor launch per gradient dtype (the gradient
+        tensors are new allocations every step, so the pointer table is rebuilt and uploaded each time: ~20 KB)."""
+        lib, p_, st = _C.lib(), _C.ptr, _C.stream
+        chunk = int(lib.tn_sumsq_multi_chunk())
+        by_dtype = {}
+        for g in grads:
+            if g is not None and g.numel():
+                by_dtype.setdefault(g.dtype, []).append(g)
+        for dt, gs in by_dtype.items():
+            sizes = [g.numel() for g in gs]
+            first, tot = [], 0
+            for n in sizes:
+                first.append(tot)
+                tot += (n + chunk - 1) // chunk
+            table = torch.tensor([[g.data_ptr() for g in gs], sizes, first], dtype=torch.int64).pin_memory()
+            table = table.to(gs[0].device, non_blocking=True)
+            if self._partial is None or self._partial.numel() < tot:
+                self._partial = torch.empty(tot, dtype=torch.float32, device=gs[0].device)
+            _C.check(lib.tn_sumsq_multi(p_(table[0]), p_(table[1]), p_(table[2]), len(gs), tot, p_(self._partial),
+                                        p_(self.norm_sq), _C.dcode(gs[0]), st()), "tn_sumsq_multi")
+            self._keep = (table, gs)          # alive until the next step (the launch is asynchronous)
 
     def zero_grad(self, set_to_none: bool = True):
         for p in self.params:
@@ -58,13 +82,8 @@ class FusedAdamW:
         b1, b2 = self.betas
         bc1, bc2 = 1.0 - b1 ** self.step_count, 1.0 - b2 ** self.step_count
         self.norm_sq.zero_()
-        grads = []
-        for p in self.params:
-            g = None if p.grad is None else _local(p.grad).contiguous()
-            grads.append(g)
-            if g is not None and g.numel():
-                _C.check(lib.tn_sumsq(p_(g), p_(self.scratch), p_(self.norm_sq), g.numel(), _C.dcode(g), st()),
-                         "tn_sumsq")
+        grads = [None if p.grad is None else _local(p.grad).contiguous() for p in self.params]
+        self._sumsq(grads)
         if self.group is not None:
             torch.distributed.all_reduce(self.norm_sq, group=self.group)
         for p, g, s in zip(self.params, grads, self.state):
