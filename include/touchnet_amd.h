@@ -150,6 +150,14 @@ int tn_adamw_step(float* p, float* m, float* v, const void* g, void* p_shadow_bf
 int tn_transpose_bf16(const void* src, void* dst, int rows, int cols, long long src_ld, long long dst_ld,
                       void* stream);
 
+/* ---- BEST-RQ labels: codes[t] = argmin_v || normalize(feat[t] @ quantizer) - codebook[v] ||_2 —
+ *      BestRQTokenizer.tokenize, touchnet/tokenizer/tokenizer.py:289-299 (called per utterance from
+ *      batch_audio_packed, touchnet/models/touch_audio/processing_touch_audio.py:97).
+ *      feat [T, F], quantizer [F, E], codebook [V, E] (already L2-normalised, 16-byte aligned) fp32; codes int64 [T];
+ *      E in {8, 16, 32} (else -22).  First index wins ties, like torch.argmin. */
+int tn_bestrq_tokenize(const float* feat, const float* quantizer, const float* codebook, long long* codes, int T,
+                       int F, int E, int V, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

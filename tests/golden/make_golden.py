@@ -349,9 +349,61 @@ def frontend_cases():
     save("logmel.npz", **out)
 
 
+# ------------------------------------------------------------------ BEST-RQ tokenizer + audio-pretrain packer (§8f-4)
+def bestrq_cases():
+    from touchnet.models.touch_audio.processing_touch_audio import batch_audio_packed as ref_batch_audio
+    from touchnet.tokenizer.tokenizer import BestRQTokenizer
+    out = {}
+    # (name, vocab, input_size, emb, seed): the recipe's shape (run.sh:107-109: vocab 1024, stack*mel) and the defaults
+    for name, V, F, E, seed in (("recipe", 1024, 512, 16, 2026), ("default", 8192, 560, 16, 2026), ("small", 64, 24, 8, 7)):
+        cfg = types.SimpleNamespace(tokenizer_bestrq_vocab_size=V, tokenizer_bestrq_input_size=F,
+                                    tokenizer_bestrq_emb_size=E, tokenizer_bestrq_init_seed=seed,
+                                    tokenizer_bestrq_init_method="default")
+        tok = BestRQTokenizer(cfg)
+        g = torch.Generator().manual_seed(100 + V)
+        feat = torch.randn({1024: 300, 8192: 128, 64: 50}[V], F, generator=g)
+        codes = tok.tokenize(feat)
+        # the reference's own distances, for the near-tie margin of each frame (best vs second best)
+        xs = torch.nn.functional.normalize(feat @ tok._quantizer, dim=-1, p=2, eps=1e-8)
+        dist = torch.linalg.vector_norm(xs.unsqueeze(1) - tok._codebook.unsqueeze(0), dim=-1, ord=2)
+        top2 = torch.topk(dist, 2, dim=-1, largest=False).values
+        out[f"{name}/cfg"] = np.array([V, F, E, seed])
+        out[f"{name}/feat"] = npy(feat)
+        out[f"{name}/codes"] = np.asarray(codes, dtype=np.int64)
+        out[f"{name}/margin"] = npy(top2[:, 1] - top2[:, 0])
+        big = V > 1024                       # (the 8192-entry tables are stored subsampled: rows ::64 / ::16)
+        out[f"{name}/quantizer"] = npy(tok._quantizer)[::16] if big else npy(tok._quantizer)
+        out[f"{name}/codebook"] = npy(tok._codebook)[::64] if big else npy(tok._codebook)
+        assert tok.vocab_size == V
+    # packer: (B, T, drop_last, lengths incl. one over-long sample that must be skipped)
+    cfg = types.SimpleNamespace(tokenizer_bestrq_vocab_size=64, tokenizer_bestrq_input_size=24,
+                                tokenizer_bestrq_emb_size=8, tokenizer_bestrq_init_seed=7,
+                                tokenizer_bestrq_init_method="default")
+    tok = BestRQTokenizer(cfg)
+    rng = np.random.RandomState(11)
+    for name, B, T, drop, lens in (("overflow", 2, 40, False, [13, 20, 9, 41, 17, 30, 5, 26, 11]),
+                                   ("droplast", 3, 32, True, [int(x) for x in rng.randint(4, 30, size=14)]),
+                                   ("tail", 2, 64, False, [10, 12, 7])):
+        dcfg = types.SimpleNamespace(dataset_batchsize=B, dataset_audio_seqlen=T, audiofeat_num_mel_bins=6,
+                                     audiofeat_stack_length=4, dataloader_drop_last_batch=drop)
+        g = torch.Generator().manual_seed(len(lens))
+        feats = [torch.randn(n, 24, generator=g) for n in lens]
+        batches = list(ref_batch_audio(({"audiofeat": f} for f in feats), dcfg, tok))
+        out[f"pack/{name}/cfg"] = np.array([B, T, int(drop)])
+        out[f"pack/{name}/lens"] = np.array(lens)
+        out[f"pack/{name}/feats"] = np.concatenate([npy(f) for f in feats], 0)
+        out[f"pack/{name}/n"] = np.array(len(batches))
+        for i, bt in enumerate(batches):
+            assert bt["input_ids"] is None and bt["shift_labels"] is bt["labels"]
+            for k in ("input_features", "labels", "position_ids", "attention_mask", "sentence_lens"):
+                out[f"pack/{name}/{i}/{k}"] = npy(bt[k])
+            out[f"pack/{name}/{i}/num_sentence"] = np.array(bt["num_sentence"])
+    save("bestrq.npz", **out)
+
+
 if __name__ == "__main__":
     only = set(sys.argv[1:])
     for fn in (text_cases, asr_cases, ce_cases, docmask_cases, rope_cases, tiny_llama_case,
-               touch_audio_case, qwen2_audio_tower_case, frontend_cases):
+               touch_audio_case, qwen2_audio_tower_case, frontend_cases, bestrq_cases):
         if not only or fn.__name__ in only:
             fn()

@@ -518,3 +518,51 @@ def test_linear_group_matches_autograd(M, K, Ns, bias, wtn):
     for a, b in zip(got[3], ref[3]):
         if b is not None:
             torch.testing.assert_close(a.float().cpu(), b, rtol=2e-2, atol=2e-2 * float(b.abs().max()))
+
+
+# ------------------------------------------------------------------------------------ BEST-RQ tokenizer (§8f-4)
+@pytest.mark.parametrize("case", ["recipe", "default", "small"])
+def test_bestrq_tokenize_matches_reference_codes(golden, case):
+    """tn_bestrq_tokenize through the product BestRQTokenizer (tables drawn like the reference's) against the codes
+    the reference produced for the same features: identical wherever the reference's own best/second-best margin
+    exceeds 1e-6 (fp32 round-off of a distance ~1), and at most 1 % near-tie differences overall."""
+    import types
+    from touchnet_amd.tokenizer import BestRQTokenizer
+    g = golden("bestrq.npz")
+    V, Fdim, E, seed = [int(v) for v in g[f"{case}/cfg"]]
+    cfg = types.SimpleNamespace(tokenizer_bestrq_vocab_size=V, tokenizer_bestrq_input_size=Fdim,
+                                tokenizer_bestrq_emb_size=E, tokenizer_bestrq_init_seed=seed,
+                                tokenizer_bestrq_init_method="default", tokenizer_type="BestRQTokenizer")
+    tok = BestRQTokenizer(cfg, device=DEV)
+    codes = tok.tokenize(torch.from_numpy(g[f"{case}/feat"]).to(DEV))
+    assert codes.dtype == torch.int64 and codes.is_cuda
+    big = V > 1024
+    np.testing.assert_array_equal(tok._codebook.cpu().numpy()[::64] if big else tok._codebook.cpu().numpy(),
+                                  g[f"{case}/codebook"])
+    bad = codes.cpu().numpy() != g[f"{case}/codes"]
+    assert not (bad & (g[f"{case}/margin"] > 1e-6)).any(), g[f"{case}/margin"][bad]
+    assert bad.mean() <= 0.01
+    with pytest.raises(RuntimeError):
+        tok.tokenize(torch.from_numpy(g[f"{case}/feat"]))          # CPU tensor: refused, no host fallback
+
+
+def test_bestrq_tokenize_full_size_properties():
+    """T = 131072 frames (the recipe's row length), V = 8192: against the oracle on a 2048-frame sample, plus
+    size-independent properties: codes in range, invariance to positive scaling of a frame (normalisation), ragged
+    tail (T not a multiple of the 32-frame tile) equals the prefix of the padded call."""
+    from oracle import tokenizer as otok
+    F = _f()
+    q, c = otok.bestrq_tables(8192, 512, 16, 2026)
+    qd, cd = torch.from_numpy(q).to(DEV), torch.from_numpy(c).to(DEV)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    feat = torch.randn(131072, 512, generator=g)
+    fd = feat.to(DEV)
+    codes = F.bestrq_tokenize(fd, qd, cd)
+    assert int(codes.min()) >= 0 and int(codes.max()) < 8192
+    idx = torch.randperm(131072, generator=g)[:2048]
+    ref = otok.bestrq_tokenize(feat[idx].numpy(), q, c)
+    assert (codes[idx.to(DEV)].cpu().numpy() != ref).mean() <= 0.002       # near-ties only
+    scale = (torch.rand(4096, 1, generator=g) * 9 + 0.5).to(DEV)
+    assert (F.bestrq_tokenize(fd[:4096] * scale, qd, cd) != codes[:4096]).float().mean() <= 0.002
+    assert torch.equal(F.bestrq_tokenize(fd[:1000 + 13], qd, cd), codes[:1013])
+    assert F.bestrq_tokenize(fd[:0], qd, cd).numel() == 0

@@ -575,6 +575,24 @@ def log_mel_spectrogram(wav: torch.Tensor, num_mel_bins: int = 128, padding: int
     return feat
 
 
+def bestrq_tokenize(feat: torch.Tensor, quantizer: torch.Tensor, codebook: torch.Tensor) -> torch.Tensor:
+    """BEST-RQ codes (touchnet/tokenizer/tokenizer.py:289-299): feat [T, F], quantizer [F, E], L2-normalised
+    codebook [V, E], all fp32 on the device -> int64 [T]."""
+    for t in (feat, quantizer, codebook):
+        if not t.is_cuda or t.dtype != torch.float32 or t.dim() != 2:
+            raise RuntimeError("bestrq_tokenize: expects 2-D fp32 device tensors")
+    T, Fdim = feat.shape
+    E, V = quantizer.shape[1], codebook.shape[0]
+    if quantizer.shape[0] != Fdim or codebook.shape[1] != E:
+        raise RuntimeError(f"bestrq_tokenize: shape mismatch feat {tuple(feat.shape)} quantizer {tuple(quantizer.shape)} "
+                           f"codebook {tuple(codebook.shape)}")
+    feat, quantizer, codebook = _c(feat), _c(quantizer), _c(codebook)
+    codes = torch.empty(T, dtype=torch.int64, device=feat.device)
+    _C.check(_C.lib().tn_bestrq_tokenize(_p(feat), _p(quantizer), _p(codebook), _p(codes), T, Fdim, E, V, _cur()),
+             "tn_bestrq_tokenize")
+    return codes
+
+
 def audiofeat_stack(feat: torch.Tensor, stack: int, stride: int, normalize: bool = True) -> torch.Tensor:
     """feat fp32 [T, F] -> fp32 [ceil(T/stride), F*stack] (functions.py:258-286)."""
     feat = _c(feat).float()

@@ -2,7 +2,7 @@
 from ..llama import get_num_flop_per_token as _llama_flops
 from ..llama import get_num_params, post_init, pre_init  # noqa: F401
 from .modeling_touch_audio import TouchAudioConfig, TouchAudioForCausalLM  # noqa: F401
-from .processing_touch_audio import batch_pairaudio_pairtext_packed  # noqa: F401
+from .processing_touch_audio import batch_audio_packed, batch_pairaudio_pairtext_packed  # noqa: F401
 
 
 def get_num_flop_per_token(num_params, model_config, seq_len):
