@@ -150,6 +150,10 @@ int tn_adamw_step(float* p, float* m, float* v, const void* g, void* p_shadow_bf
 int tn_transpose_bf16(const void* src, void* dst, int rows, int cols, long long src_ld, long long dst_ld,
                       void* stream);
 
+/* ---- int16 PCM of a TouchDataset audio shard -> float32 [-1, 1) on the device (x / 32768, exact): the conversion
+ *      the reference does on a CPU worker, touchnet/data/datapipe.py:163-165 */
+int tn_pcm16_to_f32(const void* pcm_int16, float* out, long long n, void* stream);
+
 /* ---- BEST-RQ labels: codes[t] = argmin_v || normalize(feat[t] @ quantizer) - codebook[v] ||_2 —
  *      BestRQTokenizer.tokenize, touchnet/tokenizer/tokenizer.py:289-299 (called per utterance from
  *      batch_audio_packed, touchnet/models/touch_audio/processing_touch_audio.py:97).

@@ -30,6 +30,11 @@ def layer_norm(x, weight, bias, eps=1e-5, residual=None):
 swiglu = _nn.swiglu
 
 
+def pcm16_to_float(pcm):
+    """datapipe.py:164"""
+    return pcm.to(torch.float32) / 32768.0
+
+
 def linear_group(x, layers, wgrad_tn=True):
     """mirror of touchnet_amd.functional.linear_group: plain nn.Linear math per layer"""
     return [torch.nn.functional.linear(x, w, b) for w, b in layers]

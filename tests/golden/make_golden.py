@@ -401,9 +401,141 @@ def bestrq_cases():
     save("bestrq.npz", **out)
 
 
+# ------------------------------------------------------------------ TouchDataset reader + low-level datapipe (§8f-3)
+def touchdataset_case():
+    """Writes tests/golden/touchdataset/ with the reference's OWN writer classes from the reference's test assets
+    (make_data.py's ffmpeg decode of a 16 kHz mono s16 wav is the identity on its samples, so the wave module
+    stands in for it), checks the two md5s its test pins (tests/touchnet/bin/test_make_data.py:25-28), then records
+    what the reference's TouchDataset / LowLevelTouchDatapipe read back under several configurations."""
+    import hashlib
+    import json
+    import shutil
+    import subprocess
+    from touchnet.data.dataset import DType, IndexWriter, TouchDataset  # noqa: F401
+    from touchnet.data.datapipe import LowLevelTouchDatapipe
+
+    class Builder:                                    # = make_data.DataBuilder's calls into IndexWriter (:47-96)
+        def __init__(self, bin_path, dtype):
+            self.f, self.dtype, self.lens, self.docs = open(bin_path, "wb"), dtype, [], [0]
+
+        def add(self, arr):
+            a = np.array(arr, dtype=self.dtype)
+            self.f.write(a.tobytes(order="C"))
+            self.lens.append(a.size)
+            self.docs.append(len(self.lens))
+
+        def finalize(self, idx_path):
+            self.f.close()
+            with IndexWriter(idx_path, self.dtype) as w:
+                w.write(self.lens, self.docs)
+
+    root = os.path.join(HERE, "touchdataset")
+    shutil.rmtree(root, ignore_errors=True)
+    lines = [ln.strip() for ln in open(f"{R.REF}/tests/assets/dataset/data.jsonl")]
+
+    def write_shards(save_dir, samples, per):
+        shards = []
+        for i in range(0, len(samples), per):
+            d = "{}/{:09d}".format(save_dir, i // per)
+            os.makedirs(d)
+            a, m = Builder(f"{d}/audio.bin", np.int16), Builder(f"{d}/metainfo.bin", np.uint8)
+            for meta, pcm in samples[i:i + per]:
+                meta = dict(meta)
+                meta["sample_rate"] = 16000
+                a.add(pcm)
+                m.add(np.frombuffer(json.dumps(meta, ensure_ascii=False).strip().encode("utf-8"), dtype=np.uint8))
+            a.finalize(f"{d}/audio.idx")
+            m.finalize(f"{d}/metainfo.idx")
+            shards.append(d)
+        return shards
+
+    assets = []
+    for ln in lines:
+        meta = json.loads(ln)
+        pcm, sr = read_wav(f"{R.REF}/{meta['wav']}")
+        assert sr == 16000
+        assets.append((meta, pcm))
+    expect = {1: "05fe272d67459992748bbf5720c5a92e", 2: "93245372eca0dce2013c1e5bd393f17f"}
+    for per in (1, 2):
+        d = f"{root}/{per}sample_per_shard"
+        write_shards(d, assets, per)
+        cmd = (f"find {d} \\( -name '*.idx' -o -name '*.bin' \\) -type f -exec md5sum {{}} \\; | sort | "
+               "cut -d ' ' -f1 | md5sum | awk '{print $1}'")
+        got = subprocess.run(cmd, shell=True, capture_output=True, text=True).stdout.strip()
+        assert got == expect[per], (per, got, expect[per])
+        print(f"  {per}sample_per_shard md5 {got} == the reference test's constant")
+    # a synthetic third dataset with segment annotations (the assets have none): 5 utterances in 2 shards
+    rng = np.random.RandomState(3)
+    synth = []
+    for i in range(5):
+        n = int(rng.randint(16000, 40000))
+        pcm = (rng.randn(n) * 3000).astype(np.int16)
+        segs, t = [], 0.0
+        while t + 0.3 < n / 16000:
+            e = min(t + float(rng.uniform(0.2, 0.9)), n / 16000)
+            segs.append({"start": round(t, 2), "end": round(e, 2), "txt": f"utt{i}-seg{len(segs)}"})
+            t = e
+        synth.append(({"key": f"synth{i}", "wav": f"synth{i}.wav", "txt": f"text {i}", "info": {"segments": segs}}, pcm))
+    write_shards(f"{root}/synthetic", synth, 3)
+
+    out = {}
+
+    def run(name, list_dirs, dp_rank=0, dp_world=1, state=None, limit=None, **over):
+        lst = os.path.join(HERE, "_tmp_data.list")
+        with open(lst, "w") as f:
+            for d in list_dirs:
+                f.write(f"{d} audio+metainfo\n")
+        cfg = types.SimpleNamespace(datalist_path=lst, datalist_epoch=1, datalist_shuffling=False,
+                                    datalist_sharding=False, dataset_mmap=True, dataset_shuffling=False,
+                                    dataset_load_audio_via_segments=False, dataset_random_cut_audio=False,
+                                    dataset_random_cut_audio_min_length_in_ms=5000,
+                                    dataset_random_cut_audio_max_length_in_ms=3600000)
+        for k, v in over.items():
+            setattr(cfg, k, v)
+        pipe = LowLevelTouchDatapipe(cfg, dp_rank, dp_world)
+        if state:
+            pipe.load_state_dict(state)
+        keys, txts, lens, sums, heads, states = [], [], [], [], [], []
+        for i, smp in enumerate(pipe):
+            w = smp["waveform"]
+            assert w.dtype == torch.float32 and w.dim() == 2 and w.shape[0] == 1
+            pcm = (w[0].numpy() * 32768.0).astype(np.int64)
+            keys.append(smp["key"]); txts.append(smp["txt"]); lens.append(pcm.size)
+            sums.append(int(np.abs(pcm).sum())); heads.append(pcm[:4].tolist() + [0] * (4 - min(4, pcm.size)))
+            states.append([pipe.epoch, pipe.consumed_lists, pipe.consumed_samples])
+            if limit and i + 1 >= limit:
+                break
+        os.remove(lst)
+        out[f"{name}/keys"] = np.array(keys); out[f"{name}/txts"] = np.array(txts)
+        out[f"{name}/lens"] = np.array(lens); out[f"{name}/abs_sums"] = np.array(sums)
+        out[f"{name}/heads"] = np.array(heads); out[f"{name}/states"] = np.array(states)
+        print(f"  {name}: {len(keys)} samples {keys[:4]}")
+
+    rel = lambda *p: os.path.join(root, *p)
+    one = [rel("1sample_per_shard", "000000000"), rel("1sample_per_shard", "000000001")]
+    two = [rel("2sample_per_shard", "000000000")]
+    syn = [rel("synthetic", "000000000"), rel("synthetic", "000000001")]
+    run("plain_1per", one)
+    run("plain_2per", two)
+    run("shuffled_2epochs", syn + one, datalist_epoch=2, datalist_shuffling=True, dataset_shuffling=True)
+    run("sharded_rank1of2", syn + one, dp_rank=1, dp_world=2, datalist_sharding=True, datalist_shuffling=True)
+    run("segments", syn, dataset_load_audio_via_segments=True, dataset_shuffling=True)
+    run("random_cut", syn + two, dataset_random_cut_audio=True, dataset_random_cut_audio_min_length_in_ms=500,
+        dataset_random_cut_audio_max_length_in_ms=1500)
+    run("resumed", syn, state=dict(epoch=0, consumed_lists=0, consumed_samples=2), dataset_shuffling=True)
+    # raw reader: partial reads
+    ds = TouchDataset(two[0], True, "audio+metainfo")
+    out["reader/len"] = np.array(len(ds))
+    out["reader/idx0"] = np.array([int(v) for v in ds.get_idx(0, "audio")])
+    out["reader/idx1"] = np.array([int(v) for v in ds.get_idx(1, "audio")])
+    out["reader/partial"] = np.asarray(ds.get(1, "audio", offset=1000, length=64))
+    out["reader/meta0"] = np.asarray(ds.get(0, "metainfo"))
+    save("touchdataset.npz", **out)
+
+
 if __name__ == "__main__":
     only = set(sys.argv[1:])
     for fn in (text_cases, asr_cases, ce_cases, docmask_cases, rope_cases, tiny_llama_case,
-               touch_audio_case, qwen2_audio_tower_case, frontend_cases, bestrq_cases):
+               touch_audio_case, qwen2_audio_tower_case, frontend_cases, bestrq_cases, touchdataset_case):
         if not only or fn.__name__ in only:
             fn()

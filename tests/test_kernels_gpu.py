@@ -566,3 +566,26 @@ def test_bestrq_tokenize_full_size_properties():
     assert (F.bestrq_tokenize(fd[:4096] * scale, qd, cd) != codes[:4096]).float().mean() <= 0.002
     assert torch.equal(F.bestrq_tokenize(fd[:1000 + 13], qd, cd), codes[:1013])
     assert F.bestrq_tokenize(fd[:0], qd, cd).numel() == 0
+
+
+# ------------------------------------------------------------------------------------ int16 PCM on the device (§8f-3)
+def test_pcm16_to_float_exact_and_frontend_equivalence(golden):
+    """tn_pcm16_to_f32 == numpy's astype(float32) / 32768 for EVERY int16 value (bit exact), on ragged / unaligned
+    slices, and the log-mel stage fed int16 samples equals the stage fed the reference's float waveform."""
+    import types
+    F = _f()
+    allv = torch.arange(-32768, 32768, dtype=torch.int32).to(torch.int16)
+    want = torch.from_numpy(allv.numpy().astype(np.float32) / 32768.0)
+    assert torch.equal(F.pcm16_to_float(allv.to(DEV)).cpu(), want)
+    for off, n in ((1, 17), (3, 4099), (0, 8), (5, 0)):
+        assert torch.equal(F.pcm16_to_float(allv.to(DEV)[off:off + n]).cpu(), want[off:off + n])
+    with pytest.raises(RuntimeError):
+        F.pcm16_to_float(allv)                                   # CPU tensor: refused
+    from touchnet_amd.data import functions as stages
+    pcm = torch.from_numpy(golden("logmel.npz")["wav0/pcm"].astype(np.int16))[None]
+    cfg = types.SimpleNamespace(audiofeat_padding=0, audiofeat_n_fft=400, audiofeat_hop_length=160,
+                                audiofeat_num_mel_bins=128)
+    a = next(stages.audio_compute_log_mel_spectrogram(iter([{"sample_rate": 16000, "waveform": pcm.clone()}]), cfg))
+    b = next(stages.audio_compute_log_mel_spectrogram(
+        iter([{"sample_rate": 16000, "waveform": pcm.to(torch.float32) / 32768.0}]), cfg))
+    assert torch.equal(a["audiofeat"], b["audiofeat"])

@@ -207,6 +207,29 @@ __global__ __launch_bounds__(256) void audiofeat_stack_kernel(const float* __res
   for (int e = lane; e < n; e += 64) out[(size_t)row * n + e] = (src(e) - mean) * inv;
 }
 
+// int16 PCM -> float32 in [-1, 1): x * 2^-15, exactly numpy's `astype(float32) / 32768.0` of the reference's
+// datapipe (touchnet/data/datapipe.py:164).  Lets the caller upload 2 bytes per sample.
+__global__ __launch_bounds__(256) void pcm16_to_f32_kernel(const int16_t* __restrict__ in, float* __restrict__ out,
+                                                           long long n) {
+  const long long i8 = ((long long)blockIdx.x * 256 + threadIdx.x) * 8;
+  if (i8 >= n) return;
+  if (i8 + 8 <= n && ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
+    const uint4 v = *reinterpret_cast<const uint4*>(in + i8);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    float f[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      f[2 * k] = (float)(int16_t)(w[k] & 0xffffu) * (1.f / 32768.f);
+      f[2 * k + 1] = (float)(int16_t)(w[k] >> 16) * (1.f / 32768.f);
+    }
+    float4* o = reinterpret_cast<float4*>(out + i8);
+    o[0] = make_float4(f[0], f[1], f[2], f[3]);
+    o[1] = make_float4(f[4], f[5], f[6], f[7]);
+  } else {
+    for (long long i = i8; i < min(i8 + 8, n); ++i) out[i] = (float)in[i] * (1.f / 32768.f);
+  }
+}
+
 }  // namespace tn
 
 using namespace tn;
@@ -249,6 +272,16 @@ int tn_audiofeat_stack(const float* feat, float* out, int T, int F, int stack, i
   const int t_lfr = (T + stride - 1) / stride;
   hipLaunchKernelGGL(audiofeat_stack_kernel, dim3((t_lfr + 3) / 4), dim3(256), 0, (hipStream_t)stream, feat, out, T,
                      F, stack, stride, t_lfr, normalize);
+  TN_LAUNCH_CHECK();
+  return TN_OK;
+}
+
+int tn_pcm16_to_f32(const void* pcm, float* out, long long n, void* stream) {
+  if (n <= 0) return TN_OK;
+  const long long blocks = (n + 2047) / 2048;
+  if (blocks > 0x7fffffffLL) return TN_EINVAL;
+  hipLaunchKernelGGL(pcm16_to_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                     (const int16_t*)pcm, out, n);
   TN_LAUNCH_CHECK();
   return TN_OK;
 }

@@ -6,8 +6,9 @@ MidLevelTouchDatapipe(source, f, *args) (touchnet/data/datapipe.py:183-213) unch
     audio_compute_log_mel_spectrogram   functions.py:159-190
     audiofeat_stack                     functions.py:258-286
 
-Samples carry `waveform` [1, N] float32 in [-1, 1) (datapipe.py int16 / 32768); it is moved to the
-current HIP device once and every later stage stays there.
+Samples carry `waveform` [1, N]: float32 in [-1, 1) (datapipe.py int16 / 32768) or, from
+touchnet_amd.data.datapipe with `dataset_keep_pcm16`, the int16 samples themselves (2 bytes per sample over PCIe,
+converted in HBM).  It is moved to the current HIP device once and every later stage stays there.
 """
 import torch
 
@@ -18,6 +19,8 @@ def _dev_wave(sample):
     w = sample["waveform"]
     if not w.is_cuda:
         w = w.to(torch.device("cuda", torch.cuda.current_device()), non_blocking=True)
+    if w.dtype == torch.int16:
+        w = ops().pcm16_to_float(w)
     return w.reshape(-1)
 
 

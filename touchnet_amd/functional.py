@@ -575,6 +575,16 @@ def log_mel_spectrogram(wav: torch.Tensor, num_mel_bins: int = 128, padding: int
     return feat
 
 
+def pcm16_to_float(pcm: torch.Tensor) -> torch.Tensor:
+    """int16 PCM on the device -> float32 in [-1, 1) (x / 32768, exact; touchnet/data/datapipe.py:164)."""
+    if not pcm.is_cuda or pcm.dtype != torch.int16:
+        raise RuntimeError("pcm16_to_float: expects an int16 device tensor")
+    pcm = _c(pcm)
+    out = torch.empty(pcm.shape, dtype=torch.float32, device=pcm.device)
+    _C.check(_C.lib().tn_pcm16_to_f32(_p(pcm), _p(out), pcm.numel(), _cur()), "tn_pcm16_to_f32")
+    return out
+
+
 def bestrq_tokenize(feat: torch.Tensor, quantizer: torch.Tensor, codebook: torch.Tensor) -> torch.Tensor:
     """BEST-RQ codes (touchnet/tokenizer/tokenizer.py:289-299): feat [T, F], quantizer [F, E], L2-normalised
     codebook [V, E], all fp32 on the device -> int64 [T]."""
