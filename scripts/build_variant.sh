@@ -9,7 +9,8 @@ out=$root/touchnet_amd/_lib/variants/$name
 mkdir -p "$out"
 pids=()
 for src in "$root"/touchnet_amd/csrc/*.hip; do
-  hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-result "$@" -c "$src" -o "$out/$(basename "${src%.hip}").o" &
+  extra=""; case "$(basename "$src")" in attn_fwd.hip|attn_fwd_pp.hip) extra="-fno-honor-nans";; esac   # = build.py EXTRA_FLAGS
+  hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-result $extra "$@" -c "$src" -o "$out/$(basename "${src%.hip}").o" &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait "$p"; done

@@ -23,6 +23,12 @@ ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result"]
 
 
+# per-file extras.  -fno-honor-nans: lets fmaxf chains over MFMA outputs become v_max3_f32 without a canonicalising
+# v_max per element (the forward softmax's row max); these kernels produce and consume no NaNs (masked scores are
+# -inf, fully masked rows are handled explicitly).
+EXTRA_FLAGS = {"attn_fwd.hip": ["-fno-honor-nans"], "attn_fwd_pp.hip": ["-fno-honor-nans"]}
+
+
 def _hipcc() -> str:
     exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(exe):
@@ -31,7 +37,7 @@ def _hipcc() -> str:
 
 
 def _digest(paths) -> str:
-    h = hashlib.sha256(" ".join(FLAGS).encode())
+    h = hashlib.sha256((" ".join(FLAGS) + repr(sorted(EXTRA_FLAGS.items()))).encode())
     for p in sorted(paths):
         with open(p, "rb") as f:
             h.update(f.read())
@@ -54,7 +60,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     def compile_one(src):
         obj = os.path.join(OUT, os.path.basename(src)[:-4] + ".o")
-        cmd = [hipcc, *FLAGS, "-c", src, "-o", obj]
+        cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(os.path.basename(src), []), "-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr}")

@@ -24,12 +24,12 @@ typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
 __device__ __forceinline__ f32x16_t mfma32(bf16x8_t a, bf16x8_t b, f32x16_t c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
-// max of three without the NaN-quieting canonicalisation fmaxf() implies (inputs here are never signalling NaNs)
-__device__ __forceinline__ float max3(float a, float b, float c) {
-  float r;
-  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-  return r;
-}
+// max of three: compiles to ONE v_max3_f32 when the file is built with -fno-honor-nans (touchnet_amd/build.py does
+// that for the attention forward kernels; without the flag every MFMA output is canonicalised first: 2x the VALU
+// work, still correct).  Deliberately NOT inline asm: hipcc's hazard recognizer does not look inside asm blocks, and
+// a v_max3 that reads a just-issued MFMA's registers without the required wait states returns stale data —
+// run-to-run 1-ulp differences in the D = 64 kernel were exactly that.
+__device__ __forceinline__ float max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 __device__ __forceinline__ bf16x8_t as_bf16x8(uint4 v) {
   u32x4_t t = {v.x, v.y, v.z, v.w};
   return __builtin_bit_cast(bf16x8_t, t);
@@ -97,6 +97,70 @@ __device__ __forceinline__ int head_of_slot(int x, int Nh, int Nkv) {
 // allowed?  Conservative on purpose: false only when the id ranges are disjoint.
 __device__ __forceinline__ bool tile_may_interact(int qminpos, int qmax, int kminpos, int kmax) {
   return !(qminpos == 0x7fffffff || kminpos == 0x7fffffff || kmax < qminpos || kminpos > qmax);
+}
+
+// ---- KV-tile list in LDS --------------------------------------------------------------------------------------
+// The tile loops used to walk the metadata arrays themselves: per tile two or three DEPENDENT scalar global loads
+// (interaction test of the next tile, then of the current one), ~1-2 k cycles of latency each way (s_memtime trace of
+// the ping-pong forward: QK^T segment 2100 -> 860 cycles without them).  Instead the workgroup compacts, ONCE per
+// chunk of tiles (the caller's list capacity), the tiles of [lo, hi] that may interact with its query id range into LDS:
+//   entry = {tile, min id, max id, min positive id};  entries [n, n + 4) = sentinels {hi_all + 1, 0, 0, 0}.
+// NT = threads per workgroup (all must call; contains barriers).  Returns n (wave-uniform, in an SGPR).
+constexpr int kListCap = 1024;
+
+template <int NT>
+__device__ __forceinline__ int build_kv_list(int4* list, int* wcount, int lo, int hi, int sentinel, int bminpos,
+                                             int bmax, const int* m_min, const int* m_max, const int* m_minpos,
+                                             int tid) {
+  constexpr int NW = NT / 64;
+  const int lane = tid & 63, wave = tid >> 6;
+  int n = 0;
+  for (int base = lo; base <= hi; base += NT) {
+    const int j = base + tid;
+    int mn = 0, mx = 0, mp = 0;
+    bool ok = false;
+    if (j <= hi) {
+      mn = m_min[j];
+      mx = m_max[j];
+      mp = m_minpos[j];
+      ok = tile_may_interact(bminpos, bmax, mp, mx);
+    }
+    const unsigned long long bal = __ballot(ok);
+    if (lane == 0) wcount[wave] = __popcll(bal);
+    __syncthreads();
+    int before = n, total = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const int c = wcount[w];
+      before += w < wave ? c : 0;
+      total += c;
+    }
+    if (ok) list[before + __popcll(bal & ((1ull << lane) - 1ull))] = make_int4(j, mn, mx, mp);
+    n += __builtin_amdgcn_readfirstlane(total);
+    __syncthreads();
+  }
+  if (tid < 4) list[n + tid] = make_int4(sentinel, 0, 0, 0);
+  __syncthreads();
+  return n;
+}
+
+// list entry i as four scalars (one broadcast LDS read + 4 readfirstlane)
+__device__ __forceinline__ int4 list_entry(const int4* list, int i) {
+  const int4 e = list[i];
+  return make_int4(__builtin_amdgcn_readfirstlane(e.x), __builtin_amdgcn_readfirstlane(e.y),
+                   __builtin_amdgcn_readfirstlane(e.z), __builtin_amdgcn_readfirstlane(e.w));
+}
+__device__ __forceinline__ int4 scalarize(int4 e) {
+  return make_int4(__builtin_amdgcn_readfirstlane(e.x), __builtin_amdgcn_readfirstlane(e.y),
+                   __builtin_amdgcn_readfirstlane(e.z), __builtin_amdgcn_readfirstlane(e.w));
+}
+
+// max over the two 32-lane halves of a wave without an LDS round trip (ds_bpermute queues behind other waves'
+// operand reads): v_permlane32_swap exchanges a's upper half with b's lower half.
+__device__ __forceinline__ float half_swap_max(float x) {
+  float a = x, b = x;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  return fmaxf(a, b);
 }
 
 // Positive-id range of a wave's 32 rows (both 32-lane halves hold the same rows), returned in SGPRs so that

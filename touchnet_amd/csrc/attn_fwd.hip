@@ -86,6 +86,9 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(const bf16_t* __re
   // ONE barrier per KV tile (2 x 38 KB at D=128 -> still two workgroups per CU)
   constexpr int BUF = BN * KLD + D * TLds<BN>::STRIDE + 2 * BN;
   __shared__ __attribute__((aligned(16))) bf16_t smem[2 * BUF];
+  constexpr int CAP = 192;            // list chunk: 3 KB, keeps two workgroups per CU at D = 128 (2 x 79.4 KB)
+  __shared__ __attribute__((aligned(16))) int4 tlist[CAP + 4];        // interacting KV tiles (attn_common.h)
+  __shared__ int wcount[NW];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hi = lane >> 5;
@@ -125,12 +128,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(const bf16_t* __re
     bmax = max(bmax, m_max[t]);
     j = min(j, meta.q_lo[(size_t)b * meta.nt + t]);
   }
-  const int j_hi = t1;
-  auto advance = [&](int jj) {
-    while (jj <= j_hi && !tile_may_interact(bminpos, bmax, m_minpos[jj], m_max[jj])) ++jj;
-    return jj;
-  };
-  j = advance(j);
+  const int j_hi = t1, j_lo = j;
 
   f32x16_t oacc[DBLK];
 #pragma unroll
@@ -158,25 +156,27 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(const bf16_t* __re
     vst.store(base + BN * KLD, tid);
     if (tid < BN) reinterpret_cast<int*>(base + BN * KLD + D * TLds<BN>::STRIDE)[tid] = dstage;
   };
-  int jn = j_hi + 1;
-  if (j <= j_hi) {
-    issue(j);
-    stage_store(0);
-    jn = advance(j + 1);
-    if (jn <= j_hi) issue(jn);          // tile j+1 flies under the compute of tile j
-  }
-  __syncthreads();
+  // The tiles of [j_lo, j_hi] are walked in chunks of CAP through the LDS list.
   int cur = 0;
-
-  while (j <= j_hi) {
-    const bf16_t* Ks = smem + cur * BUF;
-    const bf16_t* Vt = Ks + BN * KLD;
-    const int* docs = reinterpret_cast<const int*>(Vt + D * TLds<BN>::STRIDE);
-    const int k0 = j * BN;
-    const int kminpos = m_minpos[j], kmax = m_max[j];
+  for (int c_lo = j_lo; c_lo <= j_hi; c_lo += CAP) {
+    const int n = build_kv_list<NT>(tlist, wcount, c_lo, min(c_lo + CAP - 1, j_hi), j_hi + 1, bminpos, bmax, m_min,
+                                    m_max, m_minpos, tid);
+    if (n == 0) continue;
+    issue(list_entry(tlist, 0).x);
+    stage_store(cur);
+    int4 e_cur = list_entry(tlist, 0), e_nxt = list_entry(tlist, 1);
+    if (e_nxt.x <= j_hi) issue(e_nxt.x);    // tile i+1 flies under the compute of tile i
+    __syncthreads();
+    for (int i = 0; i < n; ++i) {
+      const int4 e_nn = tlist[i + 2];       // (vector read now, scalarised at the hand-over)
+      const bf16_t* Ks = smem + cur * BUF;
+      const bf16_t* Vt = Ks + BN * KLD;
+      const int* docs = reinterpret_cast<const int*>(Vt + D * TLds<BN>::STRIDE);
+      const int j = e_cur.x, kmin = e_cur.y, kmax = e_cur.z, kminpos = e_cur.w;
+      const int k0 = j * BN;
     if (uniform(k0 <= wq0 + 31 && tile_may_interact(wminpos, wmax, kminpos, kmax))) {
       const bool need_mask = uniform(
-          !(m_min[j] == kmax && kmax == wminpos && wminpos == wmax && !w_has_zero && (k0 + BN - 1 <= wq0)));
+          !(kmin == kmax && kmax == wminpos && wminpos == wmax && !w_has_zero && (k0 + BN - 1 <= wq0)));
       // ---- S^T[kv, q] = K[kv, :] . Q[q, :]
       f32x16_t sacc[2];
 #pragma unroll
@@ -206,11 +206,21 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(const bf16_t* __re
           }
         }
       }
+      {   // four independent v_max3 chains (fmaxf() canonicalises every MFMA output first: 2x the VALU work)
+        float mxs[4];
 #pragma unroll
-      for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) mx = fmaxf(mx, fmaxf(sacc[blk][r], sacc[blk][r + 1]));   // v_max3_f32
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * scale_log2;
+        for (int c = 0; c < 4; ++c) {
+          const int blk = c >> 1, o = 8 * (c & 1);
+          mxs[c] = max3(sacc[blk][o + 0], sacc[blk][o + 1], sacc[blk][o + 2]);
+          mxs[c] = max3(mxs[c], sacc[blk][o + 3], sacc[blk][o + 4]);
+          mxs[c] = max3(mxs[c], sacc[blk][o + 5], sacc[blk][o + 6]);
+        }
+        mx = max3(mxs[0], mxs[1], sacc[0][7]);
+        mx = max3(mx, mxs[2], sacc[0][15]);
+        mx = max3(mx, mxs[3], sacc[1][7]);
+        mx = max3(mx, sacc[1][15], sacc[1][15]);
+      }
+      mx = half_swap_max(mx) * scale_log2;
       if (ABL == 2) mx = m_run;
       // Deferred rescale (threshold 8 in the log2 domain): while no row's running max grows by more than 2^8 the
       // old reference max stays, P <= 256 is exact enough in bf16 and the 16*DBLK-register O rescale is skipped.
@@ -259,20 +269,18 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(const bf16_t* __re
         }
       }
     }
-    // ---- hand-over: tile jn (already in registers) -> the other buffer, then prefetch the tile after it.
-    // WAR-safe: the other buffer was last read in the previous iteration, which every wave left through the
-    // barrier below; RAW-safe: it is read only after this iteration's barrier.
-    if (jn <= j_hi) {
-      if (ABL != 1) stage_store(cur ^ 1);
-      const int jnn = advance(jn + 1);
-      if (jnn <= j_hi && ABL != 1) issue(jnn);
-      j = jn;
-      jn = jnn;
-    } else {
-      j = jn;
+      // ---- hand-over: tile i+1 (already in registers) -> the other buffer, then prefetch tile i+2.
+      // WAR-safe: the other buffer was last read in the previous iteration, which every wave left through the
+      // barrier below; RAW-safe: it is read only after this iteration's barrier.
+      e_cur = e_nxt;
+      e_nxt = scalarize(e_nn);
+      if (i + 1 < n) {
+        if (ABL != 1) stage_store(cur ^ 1);
+        if (e_nxt.x <= j_hi && i + 2 < n && ABL != 1) issue(e_nxt.x);
+      }
+      if (ABL != 5) __syncthreads();
+      cur ^= 1;
     }
-    if (ABL != 5) __syncthreads();
-    cur ^= 1;
   }
 
   // ---- epilogue: normalise, store O (4 consecutive head-dim elements = 8 bytes per store) and LSE2

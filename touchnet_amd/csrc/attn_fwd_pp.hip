@@ -46,14 +46,6 @@ __device__ unsigned long long g_pp_blocks[8192][2];   // per workgroup: s_memrea
 #endif
 __device__ __forceinline__ void keep_alive(uint4 v) { asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w)); }
 
-// max over the two 32-lane halves of a wave without an LDS round trip (ds_bpermute queues behind the partner
-// group's operand reads): v_permlane32_swap exchanges a's upper half with b's lower half.
-__device__ __forceinline__ float half_swap_max(float x) {
-  float a = x, b = x;
-  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
-  return max3(a, b, b);
-}
-
 // LDS image of V^T for the P.V operand: element (d, kv) at  d * (R + 8) + 4 * pos(kv >> 2) + (kv & 3)  with
 // pos(g) = 4 * (g >> 2) + bitswap2(g & 3): the two 4-kv groups {g, g + 2} that one lane-half contracts in one MFMA
 // (rows 4*hi + {0..3} and + 8 of the QK^T C-layout) sit side by side, so an operand is ONE ds_read_b128 (256 B/clk,
