@@ -35,7 +35,7 @@ def pcm16_to_float(pcm):
     return pcm.to(torch.float32) / 32768.0
 
 
-def linear_group(x, layers, wgrad_tn=True):
+def linear_group(x, layers, wgrad="tn", dgrad_tn=True):
     """mirror of touchnet_amd.functional.linear_group: plain nn.Linear math per layer"""
     return [torch.nn.functional.linear(x, w, b) for w, b in layers]
 

@@ -489,9 +489,10 @@ def test_transpose_bf16_bit_exact(R, C):
         F.transpose_2d(x[:, :C - 1])                                           # not a multiple of 8 -> -22, loud
 
 
-@pytest.mark.parametrize("M,K,Ns,bias,wtn", [(512, 256, (256, 64, 64), True, True), (2048, 1024, (2816, 2816), False, True),
-                                             (384, 128, (128,), False, True), (384, 2816, (1024,), False, False),
-                                             (100, 64, (64, 32), True, True)])
+@pytest.mark.parametrize("M,K,Ns,bias,wtn", [(512, 256, (256, 64, 64), True, "tn"), (2048, 1024, (2816, 2816), False, "tn"),
+                                             (384, 128, (128,), False, "tn"), (384, 2816, (1024,), False, "nt"),
+                                             (1000, 1280, (1280, 1280, 1280), True, "nt_fused"),
+                                             (100, 64, (64, 32), True, "tn")])
 def test_linear_group_matches_autograd(M, K, Ns, bias, wtn):
     """Forward = nn.Linear; backward (transposed-operand weight-gradient GEMM over the whole group, addmm-accumulated
     input gradient) against autograd's own nn.Linear backward in fp32 on the same bf16-rounded inputs.
@@ -512,7 +513,7 @@ def test_linear_group_matches_autograd(M, K, Ns, bias, wtn):
         return ys, xx.grad, [w.grad for w in ww], [None if b is None else b.grad for b in bb]
 
     ref = run("cpu", torch.float32, lambda xx, layers: [torch.nn.functional.linear(xx, w, b) for w, b in layers])
-    got = run(DEV, torch.bfloat16, lambda xx, layers: F.linear_group(xx, layers, wgrad_tn=wtn))
+    got = run(DEV, torch.bfloat16, lambda xx, layers: F.linear_group(xx, layers, wgrad=wtn, dgrad_tn=wtn != "nt_fused"))
     for a, b in zip(got[0], ref[0]):
         torch.testing.assert_close(a.float().cpu(), b, rtol=2e-2, atol=2e-2)
     torch.testing.assert_close(got[1].float().cpu(), ref[1], rtol=2e-2, atol=2e-2 * float(ref[1].abs().max()))

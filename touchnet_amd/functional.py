@@ -469,14 +469,17 @@ class _LinearGroup(torch.autograd.Function):
     The INPUT gradient dX = sum_i dY_i W_i contracts over W_i's slow dimension; with W_i transposed first (33-90 MB,
     ~0.01-0.04 ms) the same hipBLASLt GEMM runs 8-19 % faster (scripts/gemm_layout_bench.py: 4096^2 0.50 -> 0.43 ms,
     11008 -> 4096 1.11 -> 0.93 ms); it accumulates over the group inside the GEMM epilogue (addmm, beta = 1).
-    ``wgrad_tn=False`` keeps autograd's weight-gradient layout (down_proj: no gain at N = 4096, K = 11008)."""
+    ``wgrad``: "tn" (above) | "nt" autograd's layout per layer (down_proj: no gain at N = 4096, K = 11008) |
+    "nt_fused" one NT GEMM over the column-concatenated dY (the 1280-wide audio tower: three 1280 x 1280 outputs
+    are 25 tiles each, 351 TFLOP/s; fused 781 TFLOP/s, while TN brings nothing at that width).
+    ``dgrad_tn=False`` keeps W as stored for the input gradient (no gain at 1280 x 1280)."""
 
     @staticmethod
-    def forward(ctx, x, n, wgrad_tn, *wb):
+    def forward(ctx, x, n, wgrad, dgrad_tn, *wb):
         ws, bs = wb[:n], wb[n:]
         ctx.save_for_backward(x, *ws)
         ctx.has_bias = [b is not None for b in bs]
-        ctx.wgrad_tn = wgrad_tn
+        ctx.wgrad, ctx.dgrad_tn = wgrad, dgrad_tn
         return tuple(torch.nn.functional.linear(x, w, b) for w, b in zip(ws, bs))
 
     @staticmethod
@@ -488,12 +491,12 @@ class _LinearGroup(torch.autograd.Function):
         M = x2.shape[0]
         dys = [torch.zeros(M, w.shape[0], dtype=x.dtype, device=x.device) if d is None else _c(d).reshape(M, -1)
                for d, w in zip(dys, ws)]
-        need_x, need_w = ctx.needs_input_grad[0], [ctx.needs_input_grad[3 + i] for i in range(n)]
+        need_x, need_w = ctx.needs_input_grad[0], [ctx.needs_input_grad[4 + i] for i in range(n)]
         Ns = [w.shape[0] for w in ws]
         hip_ok = x.dtype == torch.bfloat16 and x.is_cuda and _tn_ok(M, K, Ns)
         dx = None
         if need_x:
-            wv = [transpose_2d(_c(w)).t() for w in ws] if hip_ok else ws           # [N, K] views of W^T storage
+            wv = [transpose_2d(_c(w)).t() for w in ws] if (hip_ok and ctx.dgrad_tn) else ws   # [N, K] views of W^T
             dx = torch.mm(dys[0], wv[0])
             for d, w in zip(dys[1:], wv[1:]):
                 dx.addmm_(d, w)
@@ -501,7 +504,9 @@ class _LinearGroup(torch.autograd.Function):
             del wv
         dws = [None] * n
         if any(need_w):
-            if hip_ok and ctx.wgrad_tn:
+            if ctx.wgrad == "nt_fused" and n > 1:
+                dws = list(torch.split(torch.mm(torch.cat(dys, dim=1).t(), x2), Ns, dim=0))
+            elif hip_ok and ctx.wgrad == "tn":
                 xt = transpose_2d(_c(x2))                                          # [K, M]
                 dyt = torch.empty(sum(Ns), M, dtype=x.dtype, device=x.device)      # [sum N, M]
                 o = 0
@@ -513,16 +518,18 @@ class _LinearGroup(torch.autograd.Function):
             else:
                 dws = [torch.mm(d.t(), x2) for d in dys]
             dws = [g if nw else None for g, nw in zip(dws, need_w)]
-        dbs = [d.sum(0) if (hb and ctx.needs_input_grad[3 + n + i]) else None
+        dbs = [d.sum(0) if (hb and ctx.needs_input_grad[4 + n + i]) else None
                for i, (d, hb) in enumerate(zip(dys, ctx.has_bias))]
-        return (dx, None, None, *dws, *dbs)
+        return (dx, None, None, None, *dws, *dbs)
 
 
-def linear_group(x, layers, wgrad_tn: bool = True):
+def linear_group(x, layers, wgrad: str = "tn", dgrad_tn: bool = True):
     """``layers``: list of (weight [N_i, K], bias [N_i] | None) sharing the input ``x`` -> list of outputs."""
+    if wgrad not in ("tn", "nt", "nt_fused"):
+        raise ValueError(f"linear_group: wgrad={wgrad!r}")
     ws = [w for w, _ in layers]
     bs = [b for _, b in layers]
-    return list(_LinearGroup.apply(x, len(ws), wgrad_tn, *ws, *bs))
+    return list(_LinearGroup.apply(x, len(ws), wgrad, dgrad_tn, *ws, *bs))
 
 
 # ------------------------------------------------------------------------------------ frontend

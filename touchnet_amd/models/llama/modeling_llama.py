@@ -90,7 +90,7 @@ class MLP(nn.Module):
     def forward(self, x):
         gate, up = ops().linear_group(x, [(self.gate_proj.weight, None), (self.up_proj.weight, None)])
         # (down_proj, 11008 -> 4096, gains nothing from the transposed weight-gradient layout)
-        return ops().linear_group(ops().swiglu(gate, up), [(self.down_proj.weight, None)], wgrad_tn=False)[0]
+        return ops().linear_group(ops().swiglu(gate, up), [(self.down_proj.weight, None)], wgrad="nt")[0]
 
 
 class DecoderLayer(nn.Module):
