@@ -150,6 +150,13 @@ int tn_adamw_step(float* p, float* m, float* v, const void* g, void* p_shadow_bf
 int tn_transpose_bf16(const void* src, void* dst, int rows, int cols, long long src_ld, long long dst_ld,
                       void* stream);
 
+/* ---- bias gradient of a linear layer: out[c] = sum_r x[r*ld + c], x bf16 [rows, cols] (cols, ld multiples of 8),
+ *      out bf16 [cols]; fp32 accumulation, deterministic two-stage reduction through ws
+ *      (tn_colsum_workspace_floats(rows, cols) floats).  Replaces the `grad_output.sum(0)` of
+ *      torch.nn.functional.linear's backward for the biased projections (Qwen2 q/k/v, the audio tower). */
+long long tn_colsum_workspace_floats(int rows, int cols);
+int tn_colsum_bf16(const void* x, void* out, float* ws, int rows, int cols, long long ld, void* stream);
+
 /* ---- int16 PCM of a TouchDataset audio shard -> float32 [-1, 1) on the device (x / 32768, exact): the conversion
  *      the reference does on a CPU worker, touchnet/data/datapipe.py:163-165 */
 int tn_pcm16_to_f32(const void* pcm_int16, float* out, long long n, void* stream);

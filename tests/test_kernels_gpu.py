@@ -489,6 +489,21 @@ def test_transpose_bf16_bit_exact(R, C):
         F.transpose_2d(x[:, :C - 1])                                           # not a multiple of 8 -> -22, loud
 
 
+@pytest.mark.parametrize("R,C", [(7, 8), (64, 1280), (30000, 1280), (4097, 5120), (16384, 4096)])
+def test_column_sum_bias_gradient(R, C):
+    """tn_colsum_bf16 vs an fp64 column sum of the same bf16 values: fp32 accumulation, one bf16 rounding; also on a
+    column slice of a wider matrix (row stride > cols) and deterministic."""
+    F = _f()
+    x = torch.randn(R, C + 16, device=DEV).to(torch.bfloat16)
+    for view in (x[:, :C], x[:, 8:8 + C].contiguous()):
+        got = F.column_sum(view)
+        ref = view.double().sum(0)
+        assert got.dtype == torch.bfloat16 and got.shape == (C,)
+        tol = 2.0 ** -8 * ref.abs().clamp_min(1.0) + 1e-3 * math.sqrt(R)     # bf16 ulp of the result + fp32 sum error
+        assert ((got.double() - ref).abs() <= tol).all(), float((got.double() - ref).abs().max())
+        assert torch.equal(got, F.column_sum(view))
+
+
 @pytest.mark.parametrize("M,K,Ns,bias,wtn", [(512, 256, (256, 64, 64), True, "tn"), (2048, 1024, (2816, 2816), False, "tn"),
                                              (384, 128, (128,), False, "tn"), (384, 2816, (1024,), False, "nt"),
                                              (1000, 1280, (1280, 1280, 1280), True, "nt_fused"),

@@ -50,12 +50,15 @@ PROTOTYPES = {
     "tn_sumsq": [_vp, _vp, _vp, _ll, _i, _vp],
     "tn_adamw_step": [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _f, _f, _f, _f, _i, _vp],
     "tn_transpose_bf16": [_vp, _vp, _i, _i, _ll, _ll, _vp],
+    "tn_colsum_workspace_floats": [_i, _i],
+    "tn_colsum_bf16": [_vp, _vp, _vp, _i, _i, _ll, _vp],
     "tn_pcm16_to_f32": [_vp, _vp, _ll, _vp],
     "tn_bestrq_tokenize": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "tn_sumsq_multi_chunk": [],
     "tn_sumsq_multi": [_vp, _vp, _vp, _i, _ll, _vp, _vp, _i, _vp],
 }
-_RESTYPE = {"tn_version": C.c_char_p, "tn_sumsq_multi_chunk": C.c_longlong}
+_RESTYPE = {"tn_version": C.c_char_p, "tn_sumsq_multi_chunk": C.c_longlong,
+            "tn_colsum_workspace_floats": C.c_longlong}
 
 _lib = None
 

@@ -454,6 +454,17 @@ def transpose_2d(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.T
     return out
 
 
+def column_sum(x: torch.Tensor) -> torch.Tensor:
+    """``x.sum(0)`` of a bf16 [rows, cols] device matrix (fp32 accumulation, bf16 result): the bias gradient."""
+    R, Cn = x.shape
+    if x.dtype != torch.bfloat16 or not x.is_cuda or x.stride(1) != 1 or Cn % 8 or x.stride(0) % 8:
+        return x.sum(0)                                    # (fp32 / odd widths: torch's reduction, still on the device)
+    ws = torch.empty(int(_C.lib().tn_colsum_workspace_floats(R, Cn)), dtype=torch.float32, device=x.device)
+    out = torch.empty(Cn, dtype=x.dtype, device=x.device)
+    _C.check(_C.lib().tn_colsum_bf16(_p(x), _p(out), _p(ws), R, Cn, x.stride(0), _cur()), "tn_colsum_bf16")
+    return out
+
+
 def _tn_ok(M: int, K: int, Ns) -> bool:
     return M % 8 == 0 and K % 8 == 0 and all(n % 8 == 0 for n in Ns)
 
@@ -518,7 +529,7 @@ class _LinearGroup(torch.autograd.Function):
             else:
                 dws = [torch.mm(d.t(), x2) for d in dys]
             dws = [g if nw else None for g, nw in zip(dws, need_w)]
-        dbs = [d.sum(0) if (hb and ctx.needs_input_grad[4 + n + i]) else None
+        dbs = [column_sum(d) if (hb and ctx.needs_input_grad[4 + n + i]) else None
                for i, (d, hb) in enumerate(zip(dys, ctx.has_bias))]
         return (dx, None, None, None, *dws, *dbs)
 

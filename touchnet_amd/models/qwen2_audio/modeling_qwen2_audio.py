@@ -92,7 +92,8 @@ class EncoderAttention(nn.Module):
         k = k.view(B, T, self.num_heads, self.head_dim)
         v = v.view(B, T, self.num_heads, self.head_dim)
         a = ops().packed_attention(q, k, v, mask, self.head_dim ** -0.5)
-        return self.out_proj(a.view(B, T, C))
+        return ops().linear_group(a.view(B, T, C), [(self.out_proj.weight, self.out_proj.bias)], wgrad="nt",
+                                  dgrad_tn=False)[0]
 
 
 class EncoderLayer(nn.Module):
@@ -111,7 +112,8 @@ class EncoderLayer(nn.Module):
             x, residual = self.self_attn_layer_norm(delta, residual)
         a = self.self_attn(x, mask)
         x, residual = self.final_layer_norm(a, residual)
-        return self.fc2(ops().gelu(self.fc1(x))), residual
+        lin = lambda t, m: ops().linear_group(t, [(m.weight, m.bias)], wgrad="nt", dgrad_tn=False)[0]   # HIP bias grad
+        return lin(ops().gelu(lin(x, self.fc1)), self.fc2), residual
 
 
 class Qwen2AudioEncoder(nn.Module):
