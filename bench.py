@@ -272,6 +272,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-rooflines", action="store_true")
     ap.add_argument("--unfused-ce", action="store_true")
+    ap.add_argument("--compact-lm-head", action="store_true",
+                    help="opt-in: lm_head + CE only on labelled positions (exact; one host sync per step)")
     ap.add_argument("--no-gemm-tuning", action="store_true", help="library-default GEMM algorithm selection")
     args = ap.parse_args()
 
@@ -293,6 +295,7 @@ def main():
 
     wl = Workload(args.workload, device, rank, args.batch, args.seqlen)
     wl.job.training_enable_fused_ce = not args.unfused_ce
+    wl.job.training_ce_compact_rows = args.compact_lm_head
     trainer = Trainer(wl.job, wl.model_config, device, dp_mesh=mesh)
 
     def step():
@@ -338,6 +341,7 @@ def main():
                        "seq_len": wl.T, "parallelism": f"fsdp2-dp{world}" if (world > 1 or forced) else "single-gpu",
                        "params": trainer.num_params, "flop_per_token": fpt,
                        "fused_linear_ce": wl.job.training_enable_fused_ce,
+                       "lm_head_rows": "labelled only (opt-in)" if args.compact_lm_head else "all B*T positions",
                        "gemm_algorithms": "TunableOp replay (touchnet_amd/tuning)" if tuned else "library default"},
             "step_mfu": round(mfu, 4),
             "mfu_convention": "6*N_wo_emb + 12*L*H*Dh*T per token (touchnet/models/*/__init__.py), no causal/packing "

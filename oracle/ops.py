@@ -90,7 +90,7 @@ def packed_cross_entropy(pred, labels, sentence_lens, num_sentence, ignore_index
 
 
 def fused_linear_cross_entropy(hidden, weight, labels, sentence_lens, num_sentence, ignore_index=-100,
-                               chunk_tokens=16384):
+                               chunk_tokens=16384, compact=False):
     return packed_cross_entropy(torch.nn.functional.linear(hidden, weight), labels, sentence_lens, num_sentence,
                                 ignore_index)
 

@@ -437,6 +437,17 @@ def test_ce_full_vocab_properties():
     assert float(l1) == pytest.approx(float(l2), rel=1e-5) and float(st1[2]) == float(st2[2])
     _close(hg.grad, h2.grad, 2e-4, 2e-2, "dh")
     _close(wg.grad, w2.grad, 2e-4, 3e-2, "dW")
+    # opt-in row compaction (lm_head only on labelled positions): same loss, stats and gradients; ignored rows get 0
+    h3, w3 = h.clone().requires_grad_(), w.clone().requires_grad_()
+    l3, st3 = F.fused_linear_cross_entropy(h3, w3, labels, sl, 9, -100, 32, compact=True)
+    l3.backward()
+    assert float(l3) == pytest.approx(float(l1), rel=1e-6) and torch.allclose(st3, st1, rtol=1e-6, atol=0)
+    _close(h3.grad, hg.grad, 1e-3, 1e-2, "dh compact")           # (different chunking -> summation order: bf16 ulps)
+    _close(w3.grad, wg.grad, 1e-3, 1e-2, "dW compact")
+    assert float(h3.grad[0, ::3].abs().max()) == 0.0
+    none = torch.full_like(labels, -100)
+    l4, _ = F.fused_linear_cross_entropy(h.clone().requires_grad_(), w, none, sl, 9, -100, 32, compact=True)
+    assert float(l4) == 0.0
 
 
 @pytest.mark.parametrize("cp,T,Nh,Nkv,D,maxdoc", [(2, 1024, 4, 2, 128, 300), (4, 2048, 2, 2, 64, 2048),

@@ -39,6 +39,7 @@ class TrainConfig:
     training_fsdp_reshard_after_forward: str = "never"
     training_enable_fused_ce: bool = True      # role of `training_enable_liger_kernel`'s fused-linear-CE branch
     training_ce_chunk_tokens: int = 16384
+    training_ce_compact_rows: bool = False     # opt-in: lm_head only on labelled positions (one host sync per step)
     lr_scheduler_lr: float = 8e-4
     lr_scheduler_warmup_steps: int = 2000
     lr_scheduler_steps: int = 100000
@@ -123,7 +124,8 @@ class Trainer:
         data.pop("shift_labels", None)
         if self.job.training_enable_fused_ce:                       # `pred.loss` branch (train.py:443-445)
             pred = self.model(**data, labels=labels, sentence_lens=sl, num_sentence=ns,
-                              ce_chunk_tokens=self.job.training_ce_chunk_tokens)
+                              ce_chunk_tokens=self.job.training_ce_chunk_tokens,
+                              ce_compact=self.job.training_ce_compact_rows)
             return pred.loss, pred.loss_per_token, pred.acc
         pred = self.model(**data)
         loss, per_token = self.spec.loss_fn(pred.logits, labels, sl, ns)

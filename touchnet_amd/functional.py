@@ -392,12 +392,25 @@ class _FusedLinearCE(torch.autograd.Function):
     gradient in backward."""
 
     @staticmethod
-    def forward(ctx, hidden, weight, labels, sentence_lens, num_sentence, ignore_index, chunk):
+    def forward(ctx, hidden, weight, labels, sentence_lens, num_sentence, ignore_index, chunk, compact=False):
         H = hidden.shape[-1]
         h2 = hidden.reshape(-1, H)
-        n, V = h2.shape[0], weight.shape[0]
         lab = labels.reshape(-1).to(torch.int64).contiguous()
         sl = sentence_lens.reshape(-1).to(torch.int64).contiguous()
+        rows = None
+        if compact:
+            # OPT-IN: positions whose label is ignore_index contribute exactly 0 to the loss, to d(hidden) and to
+            # d(weight) — the CE kernels already never read their logits; with `compact` the lm_head GEMMs skip them
+            # too (ASR-SFT batches: >90 % of the positions are audio/prompt).  Same loss and gradients up to GEMM
+            # summation order.  Costs one host sync per step (the row count sizes the GEMM), hence not the default.
+            rows = torch.nonzero(lab != ignore_index).squeeze(1)
+            n_all = h2.shape[0]
+            h2, lab, sl = h2.index_select(0, rows), lab.index_select(0, rows), sl.index_select(0, rows)
+            if rows.numel() == 0:                              # nothing labelled: zero loss, zero gradients
+                rows = None
+                h2, lab, sl = hidden.reshape(-1, H), labels.reshape(-1).to(torch.int64).contiguous(), \
+                    sentence_lens.reshape(-1).to(torch.int64).contiguous()
+        n, V = h2.shape[0], weight.shape[0]
         ns = _num_sentence_dev(num_sentence, hidden.device)
         one = torch.ones(1, dtype=torch.float32, device=hidden.device)
         nll = torch.empty(n, dtype=torch.float32, device=hidden.device)
@@ -423,6 +436,8 @@ class _FusedLinearCE(torch.autograd.Function):
             del logits
         _C.check(lib.tn_ce_reduce(p(nll), p(hit), p(lab), p(sl), p(ns), p(out), n, int(ignore_index), st()),
                  "tn_ce_reduce")
+        if rows is not None:                                   # scatter d(hidden) back; ignored rows stay 0
+            dh = torch.zeros(n_all, H, dtype=dh.dtype, device=dh.device).index_copy_(0, rows, dh)
         ctx.save_for_backward(dh, dw)
         ctx.hshape, ctx.wdtype = hidden.shape, weight.dtype
         ctx.mark_non_differentiable(out)
@@ -432,13 +447,15 @@ class _FusedLinearCE(torch.autograd.Function):
     def backward(ctx, g_loss, _g):
         dh, dw = ctx.saved_tensors
         g = g_loss.to(torch.float32)
-        return (dh * g.to(dh.dtype)).view(ctx.hshape), (dw * g).to(ctx.wdtype), None, None, None, None, None
+        return (dh * g.to(dh.dtype)).view(ctx.hshape), (dw * g).to(ctx.wdtype), None, None, None, None, None, None
 
 
 def fused_linear_cross_entropy(hidden, weight, labels, sentence_lens, num_sentence, ignore_index=-100,
-                               chunk_tokens=16384):
-    """Returns ``(loss_per_sample [differentiable], stats)`` like packed_cross_entropy, from hidden states."""
-    return _FusedLinearCE.apply(hidden, weight, labels, sentence_lens, num_sentence, ignore_index, chunk_tokens)
+                               chunk_tokens=16384, compact=False):
+    """Returns ``(loss_per_sample [differentiable], stats)`` like packed_cross_entropy, from hidden states.
+    ``compact=True``: run lm_head only on the labelled positions (see _FusedLinearCE.forward)."""
+    return _FusedLinearCE.apply(hidden, weight, labels, sentence_lens, num_sentence, ignore_index, chunk_tokens,
+                                compact)
 
 
 # ------------------------------------------------------------------------------------ linear layers

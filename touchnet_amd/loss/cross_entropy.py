@@ -35,9 +35,9 @@ def cached_accuracy(pred, labels):
 
 
 def fused_linear_cross_entropy(hidden, weight, labels, sentence_lens, num_sentence, ignore_index: int = -100,
-                               chunk_tokens: int = 16384):
+                               chunk_tokens: int = 16384, compact: bool = False):
     """(loss_per_sample, loss_per_token, accuracy) straight from the final hidden states: lm_head GEMM +
     packed CE chunked over tokens (touchnet_amd.functional.fused_linear_cross_entropy)."""
     loss, stats = ops().fused_linear_cross_entropy(hidden, weight, labels, sentence_lens, num_sentence,
-                                                   ignore_index, chunk_tokens)
+                                                   ignore_index, chunk_tokens, compact)
     return loss, stats[1], stats[2]

@@ -183,7 +183,7 @@ class PackedCausalLM(nn.Module):
 
     def forward(self, input_ids=None, inputs_embeds=None, position_ids=None, attention_mask=None,
                 labels=None, sentence_lens=None, num_sentence=None, ce_chunk_tokens: int = 16384,
-                context_parallel=None, **unused):
+                ce_compact: bool = False, context_parallel=None, **unused):
         """Without `labels`: returns `.logits` (the reference's default path, loss_fn runs in the trainer).
         With `labels` (+ `sentence_lens`, `num_sentence`): lm_head and the packed CE run fused INSIDE the
         model — the role liger's fused-linear-CE plays in the reference (`pred.loss`, train.py:443-445), but
@@ -195,5 +195,5 @@ class PackedCausalLM(nn.Module):
             return SimpleNamespace(logits=self.lm_head(h), loss=None)
         from touchnet_amd.loss.cross_entropy import fused_linear_cross_entropy
         loss, per_token, acc = fused_linear_cross_entropy(h, self.lm_head.weight, labels, sentence_lens, num_sentence,
-                                                          chunk_tokens=ce_chunk_tokens)
+                                                          chunk_tokens=ce_chunk_tokens, compact=ce_compact)
         return SimpleNamespace(logits=None, loss=loss, loss_per_token=per_token, acc=acc)
