@@ -18,12 +18,21 @@ import torch  # noqa: E402
 
 bf, dev = torch.bfloat16, "cuda"
 M = 16384
-for N, K in ((4096, 4096), (12288, 4096), (22016, 4096)):
+import time  # noqa: E402
+
+SHAPES = [tuple(int(v) for v in a.split('x')) for a in sys.argv[1:]] or [(4096, 4096), (12288, 4096), (22016, 4096)]
+for N, K in SHAPES:
     dyt = torch.randn(N, M, dtype=bf, device=dev)
     xt = torch.randn(K, M, dtype=bf, device=dev)
     torch.mm(dyt, xt.t())
     torch.cuda.synchronize()
-    print(f"# tuned dW[{N},{K}] over M={M}", file=sys.stderr, flush=True)
+    t0 = time.perf_counter()
+    for _ in range(20):
+        torch.mm(dyt, xt.t())
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / 20 * 1e3
+    print(f"# tuned dW[{N},{K}] over M={M}: {ms:.3f} ms sustained = {2.0 * M * N * K / ms / 1e9:.0f} TFLOP/s", file=sys.stderr,
+          flush=True)
 import torch.cuda.tunable as tunable  # noqa: E402
 
 old = set(open(gemm_tuning.RESULTS).read().splitlines())

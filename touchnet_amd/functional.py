@@ -497,7 +497,7 @@ class _LinearGroup(torch.autograd.Function):
     The INPUT gradient dX = sum_i dY_i W_i contracts over W_i's slow dimension; with W_i transposed first (33-90 MB,
     ~0.01-0.04 ms) the same hipBLASLt GEMM runs 8-19 % faster (scripts/gemm_layout_bench.py: 4096^2 0.50 -> 0.43 ms,
     11008 -> 4096 1.11 -> 0.93 ms); it accumulates over the group inside the GEMM epilogue (addmm, beta = 1).
-    ``wgrad``: "tn" (above) | "nt" autograd's layout per layer (down_proj: no gain at N = 4096, K = 11008) |
+    ``wgrad``: "tn" (above) | "nt" autograd's layout per layer |
     "nt_fused" one NT GEMM over the column-concatenated dY (the 1280-wide audio tower: three 1280 x 1280 outputs
     are 25 tiles each, 351 TFLOP/s; fused 781 TFLOP/s, while TN brings nothing at that width).
     ``dgrad_tn=False`` keeps W as stored for the input gradient (no gain at 1280 x 1280)."""

@@ -89,8 +89,9 @@ class MLP(nn.Module):
 
     def forward(self, x):
         gate, up = ops().linear_group(x, [(self.gate_proj.weight, None), (self.up_proj.weight, None)])
-        # (down_proj, 11008 -> 4096, gains nothing from the transposed weight-gradient layout)
-        return ops().linear_group(ops().swiglu(gate, up), [(self.down_proj.weight, None)], wgrad="nt")[0]
+        # (down_proj's transposed-layout weight gradient only pays with the tuned algorithm of tuning/tunableop_gfx950.csv:
+        #  1.08 ms + 0.20 ms of transposes vs 1.53 ms; library default 1.45 + 0.20)
+        return ops().linear_group(ops().swiglu(gate, up), [(self.down_proj.weight, None)])[0]
 
 
 class DecoderLayer(nn.Module):
