@@ -28,6 +28,11 @@ def enable(max_devices: int = 8) -> bool:
         shutil.copy(RESULTS, os.path.join(d, f"results{i}.csv"))
     os.environ["PYTORCH_TUNABLEOP_ENABLED"] = "1"
     os.environ["PYTORCH_TUNABLEOP_TUNING"] = "0"
-    os.environ["PYTORCH_TUNABLEOP_RECORD_UNTUNED"] = "0"
+    # TN_RECORD_UNTUNED=<file stem>: list the GEMMs of a run that have no entry yet (then tune them offline with
+    # torch.cuda.tunable.tune_gemm_in_file / scripts/tune_new_gemms.py and append the lines to RESULTS)
+    rec = os.environ.get("TN_RECORD_UNTUNED")
+    os.environ["PYTORCH_TUNABLEOP_RECORD_UNTUNED"] = "1" if rec else "0"
+    if rec:
+        os.environ["PYTORCH_TUNABLEOP_UNTUNED_FILENAME"] = rec
     os.environ["PYTORCH_TUNABLEOP_FILENAME"] = os.path.join(d, "results.csv")
     return True
