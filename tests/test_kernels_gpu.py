@@ -620,3 +620,46 @@ def test_pcm16_to_float_exact_and_frontend_equivalence(golden):
     b = next(stages.audio_compute_log_mel_spectrogram(
         iter([{"sample_rate": 16000, "waveform": pcm.to(torch.float32) / 32768.0}]), cfg))
     assert torch.equal(a["audiofeat"], b["audiofeat"])
+
+
+@pytest.mark.parametrize("D,Nh,Nkv", [(128, 2, 2), (64, 4, 2)])
+def test_attention_long_sequence_multi_chunk_tile_list(D, Nh, Nkv):
+    """T = 32768 (512 KV tiles): the forward walks its LDS tile list in several chunks (192 tiles each in the default
+    schedule).  One 30000-token document followed by short ones; checked on query slices that sit before, on and after
+    the chunk boundaries against a direct fp32 evaluation of the same bf16 inputs, plus the packed == per-document
+    property on a short trailing document, run-to-run bit identity and the dQ rows of the same slices."""
+    F = _f()
+    B, T = 1, 32768
+    doc = torch.zeros(B, T, dtype=torch.int32)
+    doc[0, :30000] = 1
+    doc[0, 30000:31000] = 2
+    doc[0, 31000:32700] = 3                     # 68 pad positions at the end
+    g = torch.Generator().manual_seed(21)
+    q, k, v, do = [torch.randn(B, T, n, D, generator=g).bfloat16().to(DEV) for n in (Nh, Nkv, Nkv, Nh)]
+    mask = F.build_packed_mask(doc.to(DEV))
+    qg, kg, vg = [t.clone().requires_grad_() for t in (q, k, v)]
+    out = F.packed_attention(qg, kg, vg, mask)
+    out.backward(do)
+    assert torch.equal(out, F.packed_attention(q, k, v, mask))
+    G = Nh // Nkv
+    kf, vf = k.float().repeat_interleave(G, dim=2), v.float().repeat_interleave(G, dim=2)
+    ids = doc[0].to(DEV)
+    for s in (0, 12224, 12288 + 64, 24576 - 32, 29900, 30950, 32640):       # around multiples of 192 tiles = 12288 tokens
+        rows = torch.arange(s, min(s + 96, T), device=DEV)
+        sc = torch.einsum("rhd,thd->hrt", q[0, rows].float(), kf[0]) * D ** -0.5
+        allow = ((ids[None, :] == ids[rows][:, None]) & (ids[rows][:, None] > 0)
+                 & (torch.arange(T, device=DEV)[None, :] <= rows[:, None]))
+        sc = sc.masked_fill(~allow[None], float("-inf"))
+        p = torch.softmax(sc, dim=-1)
+        p = torch.nan_to_num(p, nan=0.0)                                      # fully masked (pad) rows -> 0
+        ref = torch.einsum("hrt,thd->rhd", p, vf[0])
+        _close(out[0, rows], ref, 1e-2, 1e-2, f"O rows {s}..")
+        dp = torch.einsum("rhd,thd->hrt", do[0, rows].float(), vf[0])
+        delta = (do[0, rows].float() * ref).sum(-1).transpose(0, 1)          # [h, r]
+        ds = p * (dp - delta[..., None])
+        dq_ref = torch.einsum("hrt,thd->rhd", ds, kf[0]) * D ** -0.5
+        _close(qg.grad[0, rows], dq_ref, 3e-2, 3e-2, f"dQ rows {s}..")
+    q1, k1, v1 = [t[:, 30000:31000].clone().requires_grad_() for t in (q, k, v)]
+    o1 = F.packed_attention(q1, k1, v1, F.causal_mask(1, 1000, DEV))
+    _close(out[:, 30000:31000], o1, 1e-2, 1e-2, "short document after the long one")
+    assert float(out[0, 32700:].float().abs().max()) == 0.0
