@@ -49,6 +49,11 @@ int tn_layernorm_bwd(const void* dy, const void* h, const void* w, const float* 
 int tn_swiglu_fwd(const void* gate, const void* up, void* out, long long n, int dtype, void* stream);
 int tn_swiglu_bwd(const void* dout, const void* gate, const void* up, void* dgate, void* dup, long long n,
                   int dtype, void* stream);
+/* bf16 variants that ALSO write the transposed tensors the MLP's weight-gradient GEMMs consume (rows, cols multiples
+ * of 8): out_t [cols, rows] = out^T;  dgu_t [2*cols, rows] = [dgate^T ; dup^T].  Same arithmetic as the two above. */
+int tn_swiglu_fwd_t(const void* gate, const void* up, void* out, void* out_t, int rows, int cols, void* stream);
+int tn_swiglu_bwd_t(const void* dout, const void* gate, const void* up, void* dgate, void* dup, void* dgu_t, int rows,
+                    int cols, void* stream);
 int tn_gelu_fwd(const void* x, void* out, long long n, int dtype, void* stream);
 int tn_gelu_bwd(const void* dout, const void* x, void* dx, long long n, int dtype, void* stream);
 

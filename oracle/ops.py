@@ -30,6 +30,12 @@ def layer_norm(x, weight, bias, eps=1e-5, residual=None):
 swiglu = _nn.swiglu
 
 
+def swiglu_mlp(x, w_gate, w_up, w_down):
+    """mirror of touchnet_amd.functional.swiglu_mlp (modeling_llama.py:174-176)"""
+    lin = torch.nn.functional.linear
+    return lin(swiglu(lin(x, w_gate), lin(x, w_up)), w_down)
+
+
 def pcm16_to_float(pcm):
     """datapipe.py:164"""
     return pcm.to(torch.float32) / 32768.0

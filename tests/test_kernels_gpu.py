@@ -500,6 +500,49 @@ def test_transpose_bf16_bit_exact(R, C):
         F.transpose_2d(x[:, :C - 1])                                           # not a multiple of 8 -> -22, loud
 
 
+@pytest.mark.parametrize("M,H,I", [(256, 128, 512), (1000, 256, 688), (4104, 512, 1376)])
+def test_swiglu_mlp_fused_node(M, H, I):
+    """The fused MLP node: (1) its SwiGLU kernels are bit-identical to the plain ones and their transposed outputs
+    are exact transposes; (2) output and all four gradients against autograd over nn.Linear / silu in fp32 on the same
+    bf16-rounded inputs."""
+    F = _f()
+    from touchnet_amd import _C
+    g = torch.Generator(device="cpu").manual_seed(M)
+    gate = torch.randn(M, I, generator=g).bfloat16().to(DEV)
+    up = torch.randn(M, I, generator=g).bfloat16().to(DEV)
+    dact = torch.randn(M, I, generator=g).bfloat16().to(DEV)
+    act, act_t = torch.empty_like(gate), torch.empty(I, M, dtype=torch.bfloat16, device=DEV)
+    _C.check(_C.lib().tn_swiglu_fwd_t(_C.ptr(gate), _C.ptr(up), _C.ptr(act), _C.ptr(act_t), M, I, _C.stream()), "fwd_t")
+    gg, uu = gate.clone().requires_grad_(), up.clone().requires_grad_()
+    ref = F.swiglu(gg, uu)
+    ref.backward(dact)
+    assert torch.equal(act, ref) and torch.equal(act_t, ref.t())
+    dg, du = torch.empty_like(gate), torch.empty_like(up)
+    dgu_t = torch.empty(2 * I, M, dtype=torch.bfloat16, device=DEV)
+    _C.check(_C.lib().tn_swiglu_bwd_t(_C.ptr(dact), _C.ptr(gate), _C.ptr(up), _C.ptr(dg), _C.ptr(du), _C.ptr(dgu_t), M, I,
+                                      _C.stream()), "bwd_t")
+    assert torch.equal(dg, gg.grad) and torch.equal(du, uu.grad)
+    assert torch.equal(dgu_t[:I], dg.t()) and torch.equal(dgu_t[I:], du.t())
+
+    x = (torch.randn(2, M // 2, H, generator=g) * 0.5).bfloat16()
+    ws = [(torch.randn(n, k, generator=g) * k ** -0.5).bfloat16() for n, k in ((I, H), (I, H), (H, I))]
+    dy = torch.randn(2, M // 2, H, generator=g).bfloat16()
+
+    def run(dev, dt, fn):
+        xx = x.to(dev, dt).requires_grad_()
+        ww = [w.to(dev, dt).requires_grad_() for w in ws]
+        y = fn(xx, *ww)
+        y.backward(dy.to(dev, dt))
+        return [y, xx.grad] + [w.grad for w in ww]
+
+    lin = torch.nn.functional.linear
+    want = run("cpu", torch.float32, lambda xx, a, b, c: lin(torch.nn.functional.silu(lin(xx, a)) * lin(xx, b), c))
+    got = run(DEV, torch.bfloat16, F.swiglu_mlp)
+    for name, a, b in zip(("y", "dx", "dWgate", "dWup", "dWdown"), got, want):
+        assert a.shape == b.shape
+        torch.testing.assert_close(a.float().cpu(), b, rtol=3e-2, atol=3e-2 * float(b.abs().max()), msg=lambda m: f"{name}: {m}")
+
+
 @pytest.mark.parametrize("R,C", [(7, 8), (64, 1280), (30000, 1280), (4097, 5120), (16384, 4096)])
 def test_column_sum_bias_gradient(R, C):
     """tn_colsum_bf16 vs an fp64 column sum of the same bf16 values: fp32 accumulation, one bf16 rounding; also on a

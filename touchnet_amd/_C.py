@@ -50,6 +50,8 @@ PROTOTYPES = {
     "tn_sumsq": [_vp, _vp, _vp, _ll, _i, _vp],
     "tn_adamw_step": [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _f, _f, _f, _f, _i, _vp],
     "tn_transpose_bf16": [_vp, _vp, _i, _i, _ll, _ll, _vp],
+    "tn_swiglu_fwd_t": [_vp, _vp, _vp, _vp, _i, _i, _vp],
+    "tn_swiglu_bwd_t": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "tn_colsum_workspace_floats": [_i, _i],
     "tn_colsum_bf16": [_vp, _vp, _vp, _i, _i, _ll, _vp],
     "tn_pcm16_to_f32": [_vp, _vp, _ll, _vp],

@@ -462,6 +462,94 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const T* __restrict__ d
   }
 }
 
+// ---- SwiGLU with transposed second outputs (bf16): the MLP's weight-gradient GEMMs want act^T, d_gate^T and d_up^T
+// (forward-layout GEMMs).  Writing them here costs one extra store of each tensor; the standalone
+// transpose pass costs a load and a store.  A thread owns an 8 x 8 block (same tiling as transpose.hip): 16-byte row
+// loads (8 adjacent lanes = one 128-byte line), v_perm register transposes, 16-byte stores both ways.
+// Arithmetic identical to swiglu_fwd_kernel / swiglu_bwd_kernel (silu rounded to bf16 before the product).
+__device__ __forceinline__ void transpose8x8_store(const uint4 (&in)[8], bf16_t* dst, long long dst_ld) {
+  const uint32_t w[8][4] = {{in[0].x, in[0].y, in[0].z, in[0].w}, {in[1].x, in[1].y, in[1].z, in[1].w},
+                            {in[2].x, in[2].y, in[2].z, in[2].w}, {in[3].x, in[3].y, in[3].z, in[3].w},
+                            {in[4].x, in[4].y, in[4].z, in[4].w}, {in[5].x, in[5].y, in[5].z, in[5].w},
+                            {in[6].x, in[6].y, in[6].z, in[6].w}, {in[7].x, in[7].y, in[7].z, in[7].w}};
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const int wi = c >> 1;
+    const uint32_t sel = (c & 1) ? 0x07060302u : 0x05040100u;
+    uint4 o;
+    o.x = __builtin_amdgcn_perm(w[1][wi], w[0][wi], sel);
+    o.y = __builtin_amdgcn_perm(w[3][wi], w[2][wi], sel);
+    o.z = __builtin_amdgcn_perm(w[5][wi], w[4][wi], sel);
+    o.w = __builtin_amdgcn_perm(w[7][wi], w[6][wi], sel);
+    *reinterpret_cast<uint4*>(dst + (long long)c * dst_ld) = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void swiglu_fwd_t_kernel(const bf16_t* __restrict__ gate, const bf16_t* __restrict__ up,
+                                                           bf16_t* __restrict__ out, bf16_t* __restrict__ out_t, int rows,
+                                                           int cols) {
+  const int cx = threadIdx.x & 7, rb = threadIdx.x >> 3;
+  const int c0 = (blockIdx.x * 8 + cx) * 8, r0 = (blockIdx.y * 32 + rb) * 8;
+  if (c0 >= cols || r0 >= rows) return;
+  uint4 o[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    Vec16<bf16_t> g, u, a;
+    float gf[8], uf[8];
+    g.load(gate + (size_t)(r0 + i) * cols + c0);
+    u.load(up + (size_t)(r0 + i) * cols + c0);
+    g.unpack(gf);
+    u.unpack(uf);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) gf[j] = gf[j] * sigmoidf_(gf[j]);
+    a.pack(gf);
+    a.unpack(gf);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) gf[j] *= uf[j];
+    a.pack(gf);
+    a.store(out + (size_t)(r0 + i) * cols + c0);
+    o[i] = a.raw;
+  }
+  transpose8x8_store(o, out_t + (size_t)c0 * rows + r0, rows);
+}
+
+__global__ __launch_bounds__(256) void swiglu_bwd_t_kernel(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ gate,
+                                                           const bf16_t* __restrict__ up, bf16_t* __restrict__ dgate,
+                                                           bf16_t* __restrict__ dup, bf16_t* __restrict__ dgu_t, int rows,
+                                                           int cols) {
+  const int cx = threadIdx.x & 7, rb = threadIdx.x >> 3;
+  const int c0 = (blockIdx.x * 8 + cx) * 8, r0 = (blockIdx.y * 32 + rb) * 8;
+  if (c0 >= cols || r0 >= rows) return;
+  uint4 og[8], ou[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    Vec16<bf16_t> d, g, u, a, b;
+    float df[8], gf[8], uf[8], dg[8], du[8];
+    const size_t off = (size_t)(r0 + i) * cols + c0;
+    d.load(dout + off);
+    g.load(gate + off);
+    u.load(up + off);
+    d.unpack(df);
+    g.unpack(gf);
+    u.unpack(uf);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float s = sigmoidf_(gf[j]);
+      const float silu = gf[j] * s;
+      du[j] = df[j] * silu;
+      dg[j] = df[j] * uf[j] * (s + silu * (1.f - s));
+    }
+    a.pack(dg);
+    b.pack(du);
+    a.store(dgate + off);
+    b.store(dup + off);
+    og[i] = a.raw;
+    ou[i] = b.raw;
+  }
+  transpose8x8_store(og, dgu_t + (size_t)c0 * rows + r0, rows);                    // rows [0, cols): d_gate^T
+  transpose8x8_store(ou, dgu_t + (size_t)(cols + c0) * rows + r0, rows);           // rows [cols, 2 cols): d_up^T
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void gelu_fwd_kernel(const T* __restrict__ x, T* __restrict__ out, size_t nvec) {
   constexpr int N = Vec16<T>::N;
@@ -737,6 +825,26 @@ int tn_swiglu_bwd(const void* dout, const void* gate, const void* up, void* dgat
     TN_LAUNCH_CHECK();
     return TN_OK;
   });
+}
+
+// bf16 only; rows, cols multiples of 8; out_t [cols, rows]; dgu_t [2 cols, rows] = [d_gate^T ; d_up^T]
+int tn_swiglu_fwd_t(const void* gate, const void* up, void* out, void* out_t, int rows, int cols, void* stream) {
+  if (rows <= 0 || cols <= 0 || (rows | cols) & 7) return TN_EINVAL;
+  dim3 grid((cols + 63) / 64, (rows + 255) / 256);
+  hipLaunchKernelGGL(swiglu_fwd_t_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)gate,
+                     (const bf16_t*)up, (bf16_t*)out, (bf16_t*)out_t, rows, cols);
+  TN_LAUNCH_CHECK();
+  return TN_OK;
+}
+
+int tn_swiglu_bwd_t(const void* dout, const void* gate, const void* up, void* dgate, void* dup, void* dgu_t, int rows,
+                    int cols, void* stream) {
+  if (rows <= 0 || cols <= 0 || (rows | cols) & 7) return TN_EINVAL;
+  dim3 grid((cols + 63) / 64, (rows + 255) / 256);
+  hipLaunchKernelGGL(swiglu_bwd_t_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dout,
+                     (const bf16_t*)gate, (const bf16_t*)up, (bf16_t*)dgate, (bf16_t*)dup, (bf16_t*)dgu_t, rows, cols);
+  TN_LAUNCH_CHECK();
+  return TN_OK;
 }
 
 int tn_gelu_fwd(const void* x, void* out, long long n, int dtype, void* stream) {

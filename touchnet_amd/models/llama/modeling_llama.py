@@ -88,10 +88,8 @@ class MLP(nn.Module):
         self.down_proj = nn.Linear(I, H, bias=False)
 
     def forward(self, x):
-        gate, up = ops().linear_group(x, [(self.gate_proj.weight, None), (self.up_proj.weight, None)])
-        # (down_proj's transposed-layout weight gradient only pays with the tuned algorithm of tuning/tunableop_gfx950.csv:
-        #  1.08 ms + 0.20 ms of transposes vs 1.53 ms; library default 1.45 + 0.20)
-        return ops().linear_group(ops().swiglu(gate, up), [(self.down_proj.weight, None)])[0]
+        # one autograd node: the SwiGLU kernels also emit the transposed operands of the weight-gradient GEMMs
+        return ops().swiglu_mlp(x, self.gate_proj.weight, self.up_proj.weight, self.down_proj.weight)
 
 
 class DecoderLayer(nn.Module):
