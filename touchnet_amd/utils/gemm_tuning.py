@@ -27,7 +27,16 @@ def enable(max_devices: int = 8) -> bool:
     for i in range(max_devices):                      # TunableOp appends the device ordinal to the file stem
         shutil.copy(RESULTS, os.path.join(d, f"results{i}.csv"))
     os.environ["PYTORCH_TUNABLEOP_ENABLED"] = "1"
-    os.environ["PYTORCH_TUNABLEOP_TUNING"] = "0"
+    # TN_TUNE_NEW=1: tune the shapes of this run that have no entry yet (entries already in RESULTS are kept as they
+    # are); the merged table is written to $PYTORCH_TUNABLEOP_FILENAME's directory at exit -> copy the new lines over
+    os.environ["PYTORCH_TUNABLEOP_TUNING"] = "1" if os.environ.get("TN_TUNE_NEW") == "1" else "0"
+    if os.environ.get("TN_TUNE_NEW") == "1":
+        os.environ.setdefault("PYTORCH_TUNABLEOP_MAX_TUNING_DURATION_MS", "30")
+        os.environ.setdefault("PYTORCH_TUNABLEOP_MAX_WARMUP_DURATION_MS", "5")
+        d = os.environ.get("TN_TUNE_DIR") or d
+        os.makedirs(d, exist_ok=True)
+        for i in range(max_devices):
+            shutil.copy(RESULTS, os.path.join(d, f"results{i}.csv"))
     # TN_RECORD_UNTUNED=<file stem>: list the GEMMs of a run that have no entry yet (then tune them offline with
     # torch.cuda.tunable.tune_gemm_in_file / scripts/tune_new_gemms.py and append the lines to RESULTS)
     rec = os.environ.get("TN_RECORD_UNTUNED")
