@@ -10,7 +10,6 @@ Qwen2-Audio-7B (sustained GEMM rate is power-limited, so the in-situ gain is far
 """
 from __future__ import annotations
 
-import atexit
 import os
 import shutil
 import tempfile
@@ -25,7 +24,6 @@ def enable(max_devices: int = 8) -> bool:
     if not os.path.exists(RESULTS) or "PYTORCH_TUNABLEOP_ENABLED" in os.environ:
         return False
     d = tempfile.mkdtemp(prefix="tn_tunableop_")
-    atexit.register(shutil.rmtree, d, ignore_errors=True)
     for i in range(max_devices):                      # TunableOp appends the device ordinal to the file stem
         shutil.copy(RESULTS, os.path.join(d, f"results{i}.csv"))
     os.environ["PYTORCH_TUNABLEOP_ENABLED"] = "1"
