@@ -86,3 +86,49 @@ def test_batch_audio_packed(golden, case):
             assert b[k].dtype == (torch.float32 if k == "input_features" else torch.int64)
             np.testing.assert_array_equal(b[k].numpy(), g[f"pack/{case}/{i}/{k}"], err_msg=f"{case} b{i} {k}")
         assert b["num_sentence"] == int(g[f"pack/{case}/{i}/num_sentence"])
+
+
+# ------------------------------------------------------------------ randomised: product packers == oracle restatement
+def _eq_batches(got, want, keys):
+    assert len(got) == len(want)
+    for i, (a, b) in enumerate(zip(got, want)):
+        for k in keys:
+            av = a[k].numpy() if isinstance(a[k], torch.Tensor) else a[k]
+            np.testing.assert_array_equal(av, b[k], err_msg=f"batch {i} {k}")
+        assert a["num_sentence"] == b["num_sentence"]
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_packers_equal_oracle_on_random_streams(seed):
+    """The vectorised product packers against the loop restatements of oracle/ (which the reference goldens pin) on
+    random streams: random B, T, drop_last, sentence / utterance lengths incl. ones that exactly fill a row, over-long
+    utterances (dropped by the audio packers) and streams that end on a full buffer."""
+    from oracle import packing as opk
+    from oracle import tokenizer as otok
+    from touchnet_amd.models.touch_audio import batch_audio_packed
+    rng = np.random.RandomState(100 + seed)
+    B, T = int(rng.randint(1, 5)), int(rng.choice([8, 17, 32, 64]))
+    drop = bool(rng.randint(2))
+    n = int(rng.randint(0, 40))
+    # text: sentence slots = len + 1 <= T (over-long text is filtered upstream of the packer)
+    sents = [[int(v) for v in rng.randint(3, 50, size=int(rng.randint(0, T)))] for _ in range(n)]
+    cfg = types.SimpleNamespace(dataset_batchsize=B, dataset_text_seqlen=T, dataset_audio_seqlen=T,
+                                audiofeat_num_mel_bins=3, audiofeat_stack_length=2, dataloader_drop_last_batch=drop)
+    ikeys = ("input_ids", "labels", "position_ids", "attention_mask", "sentence_lens")
+    _eq_batches(list(batch_text(({"input_ids": s} for s in sents), cfg, TOK)),
+                list(opk.batch_text(sents, B, T, TOK.bos, TOK.eos, TOK.pad, drop_last=drop)), ikeys)
+    # ASR pairs: audio frames + text, some segments longer than a row
+    pairs = []
+    for _ in range(n):
+        ta = int(rng.randint(1, T + 3))
+        pairs.append((rng.randn(ta, 6).astype(np.float32), [int(v) for v in rng.randint(3, 50, size=int(rng.randint(0, 6)))]))
+    got = list(batch_pairaudio_pairtext_packed(({"audiofeat": torch.from_numpy(f), "input_ids": s} for f, s in pairs),
+                                               cfg, TOK))
+    want = list(opk.batch_pairaudio_pairtext_packed(pairs, B, T, 6, TOK.bos, TOK.eos, TOK.pad, drop_last=drop))
+    _eq_batches(got, want, ikeys + ("input_features",))
+    # audio pretraining: frames only, labels from a (deterministic stand-in) tokenizer
+    tok = types.SimpleNamespace(tokenize=lambda f: [int(v) for v in (np.asarray(f)[:, 0] * 7).astype(np.int64) % 11])
+    feats = [f for f, _ in pairs]
+    got = list(batch_audio_packed(({"audiofeat": torch.from_numpy(f)} for f in feats), cfg, tok))
+    want = list(otok.batch_audio_packed(feats, B, T, 6, tok.tokenize, drop_last=drop))
+    _eq_batches(got, want, ("labels", "position_ids", "attention_mask", "sentence_lens", "input_features"))
