@@ -89,3 +89,10 @@ def test_product_ops_refuse_cpu_tensors():
     from touchnet_amd._C import KernelError
     with pytest.raises((KernelError, ImportError)):
         F.rms_norm(torch.randn(4, 64), torch.ones(64), 1e-5)
+    w = torch.randn(64, 64)
+    with pytest.raises((KernelError, ImportError)):
+        F.linear_group(torch.randn(8, 64), [(w, None)])
+    with pytest.raises((KernelError, ImportError)):
+        F.swiglu_mlp(torch.randn(8, 64), w, w, w)
+    with pytest.raises((KernelError, ImportError, RuntimeError)):
+        F.bestrq_tokenize(torch.randn(8, 16), torch.randn(16, 8), torch.randn(32, 8))

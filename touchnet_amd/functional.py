@@ -556,6 +556,8 @@ def linear_group(x, layers, wgrad: str = "tn", dgrad_tn: bool = True):
     """``layers``: list of (weight [N_i, K], bias [N_i] | None) sharing the input ``x`` -> list of outputs."""
     if wgrad not in ("tn", "nt", "nt_fused"):
         raise ValueError(f"linear_group: wgrad={wgrad!r}")
+    if not x.is_cuda:
+        raise _C.KernelError("linear_group: device tensors only (the product path has no CPU fallback)")
     ws = [w for w, _ in layers]
     bs = [b for _, b in layers]
     return list(_LinearGroup.apply(x, len(ws), wgrad, dgrad_tn, *ws, *bs))
@@ -617,8 +619,10 @@ _MLP_FUSED = os.environ.get("TN_MLP_FUSED", "1") != "0"       # (A/B switch for 
 def swiglu_mlp(x, w_gate, w_up, w_down):
     """Llama/Qwen2 MLP ``down(silu(gate(x)) * up(x))`` (bias-free).  bf16 device tensors with 8-aligned shapes take the
     fused node above; anything else composes the individual ops (same maths)."""
+    if not x.is_cuda:
+        raise _C.KernelError("swiglu_mlp: device tensors only (the product path has no CPU fallback)")
     M = x.numel() // x.shape[-1]
-    if (_MLP_FUSED and x.is_cuda and x.dtype == torch.bfloat16
+    if (_MLP_FUSED and x.dtype == torch.bfloat16
             and all(w.dtype == torch.bfloat16 for w in (w_gate, w_up, w_down))
             and _tn_ok(M, x.shape[-1], (w_gate.shape[0], w_down.shape[0]))):
         return _SwiGLUMLP.apply(x, w_gate, w_up, w_down)
