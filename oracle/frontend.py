@@ -9,9 +9,12 @@ Restates, in NumPy float32/float64 on the CPU,
     and the reference run on tests/assets/dataset/*.wav, see tests/golden/)
   * ``audio_compute_fbank``                 touchnet/data/functions.py:117-134
     -> torchaudio.compliance.kaldi.fbank (pyproject.toml `torchaudio>=2.7.0`, NOT
-    installed here, no golden vector in the reference): PARITY UNPINNED; follows the
-    published Kaldi compute-fbank-feats algorithm with torchaudio's defaults and the
-    reference's overrides (energy_floor=0.0, dither=cfg(0.0), input * 32768).
+    installed here, no golden vector in the reference): follows the published Kaldi
+    compute-fbank-feats algorithm with torchaudio's defaults and the reference's overrides
+    (energy_floor=0.0, dither=cfg(0.0), input * 32768).  NOT pinned against torchaudio
+    itself; pinned against an independent third-party implementation of the same function,
+    transformers.audio_utils' Kaldi-compatible fbank, on the reference's two test wavs
+    (tests/golden/kaldi_fbank_hf.npz, agreement 1.5e-4 on values in [-16, 24]).
 """
 from __future__ import annotations
 

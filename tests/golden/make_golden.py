@@ -349,6 +349,28 @@ def frontend_cases():
     save("logmel.npz", **out)
 
 
+# ------------------------------------------------------------------ Kaldi fbank: independent third-party pin
+def fbank_cases():
+    """torchaudio (what functions.py:117-134 calls) is not in this image.  `transformers.audio_utils` ships an
+    independent NumPy implementation written to match torchaudio.compliance.kaldi.fbank (the torchaudio-free fallback
+    of its feature extractors: povey window, remove_dc_offset, 0.97 pre-emphasis, Kaldi mel scale triangularised in
+    mel space, log of power with the fp32-epsilon floor).  Its output on the reference's two test wavs (int16-scale
+    input, as the reference feeds torchaudio) is stored as the fixture the oracle's restatement is held to."""
+    from transformers.audio_utils import mel_filter_bank, spectrogram, window_function
+    out = {}
+    wavdir = f"{R.REF}/tests/assets/dataset"
+    for i, fn in enumerate(sorted(f for f in os.listdir(wavdir) if f.endswith(".wav"))):
+        pcm, sr = read_wav(os.path.join(wavdir, fn))
+        assert sr == 16000
+        mel = mel_filter_bank(num_frequency_bins=257, num_mel_filters=80, min_frequency=20, max_frequency=8000,
+                              sampling_rate=16000, norm=None, mel_scale="kaldi", triangularize_in_mel_space=True)
+        fb = spectrogram(pcm.astype(np.float32), window_function(400, "povey", periodic=False), frame_length=400,
+                         hop_length=160, fft_length=512, power=2.0, center=False, preemphasis=0.97, mel_filters=mel,
+                         log_mel="log", mel_floor=1.192092955078125e-07, remove_dc_offset=True).T
+        out[f"wav{i}/fbank80"] = fb.astype(np.float32)
+    save("kaldi_fbank_hf.npz", **out)
+
+
 # ------------------------------------------------------------------ BEST-RQ tokenizer + audio-pretrain packer (§8f-4)
 def bestrq_cases():
     from touchnet.models.touch_audio.processing_touch_audio import batch_audio_packed as ref_batch_audio
@@ -536,6 +558,6 @@ def touchdataset_case():
 if __name__ == "__main__":
     only = set(sys.argv[1:])
     for fn in (text_cases, asr_cases, ce_cases, docmask_cases, rope_cases, tiny_llama_case,
-               touch_audio_case, qwen2_audio_tower_case, frontend_cases, bestrq_cases, touchdataset_case):
+               touch_audio_case, qwen2_audio_tower_case, frontend_cases, fbank_cases, bestrq_cases, touchdataset_case):
         if not only or fn.__name__ in only:
             fn()

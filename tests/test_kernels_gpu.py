@@ -348,9 +348,17 @@ def test_frontend_log_mel(golden):
             np.testing.assert_allclose(y, ref, atol=1e-3)
 
 
-def test_frontend_kaldi_fbank():
-    """Against the oracle restatement (parity with torchaudio itself is UNPINNED, see oracle/frontend.py)."""
+def test_frontend_kaldi_fbank(golden):
+    """Against the oracle restatement on random clips and against the third-party Kaldi-compatible fbank fixture
+    (transformers.audio_utils on the reference's two test wavs, tests/golden/kaldi_fbank_hf.npz); torchaudio itself is
+    not available in this image."""
     F = _f()
+    g, wavs = golden("kaldi_fbank_hf.npz"), golden("logmel.npz")
+    for i in (0, 1):
+        pcm = torch.from_numpy(wavs[f"wav{i}/pcm"].astype(np.int16)).to(DEV)
+        y = F.kaldi_fbank(F.pcm16_to_float(pcm), 80).cpu().numpy()
+        assert y.shape == g[f"wav{i}/fbank80"].shape
+        np.testing.assert_allclose(y, g[f"wav{i}/fbank80"], atol=3e-3)
     rng = np.random.RandomState(0)
     for n in (400, 16000, 16000 * 3 + 77):
         wav = np.clip(rng.randn(n) * 0.1, -1, 1).astype(np.float32)
