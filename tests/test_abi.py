@@ -44,3 +44,29 @@ def test_product_never_imports_oracle():
                 if re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M):
                     bad.append(os.path.join(d, f))
     assert not bad, bad
+
+
+def test_gemm_tuning_replay_env(monkeypatch, tmp_path):
+    """gemm_tuning.enable(): replay mode by default (tuning OFF, one results file per device ordinal), untouched when
+    the user configured TunableOp, opt-in tuning of new shapes into a caller-chosen directory."""
+    import os
+
+    from touchnet_amd.utils import gemm_tuning
+    for k in [k for k in os.environ if k.startswith("PYTORCH_TUNABLEOP") or k.startswith("TN_TUNE")]:
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.delenv("TN_RECORD_UNTUNED", raising=False)
+    assert os.path.exists(gemm_tuning.RESULTS)
+    lines = open(gemm_tuning.RESULTS).read().splitlines()
+    keys = [tuple(ln.split(",")[:2]) for ln in lines if not ln.startswith("Validator")]
+    assert len(keys) == len(set(keys)), "duplicate GEMM entries in the replay table"
+    assert gemm_tuning.enable() is True
+    assert os.environ["PYTORCH_TUNABLEOP_ENABLED"] == "1" and os.environ["PYTORCH_TUNABLEOP_TUNING"] == "0"
+    d = os.path.dirname(os.environ["PYTORCH_TUNABLEOP_FILENAME"])
+    assert all(os.path.exists(os.path.join(d, f"results{i}.csv")) for i in range(8))
+    assert gemm_tuning.enable() is False                       # already configured -> hands off
+    for k in [k for k in os.environ if k.startswith("PYTORCH_TUNABLEOP")]:
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("TN_TUNE_NEW", "1")
+    monkeypatch.setenv("TN_TUNE_DIR", str(tmp_path / "tune"))
+    assert gemm_tuning.enable() is True and os.environ["PYTORCH_TUNABLEOP_TUNING"] == "1"
+    assert os.environ["PYTORCH_TUNABLEOP_FILENAME"].startswith(str(tmp_path / "tune"))
