@@ -218,3 +218,95 @@ def test_context_parallel_two_ranks_gloo():
         results = dict(ret)
     for r in range(world):
         assert results[r][0] == "ok", results[r][1]
+
+
+@pytest.mark.parametrize("cp", [2, 4])
+def test_halo_need_matrix_against_elementwise_mask(cp):
+    """halo_need() vs a brute-force evaluation of the document mask: a rank needs a chunk exactly when some of its
+    query rows may attend some key of that chunk (plus its own chunks)."""
+    from touchnet_amd.utils.context_parallel import halo_need
+    rng = np.random.RandomState(cp)
+    for trial in range(20):
+        B, Tc = 2, 8
+        T = 2 * cp * Tc
+        ids = np.zeros((B, T), dtype=np.int64)
+        for b in range(B):
+            t, d = 0, 1
+            while t < T:
+                n = int(rng.randint(1, 3 * Tc))
+                ids[b, t:t + n] = d if rng.rand() > 0.15 else 0
+                t += n
+                d += 1
+        need = halo_need(ids, cp)
+        q = np.arange(T)
+        allow = (ids[:, :, None] == ids[:, None, :]) & (ids[:, :, None] > 0) & (q[None, None, :] <= q[None, :, None])
+        C = 2 * cp
+        for r in range(cp):
+            mine = (r, C - 1 - r)
+            for c in range(C):
+                rows = np.concatenate([np.arange(lc * Tc, (lc + 1) * Tc) for lc in mine])
+                brute = bool(allow[:, rows][:, :, c * Tc:(c + 1) * Tc].any()) or c in mine
+                assert bool(need[r, c]) == brute, (trial, r, c)
+
+
+def _halo_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from touchnet_amd.utils.context_parallel import ContextParallel
+    try:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        T, B, Hd = 2 * world * 128, 2, 3
+        cpar = ContextParallel(dist.group.WORLD, T)
+        g = torch.Generator().manual_seed(5)
+        full = torch.randn(B, T, Hd, generator=g)
+        w = torch.randn(B, T, Hd, generator=g)                       # fixed weights of a dummy loss
+        # documents aligned to the chunks: chunk c holds document c+1 only -> nobody needs anybody else's chunks;
+        # second layout: one document spans everything -> every earlier chunk is needed
+        outs = {}
+        for name, ids in (("disjoint", torch.arange(2 * world).repeat_interleave(128)[None].repeat(B, 1) + 1),
+                          ("one_doc", torch.ones(B, T, dtype=torch.int64))):
+            res = {}
+            for mode in ("allgather", "halo"):
+                cpar.need, cpar.halo_bytes = None, 0
+                if mode == "halo":
+                    cpar.set_documents(ids)
+                x = cpar.shard(full).clone().requires_grad_()
+                y = cpar.gather_seq(x)
+                # only what the document mask lets this rank's rows see may matter: weight the visible chunks
+                vis = torch.zeros(T)
+                need = cpar.need if mode == "halo" else None
+                from touchnet_amd.utils.context_parallel import halo_need
+                nd = halo_need(ids.numpy(), world)
+                for c in range(2 * world):
+                    if nd[rank, c]:
+                        vis[c * cpar.Tc:(c + 1) * cpar.Tc] = 1.0
+                (y * w * vis[None, :, None]).sum().backward()
+                res[mode] = (y.detach() * vis[None, :, None], x.grad.clone(), cpar.halo_bytes)
+            assert torch.equal(res["halo"][0], res["allgather"][0]), name
+            assert torch.allclose(res["halo"][1], res["allgather"][1], atol=1e-6), name
+            outs[name] = res["halo"][2]
+        ret[rank] = ("ok", outs)
+    except Exception as e:
+        import traceback
+        ret[rank] = ("fail", traceback.format_exc(), repr(e))
+    finally:
+        if dist.is_initialized():
+            dist.barrier()
+            dist.destroy_process_group()
+
+
+def test_halo_exchange_equals_allgather_and_trims():
+    """2-rank gloo: gather_seq through the halo exchange == through all-gather/reduce-scatter on everything a rank's
+    rows can see (values and gradients); chunk-aligned documents move NOTHING, one long document moves the causal
+    prefix only."""
+    world = 2
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_halo_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+        results = dict(ret)
+    for r in range(world):
+        assert results[r][0] == "ok", results[r][1]
+    chunk_bytes = 2 * 128 * 3 * 4
+    assert results[0][1]["disjoint"] == 0 and results[1][1]["disjoint"] == 0
+    # one document, cp = 2: rank 0 owns chunks {0, 3} and needs 1, 2 (fwd) ; rank 1 owns {1, 2} and needs 0; the
+    # backward moves the gradients of the same chunks the other way
+    assert results[0][1]["one_doc"] == (2 + 1) * chunk_bytes and results[1][1]["one_doc"] == (1 + 2) * chunk_bytes

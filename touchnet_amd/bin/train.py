@@ -39,6 +39,7 @@ class TrainConfig:
     training_fsdp_reshard_after_forward: str = "never"
     training_enable_fused_ce: bool = True      # role of `training_enable_liger_kernel`'s fused-linear-CE branch
     training_ce_chunk_tokens: int = 16384
+    training_cp_halo_exchange: bool = True     # CP: point-to-point exchange of the K/V chunks a rank can see (else all-gather)
     training_ce_compact_rows: bool = False     # opt-in: lm_head only on labelled positions (one host sync per step)
     lr_scheduler_lr: float = 8e-4
     lr_scheduler_warmup_steps: int = 2000
@@ -111,6 +112,11 @@ class Trainer:
             T = out["labels"].shape[1]
             if self.cp is None or self.cp.T != T:
                 self.cp = ContextParallel(self.cp_group, T)
+            if self.job.training_cp_halo_exchange:                      # document ids: from the HOST copy when there is one
+                src = batch.get("attention_mask")
+                self.cp.set_documents(src if isinstance(src, torch.Tensor) else out["attention_mask"])
+            else:
+                self.cp.need = None
             for k in ("input_ids", "labels", "position_ids", "sentence_lens", "input_features", "inputs_embeds"):
                 if isinstance(out.get(k), torch.Tensor):
                     out[k] = self.cp.shard(out[k], dim=1)
