@@ -96,3 +96,50 @@ def test_product_ops_refuse_cpu_tensors():
         F.swiglu_mlp(torch.randn(8, 64), w, w, w)
     with pytest.raises((KernelError, ImportError, RuntimeError)):
         F.bestrq_tokenize(torch.randn(8, 16), torch.randn(16, 8), torch.randn(32, 8))
+
+
+def _hf_packed_case():
+    B, T = 2, 48
+    g = torch.Generator().manual_seed(0)
+    ids = torch.randint(3, 97, (B, T), generator=g)
+    docs = torch.tensor([[1] * 10 + [2] * 20 + [3] * 15 + [0] * 3, [1] * 30 + [2] * 18])
+    pos = torch.cat([torch.cat([torch.arange(n) for n in lens]) for lens in ([10, 20, 15, 1, 1, 1], [30, 18])]).view(B, T)
+    q = torch.arange(T)
+    allow = (docs[:, :, None] == docs[:, None, :]) & (docs[:, :, None] > 0) & (q[None, None, :] <= q[None, :, None])
+    return ids, docs, pos, allow
+
+
+def test_hf_attention_interface_drives_transformers_llama():
+    """SURVEY §8b hook 2: transformers' own LlamaForCausalLM with `attn_implementation="mi355_packed"` (our
+    attention-function adapter, here on the oracle backend) == the same model in eager mode with the explicit 4-D
+    document mask, with the document ids taken (a) from restarting position_ids, (b) from `document_ids=`, (c) from
+    an integer 2-D attention_mask handed straight to the function."""
+    from transformers import LlamaConfig, LlamaForCausalLM
+
+    import oracle.ops as oops
+    from touchnet_amd.integrations import hf_attention
+    from touchnet_amd.models.backend import use_ops
+    torch.manual_seed(0)
+    cfg = LlamaConfig(hidden_size=64, intermediate_size=128, num_attention_heads=4, num_key_value_heads=2,
+                      num_hidden_layers=2, vocab_size=97, head_dim=16, max_position_embeddings=256)
+    name = hf_attention.register()
+    m = LlamaForCausalLM(cfg).eval()
+    ids, docs, pos, allow = _hf_packed_case()
+    bias = torch.zeros(ids.shape[0], 1, ids.shape[1], ids.shape[1]).masked_fill(~allow[:, None], torch.finfo(torch.float32).min)
+    m.config._attn_implementation = "eager"
+    with torch.no_grad():
+        ref = m(input_ids=ids, position_ids=pos, attention_mask=bias).logits
+    m.config._attn_implementation = name
+    valid = docs > 0
+    with use_ops(oops), torch.no_grad():
+        a = m(input_ids=ids, position_ids=pos).logits
+        b = m(input_ids=ids, position_ids=pos, document_ids=docs).logits
+    assert float((a - ref)[valid].abs().max()) < 1e-5 and float((b - ref)[valid].abs().max()) < 1e-5
+    # (c) + the layout contract of the function itself
+    qh, kh, vh = torch.randn(2, 4, 48, 16), torch.randn(2, 2, 48, 16), torch.randn(2, 2, 48, 16)
+    with use_ops(oops):
+        out, w = hf_attention.packed_attention_forward(None, qh, kh, vh, attention_mask=docs, scaling=0.25)
+    assert w is None and out.shape == (2, 48, 4, 16) and out.is_contiguous()
+    assert torch.equal(hf_attention.documents_from_positions(pos)[0, :45], docs[0, :45].to(torch.int32))
+    with pytest.raises(NotImplementedError):
+        hf_attention.packed_attention_forward(None, qh, kh, vh, dropout=0.1)

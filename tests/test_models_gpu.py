@@ -218,3 +218,41 @@ def test_fsdp2_single_rank_rccl_matches_unsharded():
     for a, b in zip(got, ref):
         assert abs(a - b) / abs(b) < 5e-3, (got, ref)      # bf16 compute from fp32 shards vs bf16 weights + fp32 master
     assert got[-1] < got[0]
+
+
+def test_hf_attention_interface_on_device():
+    """SURVEY §8b hook 2 on the MI355X: transformers' LlamaForCausalLM in bf16 with `attn_implementation="mi355_packed"`
+    (HIP document-masked attention through the HF attention-function contract) against the same weights in fp32 eager
+    mode with the explicit 4-D document mask on the CPU; forward logits and the gradient of the embedding."""
+    from transformers import LlamaConfig, LlamaForCausalLM
+
+    from touchnet_amd.integrations import hf_attention
+    torch.manual_seed(0)
+    cfg = LlamaConfig(hidden_size=256, intermediate_size=512, num_attention_heads=4, num_key_value_heads=2,
+                      num_hidden_layers=2, vocab_size=257, head_dim=64, max_position_embeddings=512)
+    name = hf_attention.register()
+    ref = LlamaForCausalLM(cfg)
+    with torch.no_grad():
+        for p in ref.parameters():
+            p.copy_(p.bfloat16().float())
+    B, T = 2, 256
+    g = torch.Generator().manual_seed(1)
+    ids = torch.randint(3, 257, (B, T), generator=g)
+    lens = ([70, 100, 60, 26], [256])
+    docs = torch.stack([torch.cat([torch.full((n,), i + 1) for i, n in enumerate(ls)]) for ls in lens])
+    pos = torch.stack([torch.cat([torch.arange(n) for n in ls]) for ls in lens])
+    q = torch.arange(T)
+    allow = (docs[:, :, None] == docs[:, None, :]) & (q[None, None, :] <= q[None, :, None])
+    bias = torch.zeros(B, 1, T, T).masked_fill(~allow[:, None], torch.finfo(torch.float32).min)
+    ref.config._attn_implementation = "eager"
+    want = ref(input_ids=ids, position_ids=pos, attention_mask=bias).logits
+    want.float().square().mean().backward()
+    dev = LlamaForCausalLM(cfg).to(DEV, torch.bfloat16)
+    dev.load_state_dict({k: v.detach().to(DEV, torch.bfloat16) for k, v in ref.state_dict().items()})
+    dev.config._attn_implementation = name
+    got = dev(input_ids=ids.to(DEV), position_ids=pos.to(DEV)).logits
+    got.float().square().mean().backward()
+    scale = float(want.abs().max())
+    assert float((got.float().cpu() - want).abs().max()) < 3e-2 * scale
+    ge, we = dev.model.embed_tokens.weight.grad.float().cpu(), ref.model.embed_tokens.weight.grad
+    assert float((ge - we).abs().max()) < 5e-2 * float(we.abs().max())

@@ -1,0 +1,72 @@
+"""SURVEY.md §8b hook 2: the HF attention-function contract, so that the reference's OWN model classes (transformers
+`LlamaForCausalLM` / `Qwen2ForCausalLM`, which TouchNet instantiates at touchnet/__init__.py:38-39, 80-81) run the
+document-masked MFMA attention kernel by setting ``"attn_implementation": "mi355_packed"`` in the model JSON:
+
+    fn(module, query [B, Nh, T, D], key [B, Nkv, T, D], value [B, Nkv, T, D], attention_mask, dropout=0.0,
+       scaling=D**-0.5, **kwargs) -> (attn_output [B, T, Nh, D] contiguous, None)
+
+(transformers/models/llama/modeling_llama.py:264-279 at the pinned 4.51.3; same contract in 5.x.)
+
+Where the document ids come from, in this order:
+  1. ``document_ids`` [B, T] int (0 = pad) passed to ``model(...)`` — HF forwards unknown keyword arguments down to
+     the attention function;
+  2. a 2-D INTEGER ``attention_mask`` whose values are document indices (what TouchNet's packers emit, processing_llama.py:24-104);
+  3. ``position_ids`` that restart at 0 for every sentence (the packed-sequence convention HF's flash-attention path
+     uses too): a new document starts wherever the position does not increase by one;
+  4. none of them: one causal document per row.
+A custom implementation name is unknown to HF's mask builders, which then hand over ``attention_mask=None`` (5.x) or a
+4-D additive causal mask (4.51): both carry no document information and are ignored here.
+"""
+from __future__ import annotations
+
+import torch
+
+from touchnet_amd.models.backend import ops
+
+NAME = "mi355_packed"
+_cache = {"key": None, "mask": None}
+
+
+def documents_from_positions(position_ids: torch.Tensor) -> torch.Tensor:
+    """position_ids [B, T] -> document ids 1.. per row: a document starts at t = 0 and wherever pos[t] != pos[t-1] + 1."""
+    p = position_ids.to(torch.int64)
+    start = torch.ones_like(p, dtype=torch.bool)
+    start[:, 1:] = p[:, 1:] != p[:, :-1] + 1
+    return torch.cumsum(start.to(torch.int32), dim=1).to(torch.int32)
+
+
+def _documents(query, attention_mask, position_ids, document_ids):
+    B, _, T, _ = query.shape
+    if document_ids is not None:
+        return document_ids
+    if (isinstance(attention_mask, torch.Tensor) and attention_mask.dim() == 2
+            and not attention_mask.is_floating_point() and attention_mask.dtype != torch.bool):
+        return attention_mask
+    if position_ids is not None:
+        if position_ids.shape[0] != B:
+            position_ids = position_ids.expand(B, -1)
+        return documents_from_positions(position_ids)
+    return torch.ones(B, T, dtype=torch.int32, device=query.device)
+
+
+def packed_attention_forward(module, query, key, value, attention_mask=None, dropout: float = 0.0, scaling=None,
+                             position_ids=None, document_ids=None, **kwargs):
+    if dropout:
+        raise NotImplementedError("mi355_packed attention: dropout is not supported (the reference trains with 0.0)")
+    if query.shape[2] != key.shape[2]:
+        raise NotImplementedError("mi355_packed attention: training/prefill only (no KV cache decoding)")
+    docs = _documents(query, attention_mask, position_ids, document_ids).to(device=query.device, dtype=torch.int32)
+    key_ = (docs.data_ptr(), tuple(docs.shape), docs._version)
+    if _cache["key"] != key_:                       # tile metadata once per forward, shared by all layers
+        _cache["key"], _cache["mask"], _cache["docs"] = key_, ops().build_packed_mask(docs), docs
+    scaling = query.shape[-1] ** -0.5 if scaling is None else scaling
+    out = ops().packed_attention(query.transpose(1, 2).contiguous(), key.transpose(1, 2).contiguous(),
+                                 value.transpose(1, 2).contiguous(), _cache["mask"], scaling)
+    return out, None
+
+
+def register(name: str = NAME) -> str:
+    """Registers the function in transformers' attention registry (AttentionInterface, >= 4.48)."""
+    from transformers import AttentionInterface
+    AttentionInterface.register(name, packed_attention_forward)
+    return name
