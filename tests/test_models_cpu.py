@@ -143,3 +143,41 @@ def test_hf_attention_interface_drives_transformers_llama():
     assert torch.equal(hf_attention.documents_from_positions(pos)[0, :45], docs[0, :45].to(torch.int32))
     with pytest.raises(NotImplementedError):
         hf_attention.packed_attention_forward(None, qh, kh, vh, dropout=0.1)
+
+
+def test_hf_module_swap_patch_keeps_transformers_llama_outputs():
+    """SURVEY §8b hook 1: apply_mi355_kernels_to_llama() (RMSNorm + MLP + attention interface) on transformers'
+    LlamaForCausalLM — oracle backend — gives the logits and gradients of the unpatched eager model; undo() restores."""
+    from transformers import LlamaConfig, LlamaForCausalLM
+    from transformers.models.llama import modeling_llama as hf
+
+    import oracle.ops as oops
+    from touchnet_amd.integrations import hf_attention, hf_patch
+    from touchnet_amd.models.backend import use_ops
+    torch.manual_seed(0)
+    cfg = LlamaConfig(hidden_size=64, intermediate_size=128, num_attention_heads=4, num_key_value_heads=2,
+                      num_hidden_layers=2, vocab_size=97, head_dim=16, max_position_embeddings=256)
+    m = LlamaForCausalLM(cfg)
+    ids, docs, pos, allow = _hf_packed_case()
+    bias = torch.zeros(ids.shape[0], 1, ids.shape[1], ids.shape[1]).masked_fill(~allow[:, None], torch.finfo(torch.float32).min)
+    valid = (docs > 0)[..., None].float()
+    m.config._attn_implementation = "eager"
+    ref = m(input_ids=ids, position_ids=pos, attention_mask=bias).logits
+    (ref * valid).square().mean().backward()
+    gref = {n: p.grad.clone() for n, p in m.named_parameters()}
+    m.zero_grad()
+    orig_norm, orig_mlp = hf.LlamaRMSNorm.forward, hf.LlamaMLP.forward
+    try:
+        hf_patch.apply_mi355_kernels_to_llama()
+        hf_patch.apply_mi355_kernels_to_llama()                     # idempotent
+        assert hf.LlamaRMSNorm.forward is not orig_norm and hf.LlamaMLP.forward is not orig_mlp
+        m.config._attn_implementation = hf_attention.NAME
+        with use_ops(oops):
+            got = m(input_ids=ids, position_ids=pos, document_ids=docs).logits
+            (got * valid).square().mean().backward()
+        assert float(((got - ref) * valid).abs().max()) < 1e-4
+        for n, p in m.named_parameters():
+            assert float((p.grad - gref[n]).abs().max()) < 1e-4 * max(1.0, float(gref[n].abs().max())), n
+    finally:
+        hf_patch.undo()
+    assert hf.LlamaRMSNorm.forward is orig_norm and hf.LlamaMLP.forward is orig_mlp

@@ -220,8 +220,8 @@ def test_fsdp2_single_rank_rccl_matches_unsharded():
     assert got[-1] < got[0]
 
 
-def test_hf_attention_interface_on_device():
-    """SURVEY §8b hook 2 on the MI355X: transformers' LlamaForCausalLM in bf16 with `attn_implementation="mi355_packed"`
+def test_hf_attention_interface_and_module_swap_on_device():
+    """SURVEY §8b hooks 2 and 1 on the MI355X: transformers' LlamaForCausalLM in bf16 with `attn_implementation="mi355_packed"`
     (HIP document-masked attention through the HF attention-function contract) against the same weights in fp32 eager
     mode with the explicit 4-D document mask on the CPU; forward logits and the gradient of the embedding."""
     from transformers import LlamaConfig, LlamaForCausalLM
@@ -250,9 +250,22 @@ def test_hf_attention_interface_on_device():
     dev = LlamaForCausalLM(cfg).to(DEV, torch.bfloat16)
     dev.load_state_dict({k: v.detach().to(DEV, torch.bfloat16) for k, v in ref.state_dict().items()})
     dev.config._attn_implementation = name
-    got = dev(input_ids=ids.to(DEV), position_ids=pos.to(DEV)).logits
-    got.float().square().mean().backward()
     scale = float(want.abs().max())
-    assert float((got.float().cpu() - want).abs().max()) < 3e-2 * scale
-    ge, we = dev.model.embed_tokens.weight.grad.float().cpu(), ref.model.embed_tokens.weight.grad
-    assert float((ge - we).abs().max()) < 5e-2 * float(we.abs().max())
+    we = ref.model.embed_tokens.weight.grad
+
+    def check(tag):
+        dev.zero_grad()
+        got = dev(input_ids=ids.to(DEV), position_ids=pos.to(DEV)).logits
+        got.float().square().mean().backward()
+        assert float((got.float().cpu() - want).abs().max()) < 3e-2 * scale, tag
+        ge = dev.model.embed_tokens.weight.grad.float().cpu()
+        assert float((ge - we).abs().max()) < 5e-2 * float(we.abs().max()), tag
+
+    check("attention interface only")
+    # hook 1 on top: RMSNorm and the SwiGLU MLP node of transformers' classes swapped for the HIP ops (liger's slot)
+    from touchnet_amd.integrations import hf_patch
+    try:
+        hf_patch.apply_mi355_kernels_to_llama()
+        check("attention + RMSNorm + MLP patched")
+    finally:
+        hf_patch.undo()
