@@ -181,3 +181,29 @@ def test_hf_module_swap_patch_keeps_transformers_llama_outputs():
     finally:
         hf_patch.undo()
     assert hf.LlamaRMSNorm.forward is orig_norm and hf.LlamaMLP.forward is orig_mlp
+
+
+def test_hf_module_swap_patch_qwen2():
+    """Same as above for transformers' Qwen2ForCausalLM (q/k/v biases stay HF's nn.Linear; RMSNorm, MLP, attention swapped)."""
+    from transformers import Qwen2Config, Qwen2ForCausalLM
+
+    import oracle.ops as oops
+    from touchnet_amd.integrations import hf_attention, hf_patch
+    from touchnet_amd.models.backend import use_ops
+    torch.manual_seed(1)
+    cfg = Qwen2Config(hidden_size=64, intermediate_size=128, num_attention_heads=4, num_key_value_heads=2,
+                      num_hidden_layers=2, vocab_size=97, max_position_embeddings=256, use_sliding_window=False)
+    m = Qwen2ForCausalLM(cfg).eval()
+    ids, docs, pos, allow = _hf_packed_case()
+    bias = torch.zeros(ids.shape[0], 1, ids.shape[1], ids.shape[1]).masked_fill(~allow[:, None], torch.finfo(torch.float32).min)
+    m.config._attn_implementation = "eager"
+    with torch.no_grad():
+        ref = m(input_ids=ids, position_ids=pos, attention_mask=bias).logits
+    try:
+        hf_patch.apply_mi355_kernels_to_qwen2()
+        m.config._attn_implementation = hf_attention.NAME
+        with use_ops(oops), torch.no_grad():
+            got = m(input_ids=ids, position_ids=pos, document_ids=docs).logits
+    finally:
+        hf_patch.undo()
+    assert float((got - ref)[docs > 0].abs().max()) < 1e-4
