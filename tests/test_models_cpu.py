@@ -207,3 +207,30 @@ def test_hf_module_swap_patch_qwen2():
     finally:
         hf_patch.undo()
     assert float((got - ref)[docs > 0].abs().max()) < 1e-4
+
+
+def test_liger_branch_shift_labels_returns_token_mean_loss():
+    """Hook 3, the reference's liger branch (train.py:434-445): called with `shift_labels` only, the model returns
+    `.loss` = mean CE over the labelled tokens (and `.logits = None`), differentiable, equal to F.cross_entropy on the
+    logits the same model returns without labels."""
+    import oracle.ops as oops
+    from touchnet_amd.models.backend import use_ops
+    from touchnet_amd.models.llama import DecoderConfig, PackedCausalLM
+    torch.manual_seed(0)
+    cfg = DecoderConfig.from_dict(dict(model_type="llama", hidden_size=64, intermediate_size=128, num_attention_heads=4,
+                                       num_hidden_layers=2, num_key_value_heads=2, head_dim=16, vocab_size=97,
+                                       tie_word_embeddings=False, rope_theta=10000.0, initializer_range=0.08))
+    m = PackedCausalLM(cfg)
+    m.post_init()
+    ids, docs, pos, _ = _hf_packed_case()
+    labels = ids.clone()
+    labels[docs == 0] = -100
+    labels[:, ::4] = -100
+    with use_ops(oops):
+        out = m(input_ids=ids, position_ids=pos, attention_mask=docs, shift_labels=labels)
+        assert out.logits is None and out.loss.requires_grad
+        logits = m(input_ids=ids, position_ids=pos, attention_mask=docs).logits
+    want = torch.nn.functional.cross_entropy(logits.reshape(-1, 97).float(), labels.reshape(-1), ignore_index=-100)
+    assert float(out.loss) == pytest.approx(float(want), rel=1e-5)
+    out.loss.backward()
+    assert m.lm_head.weight.grad is not None and torch.isfinite(m.lm_head.weight.grad).all()

@@ -181,8 +181,8 @@ class PackedCausalLM(nn.Module):
                 nn.init.ones_(m.weight)
 
     def forward(self, input_ids=None, inputs_embeds=None, position_ids=None, attention_mask=None,
-                labels=None, sentence_lens=None, num_sentence=None, ce_chunk_tokens: int = 16384,
-                ce_compact: bool = False, context_parallel=None, **unused):
+                labels=None, sentence_lens=None, num_sentence=None, shift_labels=None,
+                ce_chunk_tokens: int = 16384, ce_compact: bool = False, context_parallel=None, **unused):
         """Without `labels`: returns `.logits` (the reference's default path, loss_fn runs in the trainer).
         With `labels` (+ `sentence_lens`, `num_sentence`): lm_head and the packed CE run fused INSIDE the
         model — the role liger's fused-linear-CE plays in the reference (`pred.loss`, train.py:443-445), but
@@ -190,6 +190,17 @@ class PackedCausalLM(nn.Module):
         with `.logits = None`.  Being inside forward keeps lm_head under FSDP2's unshard/reshard hooks."""
         h = self.model(input_ids=input_ids, inputs_embeds=inputs_embeds, position_ids=position_ids,
                        attention_mask=attention_mask, context_parallel=context_parallel)
+        if labels is None and shift_labels is not None:
+            # The reference's liger branch (train.py:434-445 with training_enable_liger_kernel): the trainer pops
+            # labels / sentence_lens / num_sentence and passes only `shift_labels`; `.loss` is then the MEAN over the
+            # labelled tokens (liger's fused-linear-CE semantics, without the per-sentence normalisation).  Same fused
+            # kernel path: every labelled token is its own "sentence", num_sentence = their count (device scalar).
+            from touchnet_amd.loss.cross_entropy import fused_linear_cross_entropy
+            n_valid = (shift_labels != -100).sum().clamp_min(1).to(torch.float32)
+            loss, per_token, acc = fused_linear_cross_entropy(h, self.lm_head.weight, shift_labels,
+                                                              torch.ones_like(shift_labels), n_valid,
+                                                              chunk_tokens=ce_chunk_tokens, compact=ce_compact)
+            return SimpleNamespace(logits=None, loss=loss, loss_per_token=per_token, acc=acc)
         if labels is None:
             return SimpleNamespace(logits=self.lm_head(h), loss=None)
         from touchnet_amd.loss.cross_entropy import fused_linear_cross_entropy
