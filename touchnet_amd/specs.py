@@ -34,14 +34,21 @@ def _build_lr(optimizers, job):
 
 
 def _synthetic_loader(**kw):
-    raise NotImplementedError("the MI355X path is fed by touchnet's own datapipe (INTEGRATION.md) or by "
-                              "touchnet_amd.data.synthetic in benchmarks")
+    raise NotImplementedError("the MI355X path is fed by touchnet's own dataloader over touchnet_amd.data.datapipe "
+                              "(INTEGRATION.md) or by touchnet_amd.data.synthetic in benchmarks")
+
+
+def _build_tokenizer(args, **kwargs):
+    """touchnet/tokenizer/tokenizer.py:321-334: the BEST-RQ label tokenizer runs on the device; text tokenizers are
+    out of scope and stay the reference's (this raises NotImplementedError for them)."""
+    from touchnet_amd.tokenizer import build_tokenizer
+    return build_tokenizer(args, **kwargs)
 
 
 def _spec(name, mod, model_cls, config_cls):
     return TrainSpec(name=name, model_cls=model_cls, config_cls=config_cls, parallelize_fn=_parallelize,
                      pipelining_fn=None, build_optimizers_fn=_build_optimizers, build_lr_schedulers_fn=_build_lr,
-                     build_dataloader_fn=_synthetic_loader, build_tokenizer_fn=None, loss_fn=cross_entropy_loss,
+                     build_dataloader_fn=_synthetic_loader, build_tokenizer_fn=_build_tokenizer, loss_fn=cross_entropy_loss,
                      acc_fn=accuracy, additional_pre_init_fn=mod.pre_init, additional_post_init_fn=mod.post_init,
                      get_num_flop_per_token_fn=mod.get_num_flop_per_token, get_num_params_fn=mod.get_num_params)
 
