@@ -294,11 +294,12 @@ def _halo_worker(rank, world, port, ret):
             dist.destroy_process_group()
 
 
-def test_halo_exchange_equals_allgather_and_trims():
-    """2-rank gloo: gather_seq through the halo exchange == through all-gather/reduce-scatter on everything a rank's
-    rows can see (values and gradients); chunk-aligned documents move NOTHING, one long document moves the causal
-    prefix only."""
-    world = 2
+@pytest.mark.parametrize("world", [2, 4])
+def test_halo_exchange_equals_allgather_and_trims(world):
+    """gloo, 2 and 4 ranks: gather_seq through the halo exchange == through all-gather/reduce-scatter on everything a
+    rank's rows can see (values and gradients); chunk-aligned documents move NOTHING, one long document moves the
+    causal prefix only (byte counts derived from halo_need: forward receives + backward gradient returns)."""
+    from touchnet_amd.utils.context_parallel import halo_need
     with mp.Manager() as mgr:
         ret = mgr.dict()
         mp.spawn(_halo_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
@@ -306,7 +307,11 @@ def test_halo_exchange_equals_allgather_and_trims():
     for r in range(world):
         assert results[r][0] == "ok", results[r][1]
     chunk_bytes = 2 * 128 * 3 * 4
-    assert results[0][1]["disjoint"] == 0 and results[1][1]["disjoint"] == 0
-    # one document, cp = 2: rank 0 owns chunks {0, 3} and needs 1, 2 (fwd) ; rank 1 owns {1, 2} and needs 0; the
-    # backward moves the gradients of the same chunks the other way
-    assert results[0][1]["one_doc"] == (2 + 1) * chunk_bytes and results[1][1]["one_doc"] == (1 + 2) * chunk_bytes
+    need = halo_need(np.ones((2, 2 * world * 128), dtype=np.int64), world)
+    C = 2 * world
+    for r in range(world):
+        assert results[r][1]["disjoint"] == 0
+        mine = (r, C - 1 - r)
+        fwd = sum(bool(need[r, c]) for c in range(C) if c not in mine)            # chunks received in the forward
+        bwd = sum(bool(need[p, c]) for p in range(world) if p != r for c in mine)  # gradient pieces coming back
+        assert results[r][1]["one_doc"] == (fwd + bwd) * chunk_bytes, (r, results[r][1], fwd, bwd)
