@@ -174,6 +174,17 @@ int tn_pcm16_to_f32(const void* pcm_int16, float* out, long long n, void* stream
 int tn_bestrq_tokenize(const float* feat, const float* quantizer, const float* codebook, long long* codes, int T,
                        int F, int E, int V, void* stream);
 
+/* ---- hand-written bf16 MFMA GEMM for the linear layers (q/k/v/o/gate/up/down/lm_head of the decoder blocks,
+ *      fc1/fc2/out_proj of the audio tower): replaces torch.nn.functional.linear / liger's MLP swap,
+ *      touchnet/models/llama/__init__.py:11-15.
+ *      C[M,N] = A[M,K] . B[N,K]^T (+ bias[N]) (+ C when accumulate != 0); bf16 in/out, fp32 accumulation, ONE rounding.
+ *      Both operands contraction-contiguous (nn.Linear's forward layout).  Ct (optional, may be NULL): transposed copy
+ *      [N, M] written by the same epilogue for the weight-gradient GEMM that consumes C^T next.
+ *      -22 unless: K % 128 == 0, N % 8 == 0, lda/ldb/ldc % 8 == 0 (>= K, K, N), 16-byte aligned bases,
+ *      288 * ld * 2 < 2^31; with Ct: M % 8 == 0, ldct % 8 == 0, accumulate == 0. */
+int tn_gemm_bf16_tn(const void* A, const void* B, void* C, void* Ct, const void* bias, int M, int N, int K,
+                    long long lda, long long ldb, long long ldc, long long ldct, int accumulate, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

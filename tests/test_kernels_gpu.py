@@ -714,3 +714,68 @@ def test_attention_long_sequence_multi_chunk_tile_list(D, Nh, Nkv):
     o1 = F.packed_attention(q1, k1, v1, F.causal_mask(1, 1000, DEV))
     _close(out[:, 30000:31000], o1, 1e-2, 1e-2, "short document after the long one")
     assert float(out[0, 32700:].float().abs().max()) == 0.0
+
+
+# ---------------------------------------------------------------------------------------- hand-written MFMA GEMM
+@pytest.mark.parametrize("M,N,K,bias,acc,ct", [
+    (256, 256, 128, False, False, False),      # one tile, one trip of the 4-slot ring
+    (512, 768, 256, True, False, False),       # bias, several tiles
+    (300, 264, 384, False, False, False),      # ragged M and N (zero-filled DMA rows, guarded stores)
+    (1000, 1288, 512, True, True, False),      # accumulate into C (group input gradients), ragged
+    (512, 512, 1024, False, False, True),      # transposed copy
+    (776, 1032, 256, True, False, True),       # transposed copy, ragged, bias
+    (2048, 4096, 4096, False, False, False),   # decoder-block shape (o_proj / q_proj), XCD tile map with 128 tiles
+    (1024, 11008, 4096, False, False, False),  # gate / up: 43 column tiles (odd count through the bijective map)
+])
+def test_gemm_tn_matches_fp32_reference(M, N, K, bias, acc, ct):
+    """tn_gemm_bf16_tn vs an fp32 torch.mm of the same bf16-rounded operands (asymmetric random data, so a swapped or
+    transposed tile cannot pass); tolerance = half a bf16 ulp of the result + fp32 summation-order noise."""
+    F = _f()
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    a = (torch.randn(M, K, generator=g) * 0.5).to(torch.bfloat16)
+    b = (torch.randn(N, K, generator=g) * 0.5).to(torch.bfloat16)
+    bv = torch.randn(N, generator=g).to(torch.bfloat16) if bias else None
+    c0 = torch.randn(M, N, generator=g).to(torch.bfloat16) if acc else None
+    ref = a.double() @ b.double().t()
+    if bias:
+        ref = ref + bv.double()
+    if acc:
+        ref = ref + c0.double()
+    ad, bd = a.to(DEV), b.to(DEV)
+    out = c0.to(DEV).clone() if acc else None
+    out_t = torch.full((N, M), float("nan"), dtype=torch.bfloat16, device=DEV) if ct else None
+    got = F.gemm_tn(ad, bd, bias=bv.to(DEV) if bias else None, out=out, accumulate=acc, out_t=out_t)
+    torch.cuda.synchronize()
+    scale = float(ref.abs().max())
+    _close(got, ref, atol=scale * 2 ** -8, rtol=2 ** -7, what=f"gemm_tn {M}x{N}x{K}")
+    if ct:
+        assert torch.equal(out_t.cpu(), got.cpu().t()), "transposed copy differs from C^T"
+
+
+def test_gemm_tn_strided_operands_and_rejects():
+    F = _f()
+    from touchnet_amd import _C
+    g = torch.Generator().manual_seed(5)
+    big_a = torch.randn(512, 640, generator=g).to(torch.bfloat16).to(DEV)
+    big_b = torch.randn(384, 640, generator=g).to(torch.bfloat16).to(DEV)
+    a, b = big_a[:, 128:640], big_b[:, :512]                      # row stride 640, K = 512, 16-byte aligned starts
+    out_full = torch.zeros(512, 512, dtype=torch.bfloat16, device=DEV)
+    out = out_full[:, 64:448]                                      # ldc = 512
+    F.gemm_tn(a, b, out=out)
+    ref = a.double().cpu() @ b.double().cpu().t()
+    _close(out, ref, atol=float(ref.abs().max()) * 2 ** -8, rtol=2 ** -7, what="gemm_tn strided")
+    assert float(out_full[:, :64].abs().max()) == 0 and float(out_full[:, 448:].abs().max()) == 0
+    with pytest.raises(_C.KernelError):
+        F.gemm_tn(big_a[:, :100], big_b[:, :100])                 # K % 128 != 0
+    with pytest.raises(_C.KernelError):
+        F.gemm_tn(big_a.float(), big_b.float())
+
+
+def test_gemm_tn_deterministic():
+    F = _f()
+    g = torch.Generator().manual_seed(11)
+    a = torch.randn(1024, 2048, generator=g).to(torch.bfloat16).to(DEV)
+    b = torch.randn(1536, 2048, generator=g).to(torch.bfloat16).to(DEV)
+    first = F.gemm_tn(a, b).clone()
+    for _ in range(5):
+        assert torch.equal(F.gemm_tn(a, b), first)

@@ -58,6 +58,7 @@ PROTOTYPES = {
     "tn_bestrq_tokenize": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "tn_sumsq_multi_chunk": [],
     "tn_sumsq_multi": [_vp, _vp, _vp, _i, _ll, _vp, _vp, _i, _vp],
+    "tn_gemm_bf16_tn": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _ll, _ll, _ll, _ll, _i, _vp],
 }
 _RESTYPE = {"tn_version": C.c_char_p, "tn_sumsq_multi_chunk": C.c_longlong,
             "tn_colsum_workspace_floats": C.c_longlong}

@@ -483,6 +483,34 @@ def column_sum(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def gemm_tn(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+            accumulate: bool = False, out_t: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``out = a @ b.T (+ bias) (+ out)`` with the hand-written MFMA kernel (csrc/gemm.hip): a [M, K], b [N, K] bf16
+    device matrices with contiguous rows.  ``out_t`` [N, M] additionally receives the transposed result."""
+    if a.dim() != 2 or b.dim() != 2 or a.dtype != torch.bfloat16 or b.dtype != torch.bfloat16:
+        raise _C.KernelError("gemm_tn: 2-D bf16 operands only")
+    if a.stride(1) != 1 or b.stride(1) != 1 or a.shape[1] != b.shape[1]:
+        raise _C.KernelError("gemm_tn: operands must be contraction-contiguous [M, K] / [N, K]")
+    M, K = a.shape
+    N = b.shape[0]
+    if out is None:
+        if accumulate:
+            raise _C.KernelError("gemm_tn: accumulate needs `out`")
+        out = torch.empty(M, N, dtype=a.dtype, device=a.device)
+    if out.stride(1) != 1 or tuple(out.shape) != (M, N):
+        raise _C.KernelError("gemm_tn: bad `out`")
+    if bias is not None:
+        bias = _c(bias).to(a.dtype)
+    _C.check(_C.lib().tn_gemm_bf16_tn(_p(a), _p(b), _p(out), _p(out_t), _p(bias), M, N, K, a.stride(0), b.stride(0),
+                                      out.stride(0), out_t.stride(0) if out_t is not None else 0, int(accumulate),
+                                      _cur()), "tn_gemm_bf16_tn")
+    return out
+
+
+def gemm_tn_supported(M: int, N: int, K: int) -> bool:
+    return K % 128 == 0 and N % 8 == 0 and M > 0
+
+
 def _tn_ok(M: int, K: int, Ns) -> bool:
     return M % 8 == 0 and K % 8 == 0 and all(n % 8 == 0 for n in Ns)
 
