@@ -10,17 +10,14 @@
 // Structure (MI355X-first; numbers from MI355X_MICROARCH.md):
 //  * 256 x 256 output tile per 512-thread workgroup (8 waves = 2(M) x 4(N), wave tile 128 x 64 = 4 x 2 blocks of
 //    v_mfma_f32_32x32x16_bf16, 128 accumulator registers), one workgroup per CU, two waves per SIMD.
-//  * K is consumed in stages of 32 through a 4-slot LDS ring (4 x (16 KB A + 16 KB B) = 128 KB) filled by LDS-DMA
-//    (buffer_load_dwordx4 ... lds: no staging registers, no ds_write pass).  The DMA image is lane-linear, so the
-//    bank swizzle is applied to the per-lane SOURCE address and undone by the same XOR on the ds_read_b128 side:
-//    16-byte chunk c of row r sits in slot c ^ ((r >> 2) & 3) of the row's 64 bytes — conflict-free for the b128
-//    lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31} (each 256-byte bank row holds 4 tile rows).
-//  * ONE barrier per stage and never a vmcnt(0) in the loop: at the top of stage s a wave waits for ITS pieces of
-//    stage s+1 (vmcnt(4): the 4 pieces of stage s+2 stay in flight), the barrier then makes stage s+1 visible to
-//    everybody and proves that slot (s-1) % 4 is no longer read, so stage s+3 is issued into it straight away — two
-//    full stages (~2 k cycles) before it is needed.  Fragments of the first 16-deep half of stage s+1 are read
-//    into registers BEFORE that barrier is reached (they were guaranteed by the previous one), so the MFMA pipe
-//    does not drain across the barrier.
+//  * K is consumed in 64-deep stages ([256 rows][128 B] per operand = full cache lines) through LDS filled by
+//    LDS-DMA (buffer_load_dwordx4 ... lds: no staging registers, no ds_write pass).  The DMA image is lane-linear, so
+//    the bank swizzle is applied to the per-lane SOURCE address and undone by the same XOR on the ds_read_b128 side:
+//    16-byte chunk c of row r sits in slot c ^ ((r >> 1) & 7) of the row's 128 bytes — conflict-free for the b128
+//    lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31} (measured: SQ_LDS_BANK_CONFLICT = 1 % of LDS cycles).
+//  * ONE barrier per stage, placed in front of the stage's LAST 16-deep quarter: fragments of quarter q+1 are read
+//    while quarter q's 8 MFMAs run, so the matrix pipe does not drain across the barrier, and never a vmcnt(0) in the
+//    loop (see the two main loops below for the slot accounting).
 //  * Out-of-range rows (M, N not multiples of 256) are zero-filled by the buffer descriptor's bounds check; the
 //    tail stages re-read stage 0 into dead slots so that the vmcnt arithmetic stays uniform.
 //  * Workgroup -> tile map is XCD-aware: workgroup ids go to the 8 XCDs round-robin, so XCD x is given a contiguous
@@ -38,10 +35,8 @@
 namespace tn {
 namespace gemm {
 
-constexpr int BM = 256, BN = 256, BK = 32, NSTAGE = 4;
-constexpr int OP_STAGE = BM * BK * 2;              // 16 KB per operand per stage
-constexpr int LDS_A = 0, LDS_B = NSTAGE * OP_STAGE;  // 64 KB each
-constexpr int LDS_BYTES = 2 * NSTAGE * OP_STAGE;     // 128 KB
+constexpr int BM = 256, BN = 256;
+constexpr int LDS_BYTES = 160 * 1024;                // ring5 uses all of it; the other loops and the epilogue 128 KB
 constexpr int NT = 512;
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -68,7 +63,10 @@ __device__ __forceinline__ void tile_of_block(int bid, int nbm, int nbn, int& tm
   const int xcd = bid & 7, local = bid >> 3;
   const int q = total >> 3, r = total & 7;
   const int vid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
-  constexpr int GM = 8;
+#ifndef TN_GEMM_GM
+#define TN_GEMM_GM 8
+#endif
+  constexpr int GM = TN_GEMM_GM;
   const int per_group = GM * nbn;
   const int g = vid / per_group, w = vid - g * per_group;
   const int gm = min(GM, nbm - g * GM);  // rows in this (possibly short, last) group
@@ -87,104 +85,24 @@ struct Ctx {
 
 typedef f32x16_t Acc[4][2];
 
+// Timing experiments (scripts/build_variant.sh <name> -DTN_GEMM_ABLATE=n; results are garbage for n != 0):
+//   1 no DMA in the loop   2 no fragment reads in the loop   3 no MFMA   4 no epilogue stores   5 no barrier in the loop
+//   6 every DMA row reads row 0 (all L2 hits)
+#ifndef TN_GEMM_ABLATE
+#define TN_GEMM_ABLATE 0
+#endif
+
 // result rows (registers) = n, result column (lane) = m: 4 consecutive n per register quad -> 8-byte packs
 __device__ __forceinline__ void mma1(Acc& acc, const bf16x8_t (&a)[4], const bf16x8_t (&b)[2], int i, int j) {
+#if TN_GEMM_ABLATE == 3
+  asm volatile("" ::"v"(a[i]), "v"(b[j]));
+#else
   acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Main loop A: 4-slot ring of 32-deep stages, one barrier per stage, counted vmcnt(4).  64 bytes per row per DMA
-// piece (half cache lines: 16 rows x 64 B per wave instruction).
-// ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void mainloop_ring32(const Ctx& c, Acc& acc) {
-  char* const smem = c.smem;
-  const int wave = c.wave, lane = c.lane, l31 = c.l31, hi = c.hi;
-  int voff_a[2], voff_b[2];
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int row = wave * 32 + q * 16 + (lane >> 2);
-    const int chunk = (lane & 3) ^ ((row >> 2) & 3);
-    voff_a[q] = (int)(row * c.lda2) + chunk * 16;
-    voff_b[q] = (int)(row * c.ldb2) + chunk * 16;
-  }
-  const int nk = c.K / 32;
-  // one stage = 4 pieces per wave (A0, A1, B0, B1); issued ONE AT A TIME between MFMAs (a piece costs ~60 issue
-  // cycles, an MFMA occupies the pipe for 32: back-to-back pieces would starve the matrix pipe after every barrier)
-  auto issue_piece = [&](int slot, int soff, int piece) {
-    char* d = smem + (piece < 2 ? LDS_A : LDS_B) + slot * OP_STAGE + wave * 2048 + (piece & 1) * 1024;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(piece < 2 ? c.ra : c.rb, (lds_ptr_t)d, 16,
-                                             piece < 2 ? voff_a[piece & 1] : voff_b[piece & 1], soff, 0, 0);
-  };
-  auto stage_soff = [&](int stage) { return stage < nk ? stage * 64 : 0; };   // dead tail stages re-read stage 0
-  auto issue = [&](int slot, int stage) {
-    const int soff = stage_soff(stage);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) issue_piece(slot, soff, q);
-  };
-  const int f = (l31 >> 2) & 3;
-  const int xo0 = ((hi ^ f) << 4), xo1 = (((2 + hi) ^ f) << 4);          // k-half 0 / 1 of the 32-deep stage
-  const int a_base = LDS_A + (c.wr * 128 + l31) * 64;
-  const int b_base = LDS_B + (c.wc * 64 + l31) * 64;
-  bf16x8_t a0[4], b0[2], a1[4], b1[2];
-  auto read_half = [&](int slot, int xo, bf16x8_t (&a)[4], bf16x8_t (&b)[2]) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) b[j] = lds_frag(smem, b_base + slot * OP_STAGE + j * 2048 + xo);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) a[i] = lds_frag(smem, a_base + slot * OP_STAGE + i * 2048 + xo);
-  };
-
-  issue(0, 0);
-  issue(1, 1);
-  issue(2, 2);
-  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  read_half(0, xo0, a0, b0);
-  __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): enter the loop with nothing pending (see the loop's last line)
-
-  auto step = [&](auto SLOT, int s) {
-    constexpr int slot = decltype(SLOT)::value;
-    constexpr int nslot = (slot + 3) & 3;
-    const int soff = stage_soff(s + 3);
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // my pieces of stage s+1 have landed
-    __builtin_amdgcn_s_barrier();                       // stage s+1 complete; slot (s-1)%4 free
-    read_half(slot, xo1, a1, b1);
-    __builtin_amdgcn_s_setprio(1);
-    mma1(acc, a0, b0, 0, 0);
-    issue_piece(nslot, soff, 0);
-    mma1(acc, a0, b0, 0, 1);
-    mma1(acc, a0, b0, 1, 0);
-    issue_piece(nslot, soff, 1);
-    mma1(acc, a0, b0, 1, 1);
-    mma1(acc, a0, b0, 2, 0);
-    mma1(acc, a0, b0, 2, 1);
-    mma1(acc, a0, b0, 3, 0);
-    mma1(acc, a0, b0, 3, 1);
-    read_half((slot + 1) & 3, xo0, a0, b0);             // first half of stage s+1 (guaranteed by this barrier)
-    mma1(acc, a1, b1, 0, 0);
-    issue_piece(nslot, soff, 2);
-    mma1(acc, a1, b1, 0, 1);
-    mma1(acc, a1, b1, 1, 0);
-    issue_piece(nslot, soff, 3);
-    mma1(acc, a1, b1, 1, 1);
-    mma1(acc, a1, b1, 2, 0);
-    mma1(acc, a1, b1, 2, 1);
-    mma1(acc, a1, b1, 3, 0);
-    mma1(acc, a1, b1, 3, 1);
-    __builtin_amdgcn_s_setprio(0);
-  };
-  for (int s = 0; s < nk; s += 4) {
-    step(std::integral_constant<int, 0>{}, s);
-    step(std::integral_constant<int, 1>{}, s + 1);
-    step(std::integral_constant<int, 2>{}, s + 2);
-    step(std::integral_constant<int, 3>{}, s + 3);
-    // loop-carried fragment reads: retire them here (they were issued 8 MFMAs ago) so that hipcc's waitcnt pass does
-    // not fall back to lgkmcnt(0) in front of the first MFMA of the next trip
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// Main loop B: two slots of 64-deep stages ([256 rows][128 B] per operand per slot = full cache lines: a DMA piece is
+// Main loop A (reference for A/B runs, TN_GEMM_LOOP=1): two slots of 64-deep stages ([256 rows][128 B] per operand per slot = full cache lines: a DMA piece is
 // 8 rows x 128 B), ONE barrier per 64 of K.  A stage is consumed in four 16-deep quarters; fragments of quarter q+1
 // are read while quarter q's 8 MFMAs run.  The barrier sits in front of the LAST quarter of stage t: by then every
 // wave has read all of stage t (its slot is free for stage t+2, issued right behind the barrier, piece by piece
@@ -202,8 +120,13 @@ __device__ __forceinline__ void mainloop_pair64(const Ctx& c, Acc& acc) {
   for (int q = 0; q < 4; ++q) {               // this wave stages rows [32 w, 32 w + 32) of both operands: 4 pieces each
     const int row = wave * 32 + q * 8 + (lane >> 3);
     const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+#if TN_GEMM_ABLATE == 6
+    voff_a[q] = chunk * 16;
+    voff_b[q] = chunk * 16;
+#else
     voff_a[q] = (int)(row * c.lda2) + chunk * 16;
     voff_b[q] = (int)(row * c.ldb2) + chunk * 16;
+#endif
   }
   const int np = c.K / 64;
   auto issue_piece = [&](int slot, int soff, int piece) {          // piece 0..3 = A, 4..7 = B
@@ -247,28 +170,40 @@ __device__ __forceinline__ void mainloop_pair64(const Ctx& c, Acc& acc) {
   // hipcc's scheduler otherwise sinks the fragment reads down to their first use (shortest live ranges): the
   // software pipeline below is pinned group by group with sched_barrier(0)
 #define TN_PIN() __builtin_amdgcn_sched_barrier(0)
+#if TN_GEMM_ABLATE == 1
+#define TN_LOOP_PIECE(slot, soff, q) asm volatile("" ::"s"(soff))
+#else
+#define TN_LOOP_PIECE(slot, soff, q) issue_piece(slot, soff, q)
+#endif
+#if TN_GEMM_ABLATE == 2
+#define TN_LOOP_READ(slot, q, a, b) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]))
+#else
+#define TN_LOOP_READ(slot, q, a, b) read_q(slot, q, a, b)
+#endif
   auto pair = [&](auto SLOTC, int t) {
     constexpr int slot = decltype(SLOTC)::value;
     const int soff = stage_soff(t + 2);
     __builtin_amdgcn_s_setprio(1);
-    read_q(slot, 1, ao, bo);
+    TN_LOOP_READ(slot, 1, ao, bo);
     TN_PIN();
     mma8(ae, be);
     TN_PIN();
-    read_q(slot, 2, ae, be);
+    TN_LOOP_READ(slot, 2, ae, be);
     TN_PIN();
     mma8(ao, bo);
     TN_PIN();
-    read_q(slot, 3, ao, bo);
+    TN_LOOP_READ(slot, 3, ao, bo);
     TN_PIN();
     mma8(ae, be);
     TN_PIN();
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_s_waitcnt(0xc07f);                 // my reads of stage t are complete (quarter 3 is in registers)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // my pieces of stage t+1 (the only ones in flight) have landed
+#if TN_GEMM_ABLATE != 5
     __builtin_amdgcn_s_barrier();                       // stage t+1 visible; slot of stage t free
+#endif
     __builtin_amdgcn_s_setprio(1);
-    read_q(slot ^ 1, 0, ae, be);
+    TN_LOOP_READ(slot ^ 1, 0, ae, be);
     TN_PIN();
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -276,7 +211,7 @@ __device__ __forceinline__ void mainloop_pair64(const Ctx& c, Acc& acc) {
       for (int j = 0; j < 2; ++j) {
         mma1(acc, ao, bo, i, j);
         TN_PIN();
-        issue_piece(slot, soff, (i * 2 + j) / 2 + 4 * ((i * 2 + j) & 1));   // A0 B0 A1 B1 A2 B2 A3 B3
+        TN_LOOP_PIECE(slot, soff, (i * 2 + j) / 2 + 4 * ((i * 2 + j) & 1));   // A0 B0 A1 B1 A2 B2 A3 B3
         TN_PIN();
       }
     __builtin_amdgcn_s_setprio(0);
@@ -285,6 +220,121 @@ __device__ __forceinline__ void mainloop_pair64(const Ctx& c, Acc& acc) {
     pair(std::integral_constant<int, 0>{}, t);
     pair(std::integral_constant<int, 1>{}, t + 1);
     __builtin_amdgcn_s_waitcnt(0xc07f);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Main loop B (default): the whole 160 KB of LDS as a ring of FIVE 32 KB operand slots (operand-stage j = A(t) for j = 2t,
+// B(t) for j = 2t+1, slot j % 5), 64-deep stages in full cache lines like loop A.  Loop A can only start the DMA of
+// stage t+2 once stage t is consumed and needs it one stage later: its 64 KB round trip (~2.7 k cycles measured with
+// the MFMAs removed) is exposed whenever it exceeds a stage's MFMA time.  With the fifth slot 96 KB are in flight:
+// at the barrier of stage t the freed slots take B(t+2) (needed one stage later, issued at once) and A(t+3) (needed
+// TWO stages later, its pieces spread over the next stage's MFMAs); A(t+2) is already under way.
+//   wait at the barrier of stage t: in flight, oldest first: A(t+1), B(t+1), A(t+2) -> vmcnt(4) = A(t+2) may remain.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void mainloop_ring5(const Ctx& c, Acc& acc) {
+  char* const smem = c.smem;
+  constexpr int SLOT = 32768;
+  const int wave = c.wave, lane = c.lane, l31 = c.l31, hi = c.hi;
+  int voff_a[4], voff_b[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int row = wave * 32 + q * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+    voff_a[q] = (int)(row * c.lda2) + chunk * 16;
+    voff_b[q] = (int)(row * c.ldb2) + chunk * 16;
+  }
+  const int np = c.K / 64;
+  auto stage_soff = [&](int stage) { return stage < np ? stage * 128 : 0; };
+  auto piece_a = [&](int slot, int soff, int q) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(c.ra, (lds_ptr_t)(smem + slot * SLOT + wave * 4096 + q * 1024), 16,
+                                             voff_a[q], soff, 0, 0);
+  };
+  auto piece_b = [&](int slot, int soff, int q) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(c.rb, (lds_ptr_t)(smem + slot * SLOT + wave * 4096 + q * 1024), 16,
+                                             voff_b[q], soff, 0, 0);
+  };
+  const int f = (l31 >> 1) & 7;
+  int xa[4], xb[4];                           // per-quarter lane offsets inside a slot
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    xa[q] = (c.wr * 128 + l31) * 128 + (((2 * q + hi) ^ f) << 4);
+    xb[q] = (c.wc * 64 + l31) * 128 + (((2 * q + hi) ^ f) << 4);
+  }
+  bf16x8_t ae[4], be[2], ao[4], bo[2];
+  auto read_q = [&](int sa, int sb, int q, bf16x8_t (&a)[4], bf16x8_t (&b)[2]) {
+    const int ba = sa * SLOT + xa[q], bb = sb * SLOT + xb[q];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) b[j] = lds_frag(smem, bb + j * 4096);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = lds_frag(smem, ba + i * 4096);
+  };
+  auto mma8 = [&](const bf16x8_t (&a)[4], const bf16x8_t (&b)[2]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) mma1(acc, a, b, i, j);
+  };
+  auto next = [](int s, int d) { s += d; return s >= 5 ? s - 5 : s; };
+
+  // prologue: A0 B0 A1 B1 A2 -> slots 0..4
+  {
+    const int s0 = stage_soff(0), s1 = stage_soff(1), s2 = stage_soff(2);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) piece_a(0, s0, q);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) piece_b(1, s0, q);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) piece_a(2, s1, q);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) piece_b(3, s1, q);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) piece_a(4, s2, q);
+  }
+  asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  int sa = 0, sb = 1;                         // slots of A(t), B(t)
+  read_q(sa, sb, 0, ae, be);
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+
+  for (int t = 0; t < np; ++t) {
+    const int sa1 = next(sa, 2), sb1 = next(sb, 2);       // slots of stage t+1
+    const int soff_b = stage_soff(t + 2), soff_a = stage_soff(t + 3);
+    __builtin_amdgcn_s_setprio(1);
+    read_q(sa, sb, 1, ao, bo);
+    TN_PIN();
+    // quarter 0 (A(t+2)'s second half of pieces were issued in the previous trip's tail; see below)
+    mma8(ae, be);
+    TN_PIN();
+    read_q(sa, sb, 2, ae, be);
+    TN_PIN();
+    mma8(ao, bo);
+    TN_PIN();
+    read_q(sa, sb, 3, ao, bo);
+    TN_PIN();
+    mma8(ae, be);
+    TN_PIN();
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_waitcnt(0xc07f);                 // my reads of stage t are complete
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");    // A(t+1), B(t+1) landed; A(t+2) may still be in flight
+    __builtin_amdgcn_s_barrier();                       // stage t+1 visible; slots sa, sb free
+    __builtin_amdgcn_s_setprio(1);
+    read_q(sa1, sb1, 0, ae, be);
+    TN_PIN();
+    // last quarter of stage t: B(t+2) -> slot sa at once (due in one stage), then A(t+3) -> slot sb (due in two)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        mma1(acc, ao, bo, i, j);
+        TN_PIN();
+        if (i < 2) piece_b(sa, soff_b, i * 2 + j);
+        else piece_a(sb, soff_a, (i - 2) * 2 + j);
+        TN_PIN();
+      }
+    __builtin_amdgcn_s_setprio(0);
+    sa = sa1;
+    sb = sb1;
   }
 }
 
@@ -323,10 +373,14 @@ __global__ __launch_bounds__(NT, 2) void gemm_tn_kernel(const Params p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  if constexpr (LOOP == 0)
-    mainloop_ring32(c, acc);
-  else
+#ifdef TN_GEMM_SKEW
+  // experiment: de-phase the workgroups of an XCD (they all start together and would burst their DMA in lockstep)
+  for (int i = ((blockIdx.x >> 3) & 31) * TN_GEMM_SKEW; i > 0; --i) __builtin_amdgcn_s_sleep(1);
+#endif
+  if constexpr (LOOP == 1)
     mainloop_pair64(c, acc);
+  else
+    mainloop_ring5(c, acc);
 
   // ---- epilogue: park the wave's 128 x 64 tile in LDS, write full lines -------------------------------------------
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the dead tail DMAs must not land on the parked tile
@@ -370,7 +424,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_tn_kernel(const Params p) {
     const int row = it * 8 + (lane >> 3), c = lane & 7;
     uint4 v = *reinterpret_cast<const uint4*>(park + row * 128 + ((c ^ (row & 7)) << 4));
     const int m = wm0 + row, n = wn0 + c * 8;
-    if (m < p.M && n < p.N) {     // N is a multiple of 8 (checked by the host)
+    if (m < p.M && n < p.N && TN_GEMM_ABLATE != 4) {     // N is a multiple of 8 (checked by the host)
       bf16_t* dst = p.C + (long long)m * p.ldc + n;
       if (acc_c) {
         Vec16<bf16_t> o, nw;
@@ -425,7 +479,7 @@ extern "C" {
 int tn_gemm_bf16_tn(const void* A, const void* B, void* C, void* Ct, const void* bias, int M, int N, int K,
                     long long lda, long long ldb, long long ldc, long long ldct, int accumulate, void* stream) {
   using namespace tn::gemm;
-  if (M <= 0 || N <= 0 || K <= 0 || (K % (BK * NSTAGE)) != 0 || (N % 8) != 0) return TN_EINVAL;
+  if (M <= 0 || N <= 0 || K <= 0 || (K % 128) != 0 || (N % 8) != 0) return TN_EINVAL;
   if ((lda % 8) || (ldb % 8) || (ldc % 8) || lda < K || ldb < K || ldc < N) return TN_EINVAL;
   if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) return TN_EINVAL;
   if (Ct != nullptr && ((M % 8) || (ldct % 8) || ldct < M || ((uintptr_t)Ct & 15))) return TN_EINVAL;
@@ -445,15 +499,15 @@ int tn_gemm_bf16_tn(const void* A, const void* B, void* C, void* Ct, const void*
   p.nbn = (N + BN - 1) / BN;
   const dim3 grid(p.nbm * p.nbn), block(NT);
   hipStream_t st = (hipStream_t)stream;
-  // TN_GEMM_LOOP=0 selects the 4 x 32-deep ring (kernel-development A/B switch; default = the 2 x 64-deep loop)
-  static const int loop = [] { const char* e = getenv("TN_GEMM_LOOP"); return e ? atoi(e) : 1; }();
+  // TN_GEMM_LOOP=1: kernel-development A/B switch to the two-slot loop (default = the five-slot ring)
+  static const int loop = [] { const char* e = getenv("TN_GEMM_LOOP"); return e ? atoi(e) : 2; }();
+#define TN_LAUNCH(CT, L) hipLaunchKernelGGL((gemm_tn_kernel<CT, L>), grid, block, 0, st, p)
   if (Ct != nullptr) {
-    if (loop == 0) hipLaunchKernelGGL((gemm_tn_kernel<true, 0>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((gemm_tn_kernel<true, 1>), grid, block, 0, st, p);
+    if (loop == 1) TN_LAUNCH(true, 1); else TN_LAUNCH(true, 2);
   } else {
-    if (loop == 0) hipLaunchKernelGGL((gemm_tn_kernel<false, 0>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((gemm_tn_kernel<false, 1>), grid, block, 0, st, p);
+    if (loop == 1) TN_LAUNCH(false, 1); else TN_LAUNCH(false, 2);
   }
+#undef TN_LAUNCH
   TN_LAUNCH_CHECK();
   return TN_OK;
 }
