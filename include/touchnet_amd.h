@@ -147,6 +147,18 @@ int tn_adamw_step(float* p, float* m, float* v, const void* g, void* p_shadow_bf
                   long long n, float lr, float beta1, float beta2, float eps, float weight_decay, float max_norm,
                   float bias_corr1, float bias_corr2, int g_dtype, void* stream);
 
+/* multi-tensor step 2 (one launch per gradient dtype for ALL parameters — FSDP shards are 1/N of each tensor, a launch
+ * per tensor would dominate).  tn_adamw_prepare turns norm_sq into the device-side step state (8 floats owned by the
+ * caller, zeroed once): step count — advanced only when the norm is finite, like torch's AdamW on a skipped step —
+ * bias corrections, clip coefficient, skip flag; no host round trip.  Tables as in tn_sumsq_multi with
+ * first_chunk over tn_adamw_multi_chunk(); shadows[t] may be NULL. */
+long long tn_adamw_multi_chunk(void);
+int tn_adamw_prepare(const float* norm_sq, float* state, float beta1, float beta2, float max_norm, void* stream);
+int tn_adamw_multi(void* const* ps, void* const* ms, void* const* vs, const void* const* gs, void* const* shadows,
+                   const long long* sizes, const long long* first_chunk, int ntensors, long long nchunks,
+                   const float* state, float lr, float beta1, float beta2, float eps, float weight_decay, int g_dtype,
+                   void* stream);
+
 /* ---- bf16 transpose for the weight-gradient GEMMs of the linear layers: dst[c*dst_ld + r] = src[r*src_ld + c].
  *      Replaces the implicit operand transposes of torch.nn.functional.linear's backward (every nn.Linear of the
  *      decoder blocks the reference trains, touchnet/bin/train.py:440-470): dW = dY^T X is run with BOTH operands

@@ -115,3 +115,20 @@ def packed_attention_sharded(q_local, k_full, v_full, mask, shard, scale=None):
     p = torch.softmax(s, dim=-1, dtype=torch.float32).to(q_local.dtype)
     p = p * allow.any(-1)[:, None, :, None].to(p.dtype)
     return torch.matmul(p, v).transpose(1, 2).contiguous()
+
+
+# ---- frontend (same call signatures as touchnet_amd.functional; numpy restatements of oracle/frontend.py) ----------
+def kaldi_fbank(wav, num_mel_bins=80):
+    from . import frontend as _fe
+    return torch.from_numpy(_fe.kaldi_fbank(wav.detach().cpu().numpy().reshape(-1), num_mel_bins=num_mel_bins)).float()
+
+
+def log_mel_spectrogram(wav, num_mel_bins=128, padding=0):
+    from . import frontend as _fe
+    return torch.from_numpy(_fe.log_mel_spectrogram(wav.detach().cpu().numpy().reshape(-1), n_mels=num_mel_bins,
+                                                    padding=padding)).float()
+
+
+def audiofeat_stack(feat, stack, stride, normalize=True):
+    from . import frontend as _fe
+    return torch.from_numpy(_fe.audiofeat_stack(feat.detach().cpu().numpy(), stack, stride, normalize)).float()

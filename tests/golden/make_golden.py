@@ -555,9 +555,122 @@ def touchdataset_case():
     save("touchdataset.npz", **out)
 
 
+# ------------------------------------------------------------------ boundary: TrainSpec schema + train.py call sites
+def boundary_case():
+    """Names and order of the reference's TrainSpec fields, the ParallelDims surface, apply_fsdp's parameters, and how
+    touchnet/bin/train.py CALLS the hooks (positional count + keyword names per call site) — all read from the
+    reference's syntax trees (importing these modules drags in torchdata / tensorboard) -> boundary.json (data only)."""
+    import ast
+    import json
+
+    def tree(rel):
+        return ast.parse(open(f"{R.REF}/{rel}").read())
+
+    def klass(t, name):
+        return next(n for n in ast.walk(t) if isinstance(n, ast.ClassDef) and n.name == name)
+
+    spec = klass(tree("touchnet/utils/train_spec.py"), "TrainSpec")
+    fields = [n.target.id for n in spec.body if isinstance(n, ast.AnnAssign)]
+    required = [n.target.id for n in spec.body if isinstance(n, ast.AnnAssign) and n.value is None]
+    calls = {}
+    for node in ast.walk(tree("touchnet/bin/train.py")):
+        if isinstance(node, ast.Call) and isinstance(node.func, ast.Attribute) and node.func.attr in fields:
+            v = node.func.value
+            if isinstance(v, ast.Attribute) and v.attr == "train_spec":
+                calls.setdefault(node.func.attr, []).append(
+                    {"line": node.lineno, "n_positional": len(node.args),
+                     "keywords": [k.arg for k in node.keywords if k.arg is not None],
+                     "star_kwargs": any(k.arg is None for k in node.keywords)})
+    dist_tree = tree("touchnet/utils/distributed.py")
+    dims = klass(dist_tree, "ParallelDims")
+    deco = lambda f: [d.id if isinstance(d, ast.Name) else getattr(d, "attr", "") for d in f.decorator_list]
+    fsdp = next(n for n in ast.walk(tree("touchnet/models/helper_func.py"))
+                if isinstance(n, ast.FunctionDef) and n.name == "apply_fsdp")
+    mesh_names = sorted({c.value for n in ast.walk(dims) if isinstance(n, ast.Constant) and isinstance(n.value, str)
+                         for c in [n] if c.value in ("pp", "dp_replicate", "dp_shard", "cp", "tp", "dp", "dp_shard_cp",
+                                                     "dp_cp")})
+    out = {"train_spec_fields": fields, "train_spec_required": required, "train_py_calls": calls,
+           "parallel_dims": {"fields": [n.target.id for n in dims.body if isinstance(n, ast.AnnAssign)],
+                             "properties": sorted(f.name for f in dims.body if isinstance(f, ast.FunctionDef)
+                                                  and ("property" in deco(f) or "cached_property" in deco(f))),
+                             "mesh_dim_names": mesh_names},
+           "apply_fsdp_params": [a.arg for a in fsdp.args.args]}
+    path = os.path.join(HERE, "boundary.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print(f"wrote boundary.json: {os.path.getsize(path)} bytes")
+
+
+# ------------------------------------------------------------------ Qwen2-Audio SFT samples (token-level content)
+class _CharTokenizer:
+    """Stand-in for the HF tokenizer the reference's processor carries (tokenizers are out of scope): special tokens
+    <|...|> map to fixed ids, every other character to 10 + ord % 200.  Same call surface as used at
+    processing_qwen2_audio.py:83-101."""
+    SPECIAL = {"<|audio_bos|>": 3, "<|AUDIO|>": 4, "<|audio_eos|>": 5}
+    eos_token_id, pad_token_id = 2, 0
+
+    def convert_tokens_to_ids(self, tok):
+        return self.SPECIAL[tok]
+
+    def encode(self, text):
+        ids, i = [], 0
+        while i < len(text):
+            for sp, v in self.SPECIAL.items():
+                if text.startswith(sp, i):
+                    ids.append(v)
+                    i += len(sp)
+                    break
+            else:
+                ids.append(10 + ord(text[i]) % 200)
+                i += 1
+        return ids
+
+    def __call__(self, text, padding=False, return_tensors=None, add_special_tokens=True):
+        ids = self.encode(text)
+        if return_tensors == "pt":
+            return {"input_ids": torch.tensor([ids])}
+        return types.SimpleNamespace(input_ids=ids)
+
+
+def qwen2_audio_data_case():
+    from transformers import WhisperFeatureExtractor
+    mod = R.load_file_as("ref_qwen2_audio_processing", "touchnet/models/qwen2_audio/processing_qwen2_audio.py")
+    proc = types.SimpleNamespace(tokenizer=_CharTokenizer(), feature_extractor=WhisperFeatureExtractor(feature_size=128))
+    rng = np.random.RandomState(11)
+    durs = [0.31, 1.0, 2.503, 0.9999, 31.2, 4.0]                   # seconds; one clip longer than 30 s
+    texts = ["ab", "hello world", "x", "the quick brown fox", "long audio", "tail"]
+    samples = []
+    for d, tx in zip(durs, texts):
+        n = int(d * 16000)
+        samples.append({"waveform": torch.from_numpy((rng.randn(1, n) * 0.05).astype(np.float32)), "txt": tx,
+                        "sample_rate": 16000})
+    samples[2]["instruct"] = "Translate:"
+    cfg = types.SimpleNamespace(dataset_batchsize=1, dataset_text_seqlen=100000, dataloader_drop_last_batch=False,
+                                audio_max_length_in_ms_for_filter=40000, text_min_length_in_tokens_for_filter=1,
+                                text_max_length_in_tokens_for_filter=100000)
+    out = {}
+    for i, smp in enumerate(samples):                                # one reference batch per sample: no padding
+        b = list(mod.dynamic_batch(iter([dict(smp)]), cfg, proc))
+        assert len(b) == 1
+        b = b[0]
+        out[f"s{i}/n_samples"] = np.array(smp["waveform"].shape[1])
+        for k in ("input_ids", "labels", "sentence_lens"):
+            out[f"s{i}/{k}"] = npy(b[k][0])
+        out[f"s{i}/feature_attention_mask_sum"] = np.array(int(b["feature_attention_mask"].sum()))
+        feat = npy(b["input_features"][0])                           # [128, frames]
+        out[f"s{i}/frames"] = np.array(feat.shape[1])
+        out[f"s{i}/mel_head"] = feat[:, :40].astype(np.float32)      # first 40 frames + a strided sample of the rest
+        out[f"s{i}/mel_strided"] = feat[:, ::97].astype(np.float32)
+    out["wave_seed"] = np.array(11)
+    out["durations"] = np.array(durs)
+    out["texts"] = np.array(texts)
+    save("qwen2_audio_data.npz", **out)
+
+
 if __name__ == "__main__":
     only = set(sys.argv[1:])
     for fn in (text_cases, asr_cases, ce_cases, docmask_cases, rope_cases, tiny_llama_case,
-               touch_audio_case, qwen2_audio_tower_case, frontend_cases, fbank_cases, bestrq_cases, touchdataset_case):
+               touch_audio_case, qwen2_audio_tower_case, frontend_cases, fbank_cases, bestrq_cases, touchdataset_case,
+               boundary_case, qwen2_audio_data_case):
         if not only or fn.__name__ in only:
             fn()

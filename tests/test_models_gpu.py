@@ -114,11 +114,26 @@ def test_fused_adamw_matches_torch():
         opt_ref.step()
         assert float(norm) == pytest.approx(float(ref_norm), rel=1e-5)
         torch.testing.assert_close(p.data, q.data, rtol=2e-5, atol=2e-6)
-    # non-finite gradient: the step is skipped on the device
+    # non-finite gradient: the step is skipped on the device — and does NOT advance the step count / bias corrections
     before = p.detach().clone()
     p.grad = torch.full_like(p, float("nan"))
     opt.step()
     torch.testing.assert_close(p.data, before)
+    assert opt.step_count == 4
+    g = torch.randn_like(p)
+    p.grad, q.grad = g.clone(), g.clone()
+    opt.step()
+    torch.nn.utils.clip_grad_norm_([q], 1.0)
+    opt_ref.step()                                        # the reference skipped its step on the NaN norm
+    torch.testing.assert_close(p.data, q.data, rtol=2e-5, atol=2e-6)
+    # checkpoint round trip: a fresh optimizer loaded from state_dict continues identically
+    p2 = torch.nn.Parameter(p.detach().clone())
+    opt2 = FusedAdamW([p2], lr=1e-2, max_norm=1.0)
+    opt2.load_state_dict(opt.state_dict())
+    g = torch.randn_like(p)
+    p.grad, p2.grad = g.clone(), g.clone()
+    opt.step(), opt2.step()
+    assert torch.equal(p.data, p2.data) and opt2.step_count == opt.step_count == 6
     # bf16 parameter + fp32 master
     pb = torch.nn.Parameter(torch.randn(4096, device=DEV).bfloat16())
     ob = FusedAdamW([pb], lr=1e-2, max_norm=0.0)
@@ -126,6 +141,33 @@ def test_fused_adamw_matches_torch():
     ob.step()
     assert ob.state[0]["master"].dtype == torch.float32
     torch.testing.assert_close(pb.data, ob.state[0]["master"].bfloat16())
+
+
+def test_fused_adamw_multi_tensor_mixed_shapes():
+    """ONE launch over many tensors (odd sizes, unaligned views, fp32 and bf16 gradients, a parameter without gradient)
+    == torch.optim.AdamW + clip_grad_norm_ over the same set."""
+    from touchnet_amd.utils.optimizer import FusedAdamW
+    torch.manual_seed(1)
+    shapes = [(4096, 64), (33,), (1000, 7), (5,), (128, 130), (70000,)]
+    flat = torch.randn(100003, device=DEV)
+    ps = [torch.nn.Parameter(torch.randn(*s, device=DEV)) for s in shapes]
+    ps.append(torch.nn.Parameter(flat[3:3 + 4097].detach()))          # 4-byte aligned only: scalar path
+    ps.append(torch.nn.Parameter(torch.randn(10, device=DEV)))         # never receives a gradient
+    qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    opt = FusedAdamW(ps, lr=3e-3, max_norm=0.7)
+    ref = torch.optim.AdamW(qs, lr=3e-3, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.1)
+    for it in range(3):
+        for i, (p, q) in enumerate(zip(ps[:-1], qs[:-1])):
+            g = torch.randn_like(p) * (0.1 + i)
+            if i % 2:                                                    # bf16 gradients for half of the tensors
+                g = g.bfloat16()
+            p.grad, q.grad = g.clone(), g.float().clone()
+        norm = opt.step()
+        ref_norm = torch.nn.utils.clip_grad_norm_(qs[:-1], 0.7)
+        ref.step()
+        assert float(norm) == pytest.approx(float(ref_norm), rel=2e-5)
+        for p, q in zip(ps, qs):
+            torch.testing.assert_close(p.data, q.data, rtol=3e-5, atol=3e-6)
 
 
 def test_qwen2_audio_packed_forward_backward_small():

@@ -22,8 +22,7 @@ from typing import Optional
 import torch
 import torch.distributed as dist
 
-from touchnet_amd.models.helper_func import apply_fsdp
-from touchnet_amd.utils.distributed import dist_sum
+from touchnet_amd.utils.distributed import ParallelDims, dist_sum
 from touchnet_amd.utils.optimizer import FusedAdamW, linear_warmup_linear_decay
 from touchnet_amd.utils.train_spec import TrainSpec, get_train_spec
 
@@ -37,6 +36,10 @@ class TrainConfig:
     training_mixed_precision_param: str = "bfloat16"
     training_mixed_precision_reduce: str = "float32"
     training_fsdp_reshard_after_forward: str = "never"
+    training_activation_checkpoint_mode: str = "none"             # "none" | "full" | "selective"
+    training_activation_checkpoint_selective_ac_option: str = "2"
+    training_compile: bool = False
+    training_enable_cpu_offload: bool = False
     training_enable_fused_ce: bool = True      # role of `training_enable_liger_kernel`'s fused-linear-CE branch
     training_ce_chunk_tokens: int = 16384
     training_cp_halo_exchange: bool = True     # CP: point-to-point exchange of the K/V chunks a rank can see (else all-gather)
@@ -45,6 +48,30 @@ class TrainConfig:
     lr_scheduler_warmup_steps: int = 2000
     lr_scheduler_steps: int = 100000
     optimizer_weight_decay: float = 0.1
+
+
+class _MeshView:
+    """The slice of a world mesh `parallelize_fn` indexes: `world_mesh["dp_shard_cp"]` / `world_mesh[("dp_shard_cp",)]`."""
+
+    def __init__(self, by_name):
+        self.by_name = by_name
+        self.ndim = len(by_name)
+
+    def __getitem__(self, names):
+        names = (names,) if isinstance(names, str) else tuple(names)
+        if len(names) != 1:
+            raise KeyError(names)
+        return self.by_name[names[0]]
+
+
+class _ForceShard:
+    """ParallelDims view whose `dp_shard_enabled` is True on a 1-rank mesh (TN_FORCE_FSDP=1)."""
+
+    def __init__(self, dims):
+        self._d = dims
+
+    def __getattr__(self, k):
+        return True if k == "dp_shard_enabled" else getattr(self._d, k)
 
 
 class Trainer:
@@ -74,8 +101,21 @@ class Trainer:
         self.model_config = model_config
         self.num_params = self.spec.get_num_params_fn(model)
         self.num_params_wo_emb = self.spec.get_num_params_fn(model, exclude_embedding=True)
-        if sharded:
-            model = self.spec.parallelize_fn(model, fsdp_mesh, job)    # fp32 shards, bf16 compute
+        if self.cp_group is not None and not sharded:
+            # gradients are only reduced across cp ranks by the FSDP reduce-scatter over dp x cp: without it the
+            # replicas would silently diverge (the reference always shards over `dp_shard_cp` when cp > 1)
+            raise ValueError("context parallelism needs parameter sharding over a mesh that includes the cp ranks: "
+                             "pass fsdp_mesh = the flattened dp x cp mesh")
+        ac = job.training_activation_checkpoint_mode != "none"
+        if sharded or ac:
+            # the hook is called the way the reference trainer calls it (train.py:259-261): meta model, the mesh
+            # indexed by the reference's dimension names, ParallelDims, job config
+            n = fsdp_mesh.size() if sharded else 1
+            dims = ParallelDims(dp_replicate=1, dp_shard=n, cp=1, tp=1, pp=1, world_size=n)
+            if sharded and n == 1:                                 # TN_FORCE_FSDP on one rank: still take the FSDP branch
+                dims = _ForceShard(dims)
+            model = self.spec.parallelize_fn(model, _MeshView({"dp_shard_cp": fsdp_mesh}), dims, job)
+        if sharded:                                                # fp32 shards, bf16 compute
             model.to_empty(device=device)
             with torch.no_grad():
                 model.post_init()
@@ -112,6 +152,9 @@ class Trainer:
             T = out["labels"].shape[1]
             if self.cp is None or self.cp.T != T:
                 self.cp = ContextParallel(self.cp_group, T)
+            if not isinstance(out.get("attention_mask"), torch.Tensor):
+                # plain causal rows (the Qwen2-Audio path without packing): one document per row, GLOBAL length
+                out["attention_mask"] = torch.ones(out["labels"].shape[0], T, dtype=torch.int64, device=self.device)
             if self.job.training_cp_halo_exchange:                      # document ids: from the HOST copy when there is one
                 src = batch.get("attention_mask")
                 self.cp.set_documents(src if isinstance(src, torch.Tensor) else out["attention_mask"])

@@ -17,7 +17,7 @@ from touchnet_amd.models.backend import ops
 
 def _dev_wave(sample):
     w = sample["waveform"]
-    if not w.is_cuda:
+    if not w.is_cuda and torch.cuda.is_available():      # (without a GPU the HIP ops below refuse the tensor loudly)
         w = w.to(torch.device("cuda", torch.cuda.current_device()), non_blocking=True)
     if w.dtype == torch.int16:
         w = ops().pcm16_to_float(w)
@@ -46,4 +46,34 @@ def audiofeat_stack(data, config):
         sample["audiofeat"] = ops().audiofeat_stack(sample["audiofeat"], config.audiofeat_stack_length,
                                                     config.audiofeat_stride_length,
                                                     bool(config.audiofeat_normalize))
+        yield sample
+
+
+# ---- host stages (pure bookkeeping; same generator signatures as touchnet/data/functions.py:32-80) -------------------
+def text_tokenize(data, tokenizer):
+    """functions.py:32-49: `txt` -> `input_ids` with the reference's tokenizer object (tokenizers themselves are out
+    of scope and stay the reference's); bos/eos are added by the packers."""
+    for sample in data:
+        if "txt" in sample:
+            sample["input_ids"] = tokenizer.tokenize(sample["txt"], add_special_tokens=False)
+        yield sample
+
+
+def filter_samples(data, config):
+    """functions.py:52-80: drop samples by token count, audio duration (ms) and tokens per 10 ms of audio."""
+    for sample in data:
+        ntok = len(sample["input_ids"]) if "input_ids" in sample else None
+        if ntok is not None and not (config.text_min_length_in_tokens_for_filter <= ntok
+                                     <= config.text_max_length_in_tokens_for_filter):
+            continue
+        if "waveform" in sample:
+            ms = sample["waveform"].size(1) / sample["sample_rate"] * 1000.0
+            if config.audio_speed_perturb:
+                ms *= max(config.audio_speed_perturb_speeds)
+            if not (config.audio_min_length_in_ms_for_filter <= ms <= config.audio_max_length_in_ms_for_filter):
+                continue
+            if ntok is not None and ms > 1e-7:
+                ratio = ntok / (ms / 10)
+                if not (config.min_text_audio_ratio <= ratio <= config.max_text_audio_ratio):
+                    continue
         yield sample

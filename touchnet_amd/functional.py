@@ -18,6 +18,7 @@ from typing import Optional
 import torch
 
 from . import _C
+from . import library as L
 
 _cur = _C.stream
 _p = _C.ptr
@@ -28,134 +29,26 @@ def _c(t: torch.Tensor) -> torch.Tensor:
 
 
 # ------------------------------------------------------------------------------------ norms
-class _RMSNorm(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, residual, weight, eps):
-        H = x.shape[-1]
-        x2 = _c(x).view(-1, H)
-        rows = x2.shape[0]
-        r2 = _c(residual).view(-1, H) if residual is not None else None
-        w = _c(weight).to(x.dtype)
-        y = torch.empty_like(x2)
-        h = torch.empty_like(x2) if r2 is not None else x2
-        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
-        _C.check(_C.lib().tn_rmsnorm_fwd(_p(x2), _p(r2), _p(w), _p(y), _p(h) if r2 is not None else None,
-                                         _p(rstd), rows, H, float(eps), _C.dcode(x2), _cur()), "tn_rmsnorm_fwd")
-        ctx.save_for_backward(h, w, rstd)
-        ctx.has_res = r2 is not None
-        ctx.wdtype = weight.dtype
-        if r2 is not None:
-            return y.view(x.shape), h.view(x.shape)
-        return y.view(x.shape)
-
-    @staticmethod
-    def backward(ctx, dy, dh_new=None):
-        h, w, rstd = ctx.saved_tensors
-        rows, H = h.shape
-        dy2 = _c(dy).view(rows, H)
-        dres = _c(dh_new).view(rows, H) if dh_new is not None else None
-        dh = torch.empty_like(h)
-        dw = torch.empty(H, dtype=h.dtype, device=h.device)
-        ws = torch.empty(_C.lib().tn_norm_bwd_workspace_floats(rows, H), dtype=torch.float32, device=h.device)
-        _C.check(_C.lib().tn_rmsnorm_bwd(_p(dy2), _p(h), _p(w), _p(rstd), _p(dres), _p(dh), _p(dw), _p(ws), rows, H,
-                                         _C.dcode(h), _cur()), "tn_rmsnorm_bwd")
-        dh = dh.view(dy.shape)
-        return dh, (dh if ctx.has_res else None), dw.to(ctx.wdtype), None
-
-
 def rms_norm(x, weight, eps, residual=None):
     """y = RMSNorm(x (+ residual)) * weight.  With ``residual`` returns ``(y, x + residual)``: the
     residual add of the decoder layer (modeling_llama.py:306-324) is fused into the norm that follows it."""
-    return _RMSNorm.apply(x, residual, weight, eps)
-
-
-class _LayerNorm(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, residual, weight, bias, eps):
-        H = x.shape[-1]
-        x2 = _c(x).view(-1, H)
-        rows = x2.shape[0]
-        r2 = _c(residual).view(-1, H) if residual is not None else None
-        w, b = _c(weight).to(x.dtype), _c(bias).to(x.dtype)
-        y = torch.empty_like(x2)
-        h = torch.empty_like(x2) if r2 is not None else x2
-        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
-        rstd = torch.empty_like(mean)
-        _C.check(_C.lib().tn_layernorm_fwd(_p(x2), _p(r2), _p(w), _p(b), _p(y), _p(h) if r2 is not None else None,
-                                           _p(mean), _p(rstd), rows, H, float(eps), _C.dcode(x2), _cur()),
-                 "tn_layernorm_fwd")
-        ctx.save_for_backward(h, w, mean, rstd)
-        ctx.has_res = r2 is not None
-        ctx.wdtype = weight.dtype
-        if r2 is not None:
-            return y.view(x.shape), h.view(x.shape)
-        return y.view(x.shape)
-
-    @staticmethod
-    def backward(ctx, dy, dh_new=None):
-        h, w, mean, rstd = ctx.saved_tensors
-        rows, H = h.shape
-        dy2 = _c(dy).view(rows, H)
-        dres = _c(dh_new).view(rows, H) if dh_new is not None else None
-        dh = torch.empty_like(h)
-        dw = torch.empty(H, dtype=h.dtype, device=h.device)
-        db = torch.empty_like(dw)
-        ws = torch.empty(_C.lib().tn_norm_bwd_workspace_floats(rows, H), dtype=torch.float32, device=h.device)
-        _C.check(_C.lib().tn_layernorm_bwd(_p(dy2), _p(h), _p(w), _p(mean), _p(rstd), _p(dres), _p(dh), _p(dw),
-                                           _p(db), _p(ws), rows, H, _C.dcode(h), _cur()), "tn_layernorm_bwd")
-        dh = dh.view(dy.shape)
-        return dh, (dh if ctx.has_res else None), dw.to(ctx.wdtype), db.to(ctx.wdtype), None
+    y, h, _ = L.rmsnorm_fwd(x, residual, weight, float(eps))
+    return (y, h) if residual is not None else y
 
 
 def layer_norm(x, weight, bias, eps=1e-5, residual=None):
-    return _LayerNorm.apply(x, residual, weight, bias, eps)
+    y, h, _, _ = L.layernorm_fwd(x, residual, weight, bias, float(eps))
+    return (y, h) if residual is not None else y
 
 
 # ------------------------------------------------------------------------------------ activations
-class _SwiGLU(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, gate, up):
-        g, u = _c(gate), _c(up)
-        out = torch.empty_like(g)
-        _C.check(_C.lib().tn_swiglu_fwd(_p(g), _p(u), _p(out), g.numel(), _C.dcode(g), _cur()), "tn_swiglu_fwd")
-        ctx.save_for_backward(g, u)
-        return out
-
-    @staticmethod
-    def backward(ctx, dout):
-        g, u = ctx.saved_tensors
-        d = _c(dout)
-        dg, du = torch.empty_like(g), torch.empty_like(u)
-        _C.check(_C.lib().tn_swiglu_bwd(_p(d), _p(g), _p(u), _p(dg), _p(du), g.numel(), _C.dcode(g), _cur()),
-                 "tn_swiglu_bwd")
-        return dg, du
-
-
 def swiglu(gate, up):
     """silu(gate) * up (modeling_llama.py:174-176)."""
-    return _SwiGLU.apply(gate, up)
-
-
-class _GELU(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x):
-        x = _c(x)
-        out = torch.empty_like(x)
-        _C.check(_C.lib().tn_gelu_fwd(_p(x), _p(out), x.numel(), _C.dcode(x), _cur()), "tn_gelu_fwd")
-        ctx.save_for_backward(x)
-        return out
-
-    @staticmethod
-    def backward(ctx, dout):
-        (x,) = ctx.saved_tensors
-        d = _c(dout)
-        dx = torch.empty_like(x)
-        _C.check(_C.lib().tn_gelu_bwd(_p(d), _p(x), _p(dx), x.numel(), _C.dcode(x), _cur()), "tn_gelu_bwd")
-        return dx
+    return L.swiglu_fwd(gate, up)
 
 
 def gelu(x):
-    return _GELU.apply(x)
+    return L.gelu_fwd(x)
 
 
 # ------------------------------------------------------------------------------------ RoPE
@@ -182,41 +75,14 @@ def rope_tables(position_ids: torch.Tensor, inv_freq: torch.Tensor, dtype, atten
     """cos/sin [B*T, D/2] in ``dtype`` from packed int64 position_ids [B, T] (once per forward)."""
     pos = _c(position_ids).to(torch.int64).view(-1)
     inv = _c(inv_freq).float()
-    n, half = pos.numel(), inv.numel()
-    cos = torch.empty(n, half, dtype=dtype, device=pos.device)
-    sin = torch.empty_like(cos)
-    _C.check(_C.lib().tn_rope_table(_p(pos), _p(inv), _p(cos), _p(sin), n, half, float(attention_scaling),
-                                    _C.dcode(cos), _cur()), "tn_rope_table")
-    return cos, sin
-
-
-class _RoPE(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, q, k, cos, sin):
-        q, k = _c(q), _c(k)
-        B, T, hq, D = q.shape
-        hk = k.shape[2]
-        qo, ko = torch.empty_like(q), torch.empty_like(k)
-        _C.check(_C.lib().tn_rope_apply(_p(q), _p(k), _p(qo), _p(ko), _p(cos), _p(sin), B * T, hq, hk, D, 0,
-                                        _C.dcode(q), _cur()), "tn_rope_apply")
-        ctx.save_for_backward(cos, sin)
-        return qo, ko
-
-    @staticmethod
-    def backward(ctx, dq, dk):
-        cos, sin = ctx.saved_tensors
-        dq, dk = _c(dq), _c(dk)
-        B, T, hq, D = dq.shape
-        hk = dk.shape[2]
-        gq, gk = torch.empty_like(dq), torch.empty_like(dk)
-        _C.check(_C.lib().tn_rope_apply(_p(dq), _p(dk), _p(gq), _p(gk), _p(cos), _p(sin), B * T, hq, hk, D, 1,
-                                        _C.dcode(dq), _cur()), "tn_rope_apply(bwd)")
-        return gq, gk, None, None
+    if dtype not in _C.DTYPE_CODE:
+        raise _C.KernelError(f"unsupported dtype {dtype} (float32 / bfloat16 only)")
+    return L.rope_table(pos, inv, float(attention_scaling), dtype)
 
 
 def apply_rope(q, k, cos, sin):
     """q [B,T,Nh,D], k [B,T,Nkv,D] (the GEMM output layout — no head transpose), tables from rope_tables."""
-    return _RoPE.apply(q, k, cos, sin)
+    return L.rope_apply(q, k, cos, sin, False)
 
 
 # ------------------------------------------------------------------------------------ attention
@@ -234,9 +100,7 @@ class PackedMask:
 def build_packed_mask(doc_ids: torch.Tensor) -> PackedMask:
     B, T = doc_ids.shape
     doc = _c(doc_ids).to(torch.int32)
-    meta = torch.empty(_C.lib().tn_attn_meta_ints(B, T), dtype=torch.int32, device=doc.device)
-    _C.check(_C.lib().tn_attn_build_meta(_p(doc), _p(meta), B, T, _cur()), "tn_attn_build_meta")
-    return PackedMask(doc, meta, B, T)
+    return PackedMask(doc, L.attn_build_meta(doc), B, T)
 
 
 def causal_mask(B: int, T: int, device) -> PackedMask:
@@ -245,44 +109,13 @@ def causal_mask(B: int, T: int, device) -> PackedMask:
     return build_packed_mask(torch.ones(B, T, dtype=torch.int32, device=device))
 
 
-class _PackedAttention(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, q, k, v, mask: PackedMask, scale):
-        q, k, v = _c(q), _c(k), _c(v)
-        if q.dtype != torch.bfloat16:
-            raise _C.KernelError("packed_attention: bf16 only (MFMA 32x32x16 bf16 kernel)")
-        B, T, Nh, D = q.shape
-        Nkv = k.shape[2]
-        if (B, T) != (mask.B, mask.T):
-            raise _C.KernelError(f"mask built for {(mask.B, mask.T)}, got q {(B, T)}")
-        o = torch.empty_like(q)
-        lse2 = torch.empty(B, Nh, T, dtype=torch.float32, device=q.device)
-        _C.check(_C.lib().tn_attn_fwd(_p(q), _p(k), _p(v), _p(o), _p(lse2), _p(mask.doc), _p(mask.meta), B, T, Nh,
-                                      Nkv, D, float(scale), _cur()), "tn_attn_fwd")
-        ctx.save_for_backward(q, k, v, o, lse2)
-        ctx.mask, ctx.scale = mask, float(scale)
-        return o
-
-    @staticmethod
-    def backward(ctx, do):
-        q, k, v, o, lse2 = ctx.saved_tensors
-        do = _c(do)
-        B, T, Nh, D = q.shape
-        Nkv = k.shape[2]
-        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-        delta = torch.empty_like(lse2)
-        m = ctx.mask
-        _C.check(_C.lib().tn_attn_bwd(_p(q), _p(k), _p(v), _p(o), _p(do), _p(lse2), _p(delta), _p(dq), _p(dk),
-                                      _p(dv), _p(m.doc), _p(m.meta), B, T, Nh, Nkv, D, ctx.scale, _cur()),
-                 "tn_attn_bwd")
-        return dq, dk, dv, None, None
-
-
 def packed_attention(q, k, v, mask: PackedMask, scale: Optional[float] = None):
     """softmax(scale * Q K^T + doc-causal mask) V with q [B,T,Nh,D], k/v [B,T,Nkv,D] -> [B,T,Nh,D]."""
     if scale is None:
         scale = q.shape[-1] ** -0.5
-    return _PackedAttention.apply(q, k, v, mask, scale)
+    if tuple(q.shape[:2]) != (mask.B, mask.T):
+        raise _C.KernelError(f"mask built for {(mask.B, mask.T)}, got q {tuple(q.shape[:2])}")
+    return L.attn_fwd(q, k, v, mask.doc, mask.meta, float(scale))[0]
 
 
 @dataclass(frozen=True)
@@ -292,44 +125,8 @@ class SeqShard:
     segs: tuple
     rows_per_batch: int
 
-    def host_array(self):
-        import ctypes
-        flat = [v for seg in self.segs for v in seg] + [0] * (6 - 3 * len(self.segs))
-        return (ctypes.c_int * 6)(*flat)
-
-
-class _ShardedAttention(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, q, k_full, v_full, mask: PackedMask, shard: SeqShard, scale):
-        q, k, v = _c(q), _c(k_full), _c(v_full)
-        if q.dtype != torch.bfloat16:
-            raise _C.KernelError("packed_attention_sharded: bf16 only")
-        B, R, Nh, D = q.shape
-        T, Nkv = k.shape[1], k.shape[2]
-        if (B, T) != (mask.B, mask.T) or R != shard.rows_per_batch:
-            raise _C.KernelError(f"mask {(mask.B, mask.T)} / shard {shard.rows_per_batch} vs q {(B, R)} k {(B, T)}")
-        o = torch.empty_like(q)
-        lse2 = torch.empty(B, Nh, R, dtype=torch.float32, device=q.device)
-        segs = shard.host_array()
-        _C.check(_C.lib().tn_attn_fwd_seg(_p(q), _p(k), _p(v), _p(o), _p(lse2), _p(mask.doc), _p(mask.meta), B, T, Nh,
-                                          Nkv, D, float(scale), len(shard.segs), segs, R, _cur()), "tn_attn_fwd_seg")
-        ctx.save_for_backward(q, k, v, o, lse2)
-        ctx.mask, ctx.shard, ctx.scale = mask, shard, float(scale)
-        return o
-
-    @staticmethod
-    def backward(ctx, do):
-        q, k, v, o, lse2 = ctx.saved_tensors
-        do = _c(do)
-        B, R, Nh, D = q.shape
-        T, Nkv = k.shape[1], k.shape[2]
-        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-        delta = torch.empty_like(lse2)
-        m, sh = ctx.mask, ctx.shard
-        _C.check(_C.lib().tn_attn_bwd_seg(_p(q), _p(k), _p(v), _p(o), _p(do), _p(lse2), _p(delta), _p(dq), _p(dk),
-                                          _p(dv), _p(m.doc), _p(m.meta), B, T, Nh, Nkv, D, ctx.scale, len(sh.segs),
-                                          sh.host_array(), R, _cur()), "tn_attn_bwd_seg")
-        return dq, dk, dv, None, None, None
+    def flat(self):
+        return [int(v) for seg in self.segs for v in seg]
 
 
 def packed_attention_sharded(q_local, k_full, v_full, mask: PackedMask, shard: SeqShard,
@@ -338,7 +135,8 @@ def packed_attention_sharded(q_local, k_full, v_full, mask: PackedMask, shard: S
     The gradient w.r.t. k_full / v_full is this rank's PARTIAL sum (to be reduce-scattered by the caller)."""
     if scale is None:
         scale = q_local.shape[-1] ** -0.5
-    return _ShardedAttention.apply(q_local, k_full, v_full, mask, shard, scale)
+    return L.attn_fwd_seg(q_local, k_full, v_full, mask.doc, mask.meta, float(scale), shard.flat(),
+                          int(shard.rows_per_batch))[0]
 
 
 # ------------------------------------------------------------------------------------ loss
@@ -348,41 +146,37 @@ def _num_sentence_dev(num_sentence, device):
     return torch.tensor([float(num_sentence)], dtype=torch.float32, device=device)
 
 
-class _PackedCE(torch.autograd.Function):
+class _PackedCEInplace(torch.autograd.Function):
+    """`inplace_grad=True`: the backward writes dlogits over the logits (dead after the loss): mi355_touch::ce_bwd_."""
+
     @staticmethod
-    def forward(ctx, pred, labels, sentence_lens, num_sentence, ignore_index, inplace_grad):
-        V = pred.shape[-1]
-        logits = _c(pred).view(-1, V)
-        n = logits.shape[0]
-        lab = _c(labels).to(torch.int64).view(-1)
-        sl = _c(sentence_lens).to(torch.int64).view(-1)
-        ns = _num_sentence_dev(num_sentence, pred.device)
-        nll = torch.empty(n, dtype=torch.float32, device=pred.device)
-        lse = torch.empty_like(nll)
-        hit = torch.empty(n, dtype=torch.int32, device=pred.device)
-        out = torch.empty(4, dtype=torch.float32, device=pred.device)
-        _C.check(_C.lib().tn_ce_forward(_p(logits), _p(lab), _p(sl), _p(ns), _p(nll), _p(lse), _p(hit), _p(out), n, V,
-                                        int(ignore_index), _C.dcode(logits), _cur()), "tn_ce_forward")
+    def forward(ctx, logits, lab, sl, ns, ignore_index):
+        with torch.no_grad():
+            loss, out, lse = L.ce_fwd(logits, lab, sl, ns, ignore_index)
         ctx.save_for_backward(logits, lab, sl, lse, ns)
-        ctx.ignore_index, ctx.shape, ctx.inplace = int(ignore_index), pred.shape, bool(inplace_grad)
+        ctx.ignore_index = ignore_index
         ctx.mark_non_differentiable(out)
-        return out[0].clone(), out
+        return loss, out
 
     @staticmethod
     def backward(ctx, g_loss, _g_out):
         logits, lab, sl, lse, ns = ctx.saved_tensors
-        n, V = logits.shape
-        g = _c(g_loss).to(torch.float32).reshape(1)
-        dlog = logits if ctx.inplace else torch.empty_like(logits)
-        _C.check(_C.lib().tn_ce_backward(_p(logits), _p(dlog), _p(lab), _p(sl), _p(lse), _p(ns), _p(g), n, V,
-                                         ctx.ignore_index, _C.dcode(logits), _cur()), "tn_ce_backward")
-        return dlog.view(ctx.shape), None, None, None, None, None
+        L.ce_bwd_(logits, lab, sl, lse, ns, _c(g_loss).to(torch.float32).reshape(1), ctx.ignore_index)
+        return logits, None, None, None, None
 
 
 def packed_cross_entropy(pred, labels, sentence_lens, num_sentence, ignore_index=-100, inplace_grad=False):
     """Returns ``(loss_per_sample [differentiable], stats)`` with
     ``stats = [loss_per_sample, loss_per_token, accuracy, n_valid]`` (fp32 device tensor, no host sync)."""
-    return _PackedCE.apply(pred, labels, sentence_lens, num_sentence, ignore_index, inplace_grad)
+    V = pred.shape[-1]
+    logits = _c(pred).view(-1, V)
+    lab = _c(labels).to(torch.int64).view(-1)
+    sl = _c(sentence_lens).to(torch.int64).view(-1)
+    ns = _num_sentence_dev(num_sentence, pred.device)
+    if inplace_grad:
+        return _PackedCEInplace.apply(logits, lab, sl, ns, int(ignore_index))
+    loss, stats, _ = L.ce_fwd(logits, lab, sl, ns, int(ignore_index))
+    return loss, stats.detach()
 
 
 class _FusedLinearCE(torch.autograd.Function):
@@ -414,29 +208,24 @@ class _FusedLinearCE(torch.autograd.Function):
         n, V = h2.shape[0], weight.shape[0]
         ns = _num_sentence_dev(num_sentence, hidden.device)
         one = torch.ones(1, dtype=torch.float32, device=hidden.device)
-        nll = torch.empty(n, dtype=torch.float32, device=hidden.device)
-        lse = torch.empty_like(nll)
-        hit = torch.empty(n, dtype=torch.int32, device=hidden.device)
-        out = torch.empty(4, dtype=torch.float32, device=hidden.device)
         dh = torch.empty_like(h2)
         dw = None
-        lib, p, st = _C.lib(), _C.ptr, _C.stream
+        parts = []
         for s in range(0, n, chunk):
             e = min(s + chunk, n)
-            logits = torch.nn.functional.linear(h2[s:e], weight)              # [c, V]
-            _C.check(lib.tn_ce_forward(p(logits), p(lab[s:e]), p(sl[s:e]), p(ns), p(nll[s:e]), p(lse[s:e]),
-                                       p(hit[s:e]), None, e - s, V, int(ignore_index), _C.dcode(logits), st()),
-                     "tn_ce_forward")
-            _C.check(lib.tn_ce_backward(p(logits), p(logits), p(lab[s:e]), p(sl[s:e]), p(lse[s:e]), p(ns), p(one),
-                                        e - s, V, int(ignore_index), _C.dcode(logits), st()), "tn_ce_backward")
+            logits = torch.nn.functional.linear(h2[s:e], weight)              # [c, V]: the only logits alive
+            nll_c, lse_c, hit_c = L.ce_fwd_rows(logits, lab[s:e], sl[s:e], ns, int(ignore_index))
+            L.ce_bwd_(logits, lab[s:e], sl[s:e], lse_c, ns, one, int(ignore_index))       # logits := dlogits
+            parts.append((nll_c, hit_c))
             torch.mm(logits, weight, out=dh[s:e])                             # dh = dlogits @ W
             if dw is None:
                 dw = torch.mm(logits.t(), h2[s:e])                            # dW = dlogits^T @ h
             else:
-                dw.addmm_(logits.t(), h2[s:e])                                # fp32 accumulate inside the GEMM
+                dw.addmm_(logits.t(), h2[s:e])                                # accumulate inside the GEMM epilogue
             del logits
-        _C.check(lib.tn_ce_reduce(p(nll), p(hit), p(lab), p(sl), p(ns), p(out), n, int(ignore_index), st()),
-                 "tn_ce_reduce")
+        nll = torch.cat([a for a, _ in parts]) if len(parts) > 1 else parts[0][0]
+        hit = torch.cat([b for _, b in parts]) if len(parts) > 1 else parts[0][1]
+        out = L.ce_reduce(nll, hit, lab, sl, ns, int(ignore_index))
         if rows is not None:                                   # scatter d(hidden) back; ignored rows stay 0
             dh = torch.zeros(n_all, H, dtype=dh.dtype, device=dh.device).index_copy_(0, rows, dh)
         ctx.save_for_backward(dh, dw)
@@ -452,7 +241,7 @@ class _FusedLinearCE(torch.autograd.Function):
 
 
 def fused_linear_cross_entropy(hidden, weight, labels, sentence_lens, num_sentence, ignore_index=-100,
-                               chunk_tokens=16384, compact=False):
+                               chunk_tokens=4096, compact=False):
     """Returns ``(loss_per_sample [differentiable], stats)`` like packed_cross_entropy, from hidden states.
     ``compact=True``: run lm_head only on the labelled positions (see _FusedLinearCE.forward)."""
     return _FusedLinearCE.apply(hidden, weight, labels, sentence_lens, num_sentence, ignore_index, chunk_tokens,
@@ -462,25 +251,21 @@ def fused_linear_cross_entropy(hidden, weight, labels, sentence_lens, num_senten
 # ------------------------------------------------------------------------------------ linear layers
 def transpose_2d(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``out[c, r] = x[r, c]`` for a bf16 matrix whose rows are contiguous (row stride >= cols), HIP kernel."""
-    if x.dim() != 2 or x.dtype != torch.bfloat16 or not x.is_cuda or x.stride(1) != 1:
+    if x.dim() != 2 or x.dtype != torch.bfloat16 or not (x.is_cuda or x.is_meta) or x.stride(1) != 1:
         raise RuntimeError("transpose_2d: expects a 2-D bf16 device tensor with contiguous rows")
     R, Cn = x.shape
     if out is None:
         out = torch.empty(Cn, R, dtype=x.dtype, device=x.device)
-    _C.check(_C.lib().tn_transpose_bf16(_p(x), _p(out), R, Cn, x.stride(0), out.stride(0), _cur()),
-             "tn_transpose_bf16")
+    L.transpose_bf16_(x, out)
     return out
 
 
 def column_sum(x: torch.Tensor) -> torch.Tensor:
     """``x.sum(0)`` of a bf16 [rows, cols] device matrix (fp32 accumulation, bf16 result): the bias gradient."""
     R, Cn = x.shape
-    if x.dtype != torch.bfloat16 or not x.is_cuda or x.stride(1) != 1 or Cn % 8 or x.stride(0) % 8:
+    if x.dtype != torch.bfloat16 or not (x.is_cuda or x.is_meta) or x.stride(1) != 1 or Cn % 8 or x.stride(0) % 8:
         return x.sum(0)                                    # (fp32 / odd widths: torch's reduction, still on the device)
-    ws = torch.empty(int(_C.lib().tn_colsum_workspace_floats(R, Cn)), dtype=torch.float32, device=x.device)
-    out = torch.empty(Cn, dtype=x.dtype, device=x.device)
-    _C.check(_C.lib().tn_colsum_bf16(_p(x), _p(out), _p(ws), R, Cn, x.stride(0), _cur()), "tn_colsum_bf16")
-    return out
+    return L.colsum_bf16(x)
 
 
 def gemm_tn(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
@@ -550,7 +335,7 @@ class _LinearGroup(torch.autograd.Function):
                for d, w in zip(dys, ws)]
         need_x, need_w = ctx.needs_input_grad[0], [ctx.needs_input_grad[4 + i] for i in range(n)]
         Ns = [w.shape[0] for w in ws]
-        hip_ok = x.dtype == torch.bfloat16 and x.is_cuda and _tn_ok(M, K, Ns)
+        hip_ok = x.dtype == torch.bfloat16 and (x.is_cuda or x.is_meta) and _tn_ok(M, K, Ns)
         dx = None
         if need_x:
             wv = [transpose_2d(_c(w)).t() for w in ws] if (hip_ok and ctx.dgrad_tn) else ws   # [N, K] views of W^T
@@ -584,7 +369,7 @@ def linear_group(x, layers, wgrad: str = "tn", dgrad_tn: bool = True):
     """``layers``: list of (weight [N_i, K], bias [N_i] | None) sharing the input ``x`` -> list of outputs."""
     if wgrad not in ("tn", "nt", "nt_fused"):
         raise ValueError(f"linear_group: wgrad={wgrad!r}")
-    if not x.is_cuda:
+    if not (x.is_cuda or x.is_meta):
         raise _C.KernelError("linear_group: device tensors only (the product path has no CPU fallback)")
     ws = [w for w, _ in layers]
     bs = [b for _, b in layers]
@@ -602,14 +387,11 @@ class _SwiGLUMLP(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, wg, wu, wd):
-        lib = _C.lib()
         K, I = x.shape[-1], wg.shape[0]
         x2 = _c(x.reshape(-1, K))
         M = x2.shape[0]
         gate, up = torch.mm(x2, wg.t()), torch.mm(x2, wu.t())
-        act = torch.empty_like(gate)
-        act_t = torch.empty(I, M, dtype=x.dtype, device=x.device)
-        _C.check(lib.tn_swiglu_fwd_t(_p(gate), _p(up), _p(act), _p(act_t), M, I, _cur()), "tn_swiglu_fwd_t")
+        act, act_t = L.swiglu_fwd_t(gate, up)
         y = torch.mm(act, wd.t())
         ctx.save_for_backward(x2, gate, up, act_t, wg, wu, wd)
         ctx.xshape = x.shape
@@ -618,17 +400,13 @@ class _SwiGLUMLP(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x2, gate, up, act_t, wg, wu, wd = ctx.saved_tensors
-        lib = _C.lib()
         M, K = x2.shape
         I, H = wg.shape[0], wd.shape[0]
         dy2 = _c(dy).reshape(M, H)
         nx, ng, nu, nd = ctx.needs_input_grad
         dwd = torch.mm(transpose_2d(dy2), act_t.t()) if nd else None               # [H, I], forward layout
         dact = torch.mm(dy2, transpose_2d(_c(wd)).t())                              # [M, I]
-        dgate, dup = torch.empty_like(gate), torch.empty_like(up)
-        dgu_t = torch.empty(2 * I, M, dtype=x2.dtype, device=x2.device)
-        _C.check(lib.tn_swiglu_bwd_t(_p(dact), _p(gate), _p(up), _p(dgate), _p(dup), _p(dgu_t), M, I, _cur()),
-                 "tn_swiglu_bwd_t")
+        dgate, dup, dgu_t = L.swiglu_bwd_t(dact, gate, up)
         del dact
         dx = None
         if nx:
@@ -647,7 +425,7 @@ _MLP_FUSED = os.environ.get("TN_MLP_FUSED", "1") != "0"       # (A/B switch for 
 def swiglu_mlp(x, w_gate, w_up, w_down):
     """Llama/Qwen2 MLP ``down(silu(gate(x)) * up(x))`` (bias-free).  bf16 device tensors with 8-aligned shapes take the
     fused node above; anything else composes the individual ops (same maths)."""
-    if not x.is_cuda:
+    if not (x.is_cuda or x.is_meta):
         raise _C.KernelError("swiglu_mlp: device tensors only (the product path has no CPU fallback)")
     M = x.numel() // x.shape[-1]
     if (_MLP_FUSED and x.dtype == torch.bfloat16
@@ -686,11 +464,7 @@ def slaney_mel_filters(n_mels: int, device) -> torch.Tensor:
 
 def kaldi_fbank(wav: torch.Tensor, num_mel_bins: int = 80) -> torch.Tensor:
     """wav fp32 [N] in [-1, 1) at 16 kHz -> fp32 [frames, num_mel_bins] (functions.py:117-134)."""
-    wav = _c(wav).float().view(-1)
-    nf = _C.lib().tn_fbank_frames(wav.numel())
-    feat = torch.empty(nf, num_mel_bins, dtype=torch.float32, device=wav.device)
-    _C.check(_C.lib().tn_kaldi_fbank(_p(wav), _p(feat), wav.numel(), num_mel_bins, _cur()), "tn_kaldi_fbank")
-    return feat
+    return L.kaldi_fbank(_c(wav).float().view(-1), int(num_mel_bins))
 
 
 def log_mel_spectrogram(wav: torch.Tensor, num_mel_bins: int = 128, padding: int = 0) -> torch.Tensor:
@@ -698,23 +472,14 @@ def log_mel_spectrogram(wav: torch.Tensor, num_mel_bins: int = 128, padding: int
     wav = _c(wav).float().view(-1)
     if padding > 0:
         wav = torch.nn.functional.pad(wav, (0, padding))
-    nf = wav.numel() // 160
-    feat = torch.empty(nf, num_mel_bins, dtype=torch.float32, device=wav.device)
-    gmax = torch.empty(1, dtype=torch.float32, device=wav.device)
-    fb = slaney_mel_filters(num_mel_bins, wav.device)
-    _C.check(_C.lib().tn_log_mel(_p(wav), _p(fb), _p(feat), _p(gmax), wav.numel(), num_mel_bins, _cur()),
-             "tn_log_mel")
-    return feat
+    return L.log_mel(wav, slaney_mel_filters(num_mel_bins, wav.device), int(num_mel_bins))
 
 
 def pcm16_to_float(pcm: torch.Tensor) -> torch.Tensor:
     """int16 PCM on the device -> float32 in [-1, 1) (x / 32768, exact; touchnet/data/datapipe.py:164)."""
     if not pcm.is_cuda or pcm.dtype != torch.int16:
         raise RuntimeError("pcm16_to_float: expects an int16 device tensor")
-    pcm = _c(pcm)
-    out = torch.empty(pcm.shape, dtype=torch.float32, device=pcm.device)
-    _C.check(_C.lib().tn_pcm16_to_f32(_p(pcm), _p(out), pcm.numel(), _cur()), "tn_pcm16_to_f32")
-    return out
+    return L.pcm16_to_f32(_c(pcm))
 
 
 def bestrq_tokenize(feat: torch.Tensor, quantizer: torch.Tensor, codebook: torch.Tensor) -> torch.Tensor:
@@ -728,18 +493,11 @@ def bestrq_tokenize(feat: torch.Tensor, quantizer: torch.Tensor, codebook: torch
     if quantizer.shape[0] != Fdim or codebook.shape[1] != E:
         raise RuntimeError(f"bestrq_tokenize: shape mismatch feat {tuple(feat.shape)} quantizer {tuple(quantizer.shape)} "
                            f"codebook {tuple(codebook.shape)}")
-    feat, quantizer, codebook = _c(feat), _c(quantizer), _c(codebook)
-    codes = torch.empty(T, dtype=torch.int64, device=feat.device)
-    _C.check(_C.lib().tn_bestrq_tokenize(_p(feat), _p(quantizer), _p(codebook), _p(codes), T, Fdim, E, V, _cur()),
-             "tn_bestrq_tokenize")
-    return codes
+    if E not in (8, 16, 32):
+        raise _C.KernelError(f"bestrq_tokenize: codebook width {E} not in (8, 16, 32)")
+    return L.bestrq_tokenize(_c(feat), _c(quantizer), _c(codebook))
 
 
 def audiofeat_stack(feat: torch.Tensor, stack: int, stride: int, normalize: bool = True) -> torch.Tensor:
     """feat fp32 [T, F] -> fp32 [ceil(T/stride), F*stack] (functions.py:258-286)."""
-    feat = _c(feat).float()
-    T, F = feat.shape
-    out = torch.empty((T + stride - 1) // stride, F * stack, dtype=torch.float32, device=feat.device)
-    _C.check(_C.lib().tn_audiofeat_stack(_p(feat), _p(out), T, F, stack, stride, int(normalize), _cur()),
-             "tn_audiofeat_stack")
-    return out
+    return L.audiofeat_stack(_c(feat).float(), int(stack), int(stride), bool(normalize))

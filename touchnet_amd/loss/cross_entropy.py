@@ -11,31 +11,38 @@ TrainSpec `acc_fn` (touchnet/utils/metrics.py:26-50) does not re-read the logits
 """
 from __future__ import annotations
 
+import weakref
+
 import torch
 
 from touchnet_amd.models.backend import ops
 
-_LAST = {"key": None, "acc": None}
+# accuracy of the last loss_fn call, valid for exactly the tensor OBJECTS it was computed from (weak references +
+# in-place version counters: an address recycled by the caching allocator or a tensor modified in place can never
+# hit) and for one acc_fn call (cleared on the hit)
+_LAST = {"pred": None, "labels": None, "versions": None, "acc": None}
 
 
-def _key(pred, labels):
-    return (pred.data_ptr(), tuple(pred.shape), labels.data_ptr())
+def _remember(pred, labels, acc):
+    _LAST.update(pred=weakref.ref(pred), labels=weakref.ref(labels), versions=(pred._version, labels._version), acc=acc)
 
 
 def cross_entropy_loss(pred, labels, sentence_lens, num_sentence, ignore_index: int = -100):
     loss, stats = ops().packed_cross_entropy(pred, labels, sentence_lens, num_sentence, ignore_index)
-    _LAST["key"], _LAST["acc"] = _key(pred, labels), stats[2]
+    _remember(pred, labels, stats[2])
     return loss, stats[1]
 
 
 def cached_accuracy(pred, labels):
-    if _LAST["key"] == _key(pred, labels):
-        return _LAST["acc"]
-    return None
+    hit = (_LAST["pred"] is not None and _LAST["pred"]() is pred and _LAST["labels"]() is labels
+           and _LAST["versions"] == (pred._version, labels._version))
+    acc = _LAST["acc"] if hit else None
+    _LAST.update(pred=None, labels=None, versions=None, acc=None)
+    return acc
 
 
 def fused_linear_cross_entropy(hidden, weight, labels, sentence_lens, num_sentence, ignore_index: int = -100,
-                               chunk_tokens: int = 16384, compact: bool = False):
+                               chunk_tokens: int = 4096, compact: bool = False):
     """(loss_per_sample, loss_per_token, accuracy) straight from the final hidden states: lm_head GEMM +
     packed CE chunked over tokens (touchnet_amd.functional.fused_linear_cross_entropy)."""
     loss, stats = ops().fused_linear_cross_entropy(hidden, weight, labels, sentence_lens, num_sentence,

@@ -34,7 +34,10 @@ def block_groups(model: nn.Module):
 
 
 def apply_fsdp(model: nn.Module, dp_mesh, param_dtype=torch.bfloat16, reduce_dtype=torch.float32,
-               reshard_after_forward_policy: str = "never"):
+               pp_enabled: bool = False, cpu_offload: bool = False, reshard_after_forward_policy: str = "never"):
+    """Positional order of the reference (helper_func.py:134-145).  `pp_enabled` / `cpu_offload` must be False here."""
+    if pp_enabled or cpu_offload:
+        raise NotImplementedError("pipeline parallelism / CPU offload are outside the MI355X path")
     fully_shard, MixedPrecisionPolicy = _fully_shard()
     cfg = {"mesh": dp_mesh, "mp_policy": MixedPrecisionPolicy(param_dtype=param_dtype, reduce_dtype=reduce_dtype)}
     for blocks in block_groups(model):

@@ -32,6 +32,10 @@ class PackBuffer:
     def place(self, n: int) -> bool:
         """Reserve n slots.  Returns True when the buffer had to be flushed FIRST (caller emits, resets
         and calls again) — i.e. the segment does not fit the last row."""
+        if n > self.T:
+            # the reference fails here too (slice-size mismatch at processing_llama.py:86-90); say why
+            raise ValueError(f"segment of {n} slots does not fit a row of {self.T}: filter or truncate the sample "
+                             f"before packing (text_max_length_in_tokens_for_filter)")
         if self.col + n > self.T:
             if self.row == self.B - 1:
                 return True

@@ -1,0 +1,96 @@
+"""`parallelize_fn` of the MI355X TrainSpecs — called by the reference trainer as
+`parallelize_fn(model, world_mesh, parallel_dims, job_config)` (touchnet/bin/train.py:259-261) on the META-device model.
+
+Same order of transformations as touchnet/models/llama/parallelize_llama.py:29-102 (and its touch_audio / qwen2_audio
+siblings): tensor parallel -> activation checkpointing -> (compile) -> FSDP2 over the `dp_shard_cp` mesh (HSDP with
+`dp_replicate`) or DDP.  What differs is what the MI355X path needs:
+  * activation checkpointing wraps OUR block classes (full, or every n-th block); the kernels are deterministic and
+    stateless, so re-execution in backward (`preserve_rng_state=False`) is exact.  With 288 GB of HBM the 7B recipes
+    run WITHOUT it (218 GB peak at B=2 x 8192); it is the headroom knob for config D / larger batches.
+  * `training_compile`: nothing to compile — the blocks are hand-written kernels behind opaque custom ops; the flag is
+    accepted and ignored with a warning (the reference turns it off itself for flex_attention, train.py:129-131).
+  * CPU offload and pipeline parallelism: rejected loudly (out of scope).
+"""
+from __future__ import annotations
+
+import warnings
+
+import torch
+import torch.nn as nn
+
+from touchnet_amd.models.helper_func import apply_fsdp, block_groups
+
+_DTYPES = {"float32": torch.float32, "bfloat16": torch.bfloat16, "float16": torch.float16}
+
+
+def _checkpoint_wrapper():
+    from torch.distributed.algorithms._checkpoint.checkpoint_wrapper import checkpoint_wrapper
+    return checkpoint_wrapper
+
+
+def apply_ac(model: nn.Module, job_config) -> None:
+    """touchnet/models/helper_func.py:39-131.  `full`: every block; `selective` with an integer option n: every n-th
+    block; `selective` with "op": the op-level save list of the reference names aten matmuls / SDPA — ops this path
+    does not execute — so it maps onto "recompute the row kernels, keep the GEMM and attention outputs", which is
+    what our autograd nodes already save; it is therefore the same as no checkpointing and is reported as such."""
+    mode = job_config.training_activation_checkpoint_mode
+    if mode not in ("full", "selective"):
+        raise ValueError(f"Invalid AC mode: {mode}. Valid modes: ('full', 'selective')")
+    option = str(getattr(job_config, "training_activation_checkpoint_selective_ac_option", "2"))
+    if mode == "selective" and not (option == "op" or option.isdigit()):
+        raise ValueError(f"Invalid selective AC option: {option}. Valid options: 'op' or a positive int representing "
+                         f"layer frequency")
+    if mode == "selective" and option == "op":
+        warnings.warn("selective AC option 'op': the MI355X blocks already save only GEMM/attention outputs; no wrapper")
+        return
+    every = 1 if mode == "full" else max(1, int(option))
+    wrap = _checkpoint_wrapper()
+    count = 0
+    for blocks in block_groups(model):
+        for blk in blocks:
+            count += 1
+            if count % every == 0:
+                wrapped = wrap(blk, preserve_rng_state=False)
+                _replace_block(model, blk, wrapped)
+
+
+def _replace_block(model: nn.Module, old: nn.Module, new: nn.Module) -> None:
+    for mod in model.modules():
+        if isinstance(mod, (nn.ModuleList, nn.ModuleDict)):
+            for key, child in (mod.named_children()):
+                if child is old:
+                    mod.register_module(key, new)
+                    return
+    raise RuntimeError("block to wrap not found in a ModuleList")
+
+
+def apply_ddp(model: nn.Module, dp_mesh) -> None:
+    """touchnet/models/helper_func.py:205-228 (composable `replicate`, 100 MB buckets)."""
+    from torch.distributed._composable.replicate import replicate
+    replicate(model, device_mesh=dp_mesh, bucket_cap_mb=100)
+
+
+def parallelize_packed(model: nn.Module, world_mesh, parallel_dims, job_config) -> nn.Module:
+    if parallel_dims.pp_enabled:
+        raise NotImplementedError("pipeline parallelism is outside the MI355X path (SURVEY §2.2)")
+    if parallel_dims.tp_enabled:
+        from touchnet_amd.models.tensor_parallel import apply_tp
+        apply_tp(model, world_mesh["tp"], loss_parallel=parallel_dims.loss_parallel_enabled)
+    if getattr(job_config, "training_activation_checkpoint_mode", "none") != "none":
+        apply_ac(model, job_config)
+    if getattr(job_config, "training_compile", False):
+        warnings.warn("training_compile ignored: the MI355X blocks are hand-written kernels (nothing to compile)")
+    if getattr(job_config, "training_enable_cpu_offload", False):
+        raise NotImplementedError("CPU offload is not supported by the MI355X path (288 GB of HBM per GPU)")
+    if parallel_dims.dp_shard_enabled or parallel_dims.cp_enabled:
+        names = ("dp_replicate", "dp_shard_cp") if parallel_dims.dp_replicate_enabled else ("dp_shard_cp",)
+        apply_fsdp(model, world_mesh[names],
+                   param_dtype=_DTYPES[getattr(job_config, "training_mixed_precision_param", "bfloat16")],
+                   reduce_dtype=_DTYPES[getattr(job_config, "training_mixed_precision_reduce", "float32")],
+                   pp_enabled=False, cpu_offload=False,
+                   reshard_after_forward_policy=getattr(job_config, "training_fsdp_reshard_after_forward", "default"))
+    elif parallel_dims.dp_replicate_enabled:
+        if world_mesh.ndim > 1:
+            raise RuntimeError("DDP has not supported > 1D parallelism")
+        apply_ddp(model, world_mesh)
+    return model

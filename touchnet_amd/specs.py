@@ -6,20 +6,13 @@ Model families are selected by `training_model_name`, like in the reference:
     qwen2_audio_mi355   <- "qwen2_audio"  (Qwen2-Audio-7B, packed variant)
 INTEGRATION.md shows the three-line shim that puts these into TouchNet's own registry.
 """
+from touchnet_amd.data.dataloader import build_dataloader
 from touchnet_amd.loss.cross_entropy import cross_entropy_loss
 from touchnet_amd.models import llama, qwen2_audio, touch_audio
-from touchnet_amd.models.helper_func import apply_fsdp
-from touchnet_amd.utils.metrics import accuracy
-from touchnet_amd.utils.optimizer import FusedAdamW, linear_warmup_linear_decay
+from touchnet_amd.models.parallelize import parallelize_packed
+from touchnet_amd.utils.metrics import MI355X_BF16_DENSE_PEAK, accuracy
+from touchnet_amd.utils.optimizer import FusedAdamW, LRScheduler
 from touchnet_amd.utils.train_spec import TrainSpec, _train_specs, get_train_spec, register_train_spec  # noqa: F401
-
-
-def _parallelize(model, dp_mesh, job):
-    import torch
-    return apply_fsdp(model, dp_mesh,
-                      param_dtype=getattr(torch, getattr(job, "training_mixed_precision_param", "bfloat16")),
-                      reduce_dtype=getattr(torch, getattr(job, "training_mixed_precision_reduce", "float32")),
-                      reshard_after_forward_policy=getattr(job, "training_fsdp_reshard_after_forward", "never"))
 
 
 def _build_optimizers(model_parts, job):
@@ -29,13 +22,24 @@ def _build_optimizers(model_parts, job):
 
 
 def _build_lr(optimizers, job):
-    return lambda step: job.lr_scheduler_lr * linear_warmup_linear_decay(
-        step, job.lr_scheduler_warmup_steps, job.lr_scheduler_steps)
+    """`build_lr_schedulers_fn(optimizers, job_config)` (touchnet/bin/train.py:299): an object with step() /
+    state_dict() / load_state_dict() like the reference's LRSchedulersContainer."""
+    return LRScheduler(optimizers, job.lr_scheduler_lr, job.lr_scheduler_warmup_steps, job.lr_scheduler_steps,
+                       getattr(job, "lr_scheduler_lr_min", 0.0))
 
 
-def _synthetic_loader(**kw):
-    raise NotImplementedError("the MI355X path is fed by touchnet's own dataloader over touchnet_amd.data.datapipe "
-                              "(INTEGRATION.md) or by touchnet_amd.data.synthetic in benchmarks")
+def _build_dataloader(tokenizer=None, data_config=None, dp_rank=0, dp_world_size=1, split="train"):
+    """Called with exactly these keywords at touchnet/bin/train.py:157-170."""
+    return build_dataloader(data_config, tokenizer, dp_rank, dp_world_size, split)
+
+
+def _build_metrics_processor(job_config, parallel_dims):
+    """touchnet/bin/train.py:185.  Logging / MFU bookkeeping is the reference's own (out of scope here); its peak-FLOPS
+    table has no MI-series entry (utils/metrics.py:67-100 falls back to A100), so the MI355X dense bf16 peak is set."""
+    from touchnet.utils.metrics import build_metrics_processor
+    mp = build_metrics_processor(job_config, parallel_dims)
+    mp.gpu_peak_flops = MI355X_BF16_DENSE_PEAK
+    return mp
 
 
 def _build_tokenizer(args, **kwargs):
@@ -46,11 +50,12 @@ def _build_tokenizer(args, **kwargs):
 
 
 def _spec(name, mod, model_cls, config_cls):
-    return TrainSpec(name=name, model_cls=model_cls, config_cls=config_cls, parallelize_fn=_parallelize,
+    return TrainSpec(name=name, model_cls=model_cls, config_cls=config_cls, parallelize_fn=parallelize_packed,
                      pipelining_fn=None, build_optimizers_fn=_build_optimizers, build_lr_schedulers_fn=_build_lr,
-                     build_dataloader_fn=_synthetic_loader, build_tokenizer_fn=_build_tokenizer, loss_fn=cross_entropy_loss,
-                     acc_fn=accuracy, additional_pre_init_fn=mod.pre_init, additional_post_init_fn=mod.post_init,
-                     get_num_flop_per_token_fn=mod.get_num_flop_per_token, get_num_params_fn=mod.get_num_params)
+                     build_dataloader_fn=_build_dataloader, build_tokenizer_fn=_build_tokenizer,
+                     loss_fn=cross_entropy_loss, acc_fn=accuracy, additional_pre_init_fn=mod.pre_init,
+                     additional_post_init_fn=mod.post_init, get_num_flop_per_token_fn=mod.get_num_flop_per_token,
+                     get_num_params_fn=mod.get_num_params, build_metrics_processor_fn=_build_metrics_processor)
 
 
 def register_all():

@@ -58,3 +58,55 @@ def dist_max(x: torch.Tensor, group=None) -> torch.Tensor:
         x = x.clone()
         dist.all_reduce(x, op=dist.ReduceOp.MAX, group=group)
     return x
+
+
+# ------------------------------------------------------------------------------------------------ parallel dims
+from dataclasses import dataclass  # noqa: E402
+
+
+@dataclass
+class ParallelDims:
+    """Degrees of each parallelism and the device mesh built from them — field names, validation, mesh-dimension names
+    ("pp", "dp_replicate", "dp_shard", "cp", "tp") and the flattened sub-meshes ("dp" for data loading, "dp_shard_cp"
+    for parameter sharding, "dp_cp" for the loss all-reduce) are the reference's (touchnet/utils/distributed.py:71-196),
+    because `parallelize_fn(model, world_mesh, parallel_dims, job_config)` is called with them (touchnet/bin/train.py:259-261)."""
+    dp_replicate: int
+    dp_shard: int
+    cp: int
+    tp: int
+    pp: int
+    world_size: int
+    enable_loss_parallel: bool = False
+
+    def __post_init__(self):
+        fixed = self.dp_replicate * self.cp * self.tp * self.pp
+        if min(self.dp_replicate, self.cp, self.tp, self.pp) < 1:
+            raise AssertionError("Parallelism degree should be >= 1, except for dp_shard")
+        if self.dp_shard == -1:
+            self.dp_shard = self.world_size // fixed
+        if self.dp_shard < 1 or fixed * self.dp_shard != self.world_size:
+            raise AssertionError(f"Invalid parallel dims: dp_replicate({self.dp_replicate}) * dp_shard({self.dp_shard}) * "
+                                 f"cp({self.cp}) * tp({self.tp}) * pp({self.pp}) != WORLD_SIZE({self.world_size})")
+
+    dp_enabled = property(lambda self: self.dp_replicate > 1 or self.dp_shard > 1)
+    dp_replicate_enabled = property(lambda self: self.dp_replicate > 1)
+    dp_shard_enabled = property(lambda self: self.dp_shard > 1)
+    cp_enabled = property(lambda self: self.cp > 1)
+    tp_enabled = property(lambda self: self.tp > 1)
+    pp_enabled = property(lambda self: self.pp > 1)
+    loss_parallel_enabled = property(lambda self: self.tp > 1 and self.enable_loss_parallel)
+    non_data_parallel_size = property(lambda self: self.cp * self.tp * self.pp)
+
+    def build_mesh(self, device_type: str):
+        from torch.distributed.device_mesh import init_device_mesh
+        degrees = {"pp": self.pp, "dp_replicate": self.dp_replicate, "dp_shard": self.dp_shard, "cp": self.cp,
+                   "tp": self.tp}
+        names = tuple(n for n, d in degrees.items() if d > 1)
+        mesh = init_device_mesh(device_type, tuple(degrees[n] for n in names), mesh_dim_names=names)
+        flat = {"dp": ("dp_replicate", "dp_shard"), "dp_shard_cp": ("dp_shard", "cp"),
+                "dp_cp": ("dp_replicate", "dp_shard", "cp")}
+        for flat_name, parts in flat.items():                    # all process groups are created here, up front
+            present = tuple(n for n in parts if n in names)
+            if present:
+                mesh[present]._flatten(mesh_dim_name=flat_name)
+        return mesh

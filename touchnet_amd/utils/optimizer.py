@@ -3,19 +3,22 @@
 Hyper-parameters and update rule are the reference's (touchnet/utils/optimizer.py:157-172:
 AdamW, betas (0.9, 0.95), weight decay 0.1 on every parameter, eps 1e-8) plus the global-norm clip of
 touchnet/utils/distributed.py:426-491 and the skip-on-nonfinite of touchnet/bin/train.py:467-473 — all
-evaluated on the device, so the optimizer step issues no host synchronisation.
+evaluated on the device, so the optimizer step issues no host synchronisation: THREE launches per gradient dtype
+(multi-tensor sum of squares, its final reduction, multi-tensor AdamW) plus one 1-thread launch that turns the
+norm into the step state (step count — advanced only on a finite norm, like torch's AdamW under the reference's
+skip —, bias corrections, clip coefficient).
 
 Precision layout (identical to FSDP2's MixedPrecisionPolicy(param=bf16, reduce=fp32) that the reference
 applies, touchnet/models/helper_func.py:165):
   * single GPU:  module parameters are bf16 (what the kernels read); this class owns the fp32 master
                  copy and the fp32 Adam moments, and rewrites the bf16 parameter in the same pass
   * FSDP2:       the sharded parameters ARE the fp32 masters (FSDP all-gathers bf16 copies); the kernel
-                 runs on each rank's local shard and the squared norm is all-reduced over the mesh
+                 runs on each rank's local shard and the squared norm is all-reduced over the mesh dimensions the
+                 parameters are SHARDED on (found from the DTensor placements when no group is passed)
 """
 from __future__ import annotations
 
-import math
-from typing import Iterable, Optional
+from typing import Any, Dict, Iterable, List, Optional
 
 import torch
 
@@ -26,13 +29,28 @@ def _local(t: torch.Tensor) -> torch.Tensor:
     return t._local_tensor if hasattr(t, "_local_tensor") else t
 
 
+def _shard_groups(params) -> List[Any]:
+    """Process groups the squared gradient norm has to be summed over: one per mesh dimension on which the DTensor
+    parameters are sharded (replicated dimensions hold identical gradients after FSDP/HSDP's reduction)."""
+    groups, seen = [], set()
+    for p in params:
+        mesh = getattr(p, "device_mesh", None)
+        if mesh is None:
+            continue
+        for d, pl in enumerate(p.placements):
+            if pl.is_shard() and mesh.size(d) > 1 and (id(mesh), d) not in seen:
+                seen.add((id(mesh), d))
+                groups.append(mesh.get_group(d))
+    return groups
+
+
 class FusedAdamW:
     def __init__(self, params: Iterable[torch.nn.Parameter], lr=8e-4, betas=(0.9, 0.95), eps=1e-8,
                  weight_decay=0.1, max_norm: float = 1.0, process_group=None):
         self.params = [p for p in params if p.requires_grad]
         self.lr, self.betas, self.eps, self.weight_decay, self.max_norm = lr, betas, eps, weight_decay, max_norm
-        self.group = process_group
-        self.step_count = 0
+        # explicit group (bin/train.py: the flattened dp x cp mesh) or the groups read off the DTensor placements
+        self.groups = [process_group] if process_group is not None else _shard_groups(self.params)
         dev = _local(self.params[0]).device
         self.state = []
         for p in self.params:
@@ -40,31 +58,35 @@ class FusedAdamW:
             master = lp if lp.dtype == torch.float32 else lp.detach().float().clone()
             self.state.append(dict(master=master, m=torch.zeros_like(master), v=torch.zeros_like(master)))
         self.norm_sq = torch.zeros(1, dtype=torch.float32, device=dev)
-        self.scratch = torch.empty(_C.lib().tn_sumsq_scratch_floats(), dtype=torch.float32, device=dev)
+        self.step_state = torch.zeros(8, dtype=torch.float32, device=dev)   # tn_adamw_prepare's device state
         self._partial, self._keep = None, None
 
-    def _sumsq(self, grads):
+    # ------------------------------------------------------------------ multi-tensor tables
+    @staticmethod
+    def _table(rows, device):
+        t = torch.tensor(rows, dtype=torch.int64).pin_memory()
+        return t.to(device, non_blocking=True)
+
+    def _sumsq(self, by_dtype):
         """norm_sq += sum(g^2) over all gradients: one multi-tensor launch per gradient dtype (the gradient
         tensors are new allocations every step, so the pointer table is rebuilt and uploaded each time: ~20 KB)."""
         lib, p_, st = _C.lib(), _C.ptr, _C.stream
         chunk = int(lib.tn_sumsq_multi_chunk())
-        by_dtype = {}
-        for g in grads:
-            if g is not None and g.numel():
-                by_dtype.setdefault(g.dtype, []).append(g)
-        for dt, gs in by_dtype.items():
+        keep = []
+        for dt, items in by_dtype.items():
+            gs = [g for _, g in items]
             sizes = [g.numel() for g in gs]
             first, tot = [], 0
             for n in sizes:
                 first.append(tot)
                 tot += (n + chunk - 1) // chunk
-            table = torch.tensor([[g.data_ptr() for g in gs], sizes, first], dtype=torch.int64).pin_memory()
-            table = table.to(gs[0].device, non_blocking=True)
+            table = self._table([[g.data_ptr() for g in gs], sizes, first], gs[0].device)
             if self._partial is None or self._partial.numel() < tot:
                 self._partial = torch.empty(tot, dtype=torch.float32, device=gs[0].device)
             _C.check(lib.tn_sumsq_multi(p_(table[0]), p_(table[1]), p_(table[2]), len(gs), tot, p_(self._partial),
                                         p_(self.norm_sq), _C.dcode(gs[0]), st()), "tn_sumsq_multi")
-            self._keep = (table, gs)          # alive until the next step (the launch is asynchronous)
+            keep.append((table, gs))
+        return keep
 
     def zero_grad(self, set_to_none: bool = True):
         for p in self.params:
@@ -78,23 +100,71 @@ class FusedAdamW:
         """One clip + AdamW step.  Returns the (pre-clip) global grad norm as a 0-d device tensor."""
         lib, p_, st = _C.lib(), _C.ptr, _C.stream
         lr = self.lr if lr is None else lr
-        self.step_count += 1
         b1, b2 = self.betas
-        bc1, bc2 = 1.0 - b1 ** self.step_count, 1.0 - b2 ** self.step_count
         self.norm_sq.zero_()
-        grads = [None if p.grad is None else _local(p.grad).contiguous() for p in self.params]
-        self._sumsq(grads)
-        if self.group is not None:
-            torch.distributed.all_reduce(self.norm_sq, group=self.group)
-        for p, g, s in zip(self.params, grads, self.state):
-            if g is None or not g.numel():
+        by_dtype: Dict[torch.dtype, list] = {}
+        for i, p in enumerate(self.params):
+            if p.grad is None:
                 continue
-            lp = _local(p.data)
-            shadow = lp if lp.dtype == torch.bfloat16 else None
-            _C.check(lib.tn_adamw_step(p_(s["master"]), p_(s["m"]), p_(s["v"]), p_(g), p_(shadow), p_(self.norm_sq),
-                                       g.numel(), float(lr), b1, b2, self.eps, self.weight_decay,
-                                       float(self.max_norm), bc1, bc2, _C.dcode(g), st()), "tn_adamw_step")
+            g = _local(p.grad).contiguous()
+            if g.numel():
+                by_dtype.setdefault(g.dtype, []).append((i, g))
+        keep = self._sumsq(by_dtype)
+        for grp in self.groups:
+            torch.distributed.all_reduce(self.norm_sq, group=grp)
+        _C.check(lib.tn_adamw_prepare(p_(self.norm_sq), p_(self.step_state), b1, b2, float(self.max_norm), st()),
+                 "tn_adamw_prepare")
+        chunk = int(lib.tn_adamw_multi_chunk())
+        for dt, items in by_dtype.items():
+            rows = [[], [], [], [], [], [], []]
+            tot = 0
+            for i, g in items:
+                s = self.state[i]
+                lp = _local(self.params[i].data)
+                rows[0].append(s["master"].data_ptr())
+                rows[1].append(s["m"].data_ptr())
+                rows[2].append(s["v"].data_ptr())
+                rows[3].append(g.data_ptr())
+                rows[4].append(lp.data_ptr() if lp.dtype == torch.bfloat16 else 0)
+                rows[5].append(g.numel())
+                rows[6].append(tot)
+                tot += (g.numel() + chunk - 1) // chunk
+            t = self._table(rows, items[0][1].device)
+            _C.check(lib.tn_adamw_multi(p_(t[0]), p_(t[1]), p_(t[2]), p_(t[3]), p_(t[4]), p_(t[5]), p_(t[6]),
+                                        len(items), tot, p_(self.step_state), float(lr), b1, b2, self.eps,
+                                        self.weight_decay, _C.dcode(items[0][1]), st()), "tn_adamw_multi")
+            keep.append(t)
+        self._keep = keep                     # tables / gradients stay alive until the next step (async launches)
         return self.norm_sq.sqrt().squeeze(0)
+
+    @property
+    def step_count(self) -> int:
+        """Number of APPLIED updates (host sync: logging / checkpoint use only)."""
+        return int(self.step_state[:1].view(torch.int32).item())
+
+    # ------------------------------------------------------------------ checkpoint (touchnet/utils/checkpoint.py keeps the optimizer in its states)
+    def state_dict(self) -> Dict[str, Any]:
+        return {"step_state": self.step_state.clone(),
+                "state": {i: {"master": s["master"], "exp_avg": s["m"], "exp_avg_sq": s["v"]}
+                          for i, s in enumerate(self.state)},
+                "hyper": {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps,
+                          "weight_decay": self.weight_decay, "max_norm": self.max_norm}}
+
+    @torch.no_grad()
+    def load_state_dict(self, sd: Dict[str, Any]) -> None:
+        if len(sd["state"]) != len(self.state):
+            raise ValueError(f"optimizer state has {len(sd['state'])} tensors, this optimizer {len(self.state)}")
+        self.step_state.copy_(sd["step_state"])
+        for i, s in enumerate(self.state):
+            src = sd["state"][i]
+            s["master"].copy_(_local(src["master"]))
+            s["m"].copy_(_local(src["exp_avg"]))
+            s["v"].copy_(_local(src["exp_avg_sq"]))
+            lp = _local(self.params[i].data)
+            if lp.dtype == torch.bfloat16:
+                lp.copy_(s["master"])
+        h = sd.get("hyper", {})
+        self.lr = h.get("lr", self.lr)
 
 
 def linear_warmup_linear_decay(step: int, warmup: int, total: int, min_ratio: float = 0.0) -> float:
@@ -103,3 +173,31 @@ def linear_warmup_linear_decay(step: int, warmup: int, total: int, min_ratio: fl
         return float(step + 1) / float(warmup + 1)
     span = max(1, total - warmup)
     return max(min_ratio, 1.0 - float(step - warmup) / span * (1.0 - min_ratio))
+
+
+class LRScheduler:
+    """What `build_lr_schedulers_fn` returns (the role of LRSchedulersContainer, touchnet/utils/optimizer.py:175-231:
+    `step()`, `state_dict()`, `load_state_dict()`): drives `optimizer.lr` with the WSD-linear multiplier."""
+
+    def __init__(self, optimizer: FusedAdamW, base_lr: float, warmup: int, total: int, min_ratio: float = 0.0):
+        self.optimizer, self.base_lr, self.warmup, self.total, self.min_ratio = optimizer, base_lr, warmup, total, min_ratio
+        self.last_step = 0
+        self._apply()
+
+    def _apply(self):
+        self.optimizer.lr = self.base_lr * linear_warmup_linear_decay(self.last_step, self.warmup, self.total,
+                                                                      self.min_ratio)
+
+    def step(self) -> None:
+        self.last_step += 1
+        self._apply()
+
+    def get_last_lr(self):
+        return [self.optimizer.lr]
+
+    def state_dict(self) -> Dict[str, Any]:
+        return {"last_step": self.last_step}
+
+    def load_state_dict(self, sd: Dict[str, Any]) -> None:
+        self.last_step = int(sd["last_step"])
+        self._apply()

@@ -1,70 +1,56 @@
 """Model-family plugin registry with the surface TouchNet's trainer consumes.
 
-Surface parity (names, argument meaning, error behaviour) with touchnet/utils/train_spec.py:25-68:
-  * `TrainSpec` — one record per `training_model_name`; the sixteen slots are the hooks
-    touchnet/bin/train.py calls (model / config classes, parallelize, optimizer + scheduler builders,
-    dataloader / tokenizer builders, loss / acc functions, pre/post-init hooks, flop + parameter counters,
-    metrics processor builder).
-  * `register_train_spec(spec)` — ValueError when the name is taken.
-  * `get_train_spec(name)`      — ValueError when the name is unknown.
-  * `apply_to_train_specs(fn)`  — rewrite every registered spec through `fn`.
-INTEGRATION.md shows how the MI355X specs are entered into TouchNet's own registry.
+Surface parity (field names AND order, argument meaning, error behaviour) with touchnet/utils/train_spec.py:25-68 —
+`tests/test_boundary.py` holds the reference's field list and the call signatures of its `train.py` call sites as a
+fixture generated from the reference (tests/golden/make_golden.py) and checks this module and the registered specs
+against it:
+  * `TrainSpec` — one record per `training_model_name`; the sixteen slots are the hooks touchnet/bin/train.py calls;
+    all positional, none defaulted, in the reference's order (a spec built positionally for one registry fits the other)
+  * `register_train_spec(spec)` — ValueError when the name is taken
+  * `get_train_spec(name)`      — ValueError when the name is unknown
+  * `apply_to_train_specs(fn)`  — rewrite every registered spec through `fn`
 """
 from __future__ import annotations
 
-import dataclasses
-from typing import Any, Callable, Dict, Optional
-
-_SLOTS = (
-    # (field name, required)
-    ("name", True), ("model_cls", True), ("config_cls", True), ("parallelize_fn", True),
-    ("pipelining_fn", False), ("build_optimizers_fn", True), ("build_lr_schedulers_fn", True),
-    ("build_dataloader_fn", True), ("build_tokenizer_fn", False), ("loss_fn", True), ("acc_fn", False),
-    ("additional_pre_init_fn", False), ("additional_post_init_fn", False),
-    ("get_num_flop_per_token_fn", True), ("get_num_params_fn", True), ("build_metrics_processor_fn", False),
-)
-
-TrainSpec = dataclasses.make_dataclass(
-    "TrainSpec",
-    [(n, Any) if req else (n, Optional[Callable], dataclasses.field(default=None)) for n, req in
-     sorted(_SLOTS, key=lambda t: not t[1])],
-)
-TrainSpec.__doc__ = "Plugin record for one model family (fields = the hooks of touchnet/bin/train.py)."
+from dataclasses import dataclass
+from typing import Any, Callable, Dict
 
 
-class _Registry:
-    def __init__(self):
-        self._by_name: Dict[str, Any] = {}
-
-    def add(self, spec) -> None:
-        if spec.name in self._by_name:
-            raise ValueError(f"Model {spec.name} is already registered.")
-        self._by_name[spec.name] = spec
-
-    def get(self, name: str):
-        try:
-            return self._by_name[name]
-        except KeyError:
-            raise ValueError(f"Model {name} is not registered.") from None
-
-    def map_inplace(self, fn: Callable) -> None:
-        self._by_name = {k: fn(v) for k, v in self._by_name.items()}
-
-    def __contains__(self, name: str) -> bool:
-        return name in self._by_name
+@dataclass
+class TrainSpec:
+    name: str
+    model_cls: Any                        # nn.Module subclass, constructible on the meta device (train.py:179-182)
+    config_cls: Any                       # `.from_json_file(path)` (train.py:126-127)
+    parallelize_fn: Callable              # (model, world_mesh, parallel_dims, job_config) -> model   train.py:259-261
+    pipelining_fn: Callable               # None here: pipeline parallelism is out of scope
+    build_optimizers_fn: Callable         # (model_parts, job_config)                                  train.py:298
+    build_lr_schedulers_fn: Callable      # (optimizers, job_config)                                   train.py:299
+    build_dataloader_fn: Callable         # (tokenizer=, data_config=, dp_rank=, dp_world_size=, split=)  :157-170
+    build_tokenizer_fn: Callable          # (tokenizer_config, **special_tokens)                       train.py:150-156
+    loss_fn: Callable                     # (pred, labels, sentence_lens, num_sentence) -> (per_sample, per_token)
+    acc_fn: Callable                      # (pred, labels) -> 0-d tensor, or None to skip              train.py:449-452
+    additional_pre_init_fn: Callable      # (job_config)                                               train.py:121-122
+    additional_post_init_fn: Callable     # (model, init_device)                                       train.py:274-281
+    get_num_flop_per_token_fn: Callable   # (num_params, model_config, seq_len) -> int
+    get_num_params_fn: Callable           # (model, exclude_embedding=False) -> int
+    build_metrics_processor_fn: Callable  # (job_config, parallel_dims) — the reference's own is used (logging: out of scope)
 
 
-_REGISTRY = _Registry()
-_train_specs = _REGISTRY          # `name in _train_specs` keeps working for callers of the old module dict
+_train_specs: Dict[str, TrainSpec] = {}
 
 
-def register_train_spec(train_spec) -> None:
-    _REGISTRY.add(train_spec)
+def register_train_spec(train_spec: TrainSpec) -> None:
+    if train_spec.name in _train_specs:
+        raise ValueError(f"Model {train_spec.name} is already registered.")
+    _train_specs[train_spec.name] = train_spec
 
 
-def get_train_spec(name: str):
-    return _REGISTRY.get(name)
+def get_train_spec(name: str) -> TrainSpec:
+    if name not in _train_specs:
+        raise ValueError(f"Model {name} is not registered.")
+    return _train_specs[name]
 
 
-def apply_to_train_specs(func: Callable) -> None:
-    _REGISTRY.map_inplace(func)
+def apply_to_train_specs(func: Callable[[TrainSpec], TrainSpec]) -> None:
+    for name in list(_train_specs):
+        _train_specs[name] = func(_train_specs[name])
