@@ -47,8 +47,8 @@ def test_library_loads_on_gpu():
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("rows,H", [(37, 64), (130, 256), (64, 1280), (96, 2048), (33, 4096), (16, 8192)])
-def test_rmsnorm(dtype, rows, H):
+@pytest.mark.parametrize("rows,H", [(37, 64), (130, 256), (64, 1280), (96, 2048), (40, 3584), (33, 4096), (16, 8192)])
+def test_rmsnorm(dtype, rows, H):   # 3584 = Kimi-Audio-7B hidden size (config E)
     F = _f()
     if dtype == torch.float32 and H > 4096:
         pytest.skip("fp32 rows wider than 4096 are outside the kernel's register budget (bf16 goes to 8192)")
@@ -188,7 +188,7 @@ def test_ce_golden(golden, case):
 
 
 @pytest.mark.parametrize("dtype,V", [(torch.float32, 1000), (torch.bfloat16, 128256), (torch.bfloat16, 156032),
-                                      (torch.bfloat16, 1003)])
+                                      (torch.bfloat16, 168448), (torch.bfloat16, 1003)])   # 168448 = Kimi-Audio (config E)
 def test_ce_large_vocab(dtype, V):
     F = _f()
     B, T = 2, 24
@@ -491,6 +491,82 @@ def test_sharded_attention_emulated_context_parallel(cp, T, Nh, Nkv, D, maxdoc):
         dv_sum += vl.grad.float()
     _close(dk_sum, kf.grad, 3e-2, 2e-2, "sum of partial dK")
     _close(dv_sum, vf.grad, 3e-2, 2e-2, "sum of partial dV")
+
+
+def _attn_rows_fp64(q, k, v, doc, rows, scale):
+    """Direct evaluation of the document-masked causal attention for a few query rows of one head (fp64 on the host):
+    q [T, D], k / v [T, D] (bf16-rounded values as float64), doc [T] -> [len(rows), D]."""
+    out = []
+    for r in rows:
+        allow = (doc[: r + 1] == doc[r]) & (doc[r] > 0)
+        if not allow.any():
+            out.append(torch.zeros(q.shape[1], dtype=torch.float64))
+            continue
+        s = (k[: r + 1][allow] @ q[r]) * scale
+        p = torch.softmax(s, dim=0)
+        out.append(p @ v[: r + 1][allow])
+    return torch.stack(out)
+
+
+def test_config_d_long_audio_context_parallel_segments():
+    """BASELINE config D at full size: one row of T = 65536 holding two 30 000-token recordings + short fill, Qwen2-Audio
+    head shape, cp = 4 with head/tail load balancing = 16384 query rows per rank in two 8192-row segments
+    (`tn_attn_fwd_seg` / `tn_attn_bwd_seg`, global K/V + document ids).  Checked against
+      * direct fp64 evaluation of the masked softmax on sampled rows (first / last rows of every segment, rows next
+        to the document boundaries, pad rows), forward;
+      * the size-independent properties: every rank's forward and dQ equal the rows of the FULL-sequence kernel, the
+        four ranks' partial dK / dV sum to the full dK / dV, and the packed row equals each 30 000-token document
+        run on its own (pack-vs-pad, tests/touchnet/utils/test_pack_loss.py's property), forward and backward."""
+    F = _f()
+    B, T, Nh, Nkv, D, cp = 1, 65536, 4, 4, 128, 4
+    lens = [30000, 30000, 700, 1200, 900, 2000]                       # 64800 tokens, 736 pad positions
+    doc = torch.zeros(B, T, dtype=torch.int64)
+    t = 0
+    for i, n in enumerate(lens):
+        doc[0, t:t + n] = i + 1
+        t += n
+    g = torch.Generator().manual_seed(65536)
+    q, k, v, do = [torch.randn(B, T, n, D, generator=g).bfloat16().to(DEV) for n in (Nh, Nkv, Nkv, Nh)]
+    mask = F.build_packed_mask(doc.to(DEV))
+    qf, kf, vf = [x.clone().requires_grad_() for x in (q, k, v)]
+    of = F.packed_attention(qf, kf, vf, mask)
+    of.backward(do)
+    scale = D ** -0.5
+    Tc = T // (2 * cp)                                                # 8192
+    dk_sum, dv_sum = torch.zeros_like(k, dtype=torch.float32), torch.zeros_like(v, dtype=torch.float32)
+    docs_cpu = doc[0]
+    for r in range(cp):
+        offs = (r * Tc, (2 * cp - 1 - r) * Tc)
+        pos = torch.cat([torch.arange(o, o + Tc) for o in offs])
+        shard = F.SeqShard(((0, Tc, offs[0]), (Tc, Tc, offs[1])), 2 * Tc)
+        ql = q[:, pos].clone().requires_grad_()
+        kl, vl = k.clone().requires_grad_(), v.clone().requires_grad_()
+        ol = F.packed_attention_sharded(ql, kl, vl, mask, shard)
+        ol.backward(do[:, pos].contiguous())
+        assert torch.equal(ol, of[:, pos]), f"rank {r}: forward differs from the full-sequence kernel"
+        _close(ql.grad, qf.grad[:, pos], 1e-6, 0, f"rank {r} dQ")
+        dk_sum += kl.grad.float()
+        dv_sum += vl.grad.float()
+        # direct evaluation on sampled rows of this rank (head 1)
+        rows = sorted({offs[0], offs[0] + 1, offs[0] + Tc - 1, offs[1], offs[1] + Tc // 2, offs[1] + Tc - 1}
+                      | {x for x in (29999, 30000, 30001, 59999, 60000, 60699, 60700) if any(o <= x < o + Tc for o in offs)})
+        want = _attn_rows_fp64(q[0, :, 1].double().cpu(), k[0, :, 1].double().cpu(), v[0, :, 1].double().cpu(),
+                               docs_cpu, rows, scale)
+        local = [int((pos == x).nonzero()[0, 0]) for x in rows]
+        _close(ol[0, local, 1], want, 2e-2, 2e-2, f"rank {r}: sampled rows vs direct evaluation")
+    _close(dk_sum, kf.grad, 6e-2, 3e-2, "sum of the four partial dK")
+    _close(dv_sum, vf.grad, 6e-2, 3e-2, "sum of the four partial dV")
+    # packed == each long document on its own
+    for s_, e_ in ((0, 30000), (30000, 60000)):
+        q1, k1, v1 = [x[:, s_:e_].clone().requires_grad_() for x in (q, k, v)]
+        o1 = F.packed_attention(q1, k1, v1, F.causal_mask(1, e_ - s_, DEV))
+        o1.backward(do[:, s_:e_].contiguous())
+        _close(of[:, s_:e_], o1, 1e-2, 1e-2, f"O of document [{s_}, {e_})")
+        _close(qf.grad[:, s_:e_], q1.grad, 2e-2, 2e-2, "dQ")
+        _close(kf.grad[:, s_:e_], k1.grad, 6e-2, 3e-2, "dK")
+        _close(vf.grad[:, s_:e_], v1.grad, 6e-2, 3e-2, "dV")
+    pad = docs_cpu == 0
+    assert float(of[0][pad].float().abs().max()) == 0.0 and float(kf.grad[0][pad].float().abs().max()) == 0.0
 
 
 # ------------------------------------------------------------------------------------ linear layers

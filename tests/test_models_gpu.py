@@ -1,7 +1,8 @@
 """GPU parity of the assembled models / training step (HIP kernels, bf16) against the oracle (fp32 eager on
-the same bf16-rounded weights and batch).  Tolerance: north_star's loss bound 1e-3 relative would need fp32
-activations; with bf16 activations through 2 layers the observed gap is O(1e-3), asserted at 1e-2 here and
-measured exactly in the printed message."""
+the same bf16-rounded weights and batch).  Tolerances (north_star): loss within 1e-3 relative — asserted; logits on
+the valid (non-pad) rows within 8 % (worst element) / 0.6 % (mean) of the logit scale and every parameter gradient
+within 8 % of its own scale
+(bf16 activations through the stack vs fp32 activations in the oracle: a few bf16 ulps per op)."""
 import numpy as np
 import pytest
 import torch
@@ -29,6 +30,43 @@ def _oracle_run(model_cls, cfg, state, fwd, batch):
     return ref, logits, ps, pt
 
 
+LOSS_REL = 1e-3      # north_star: "loss matching reference within 1e-3 rel"
+
+
+def _device_vs_oracle(tr, model_cls, cfg, fwd, batch, cpu_batch=None, logit_tol=8e-2, logit_mean_tol=6e-3, grad_tol=8e-2):
+    """One forward / loss / backward of the product model on the device vs the oracle on the CPU: loss (1e-3 rel),
+    logits on valid rows, ALL parameter gradients."""
+    data = tr.next_batch(batch)
+    inputs = {k: v for k, v in data.items() if k not in ("labels", "num_sentence", "sentence_lens", "shift_labels")}
+    tr.optimizer.zero_grad()
+    pred = tr.model(**inputs)
+    loss, per_tok = tr.spec.loss_fn(pred.logits, data["labels"], data["sentence_lens"], data["num_sentence"])
+    loss.backward()
+    ref, logits, ps, pt = _oracle_run(model_cls, cfg, tr.model.state_dict(), fwd, cpu_batch or batch)
+    rel = abs(float(loss) - float(ps)) / abs(float(ps))
+    rel_t = abs(float(per_tok) - float(pt)) / abs(float(pt))
+    valid = batch["attention_mask"] > 0
+    got = pred.logits.detach().float().cpu()
+    scale = float(logits.detach()[valid].abs().max())
+    e_logit = float((got[valid] - logits.detach()[valid]).abs().max()) / scale
+    e_mean = float((got[valid] - logits.detach()[valid]).abs().mean()) / scale
+    report = []
+    for (n, p), (_, q) in zip(tr.model.named_parameters(), ref.named_parameters()):
+        if not p.requires_grad:
+            continue
+        assert p.grad is not None, n
+        gd, r = p.grad.float().cpu(), q.grad
+        denom = float(r.abs().max().clamp_min(1e-6))
+        report.append((float((gd - r).abs().max()) / denom, n, denom))
+    report.sort(reverse=True)
+    print(f"PARITY loss rel {rel:.2e} (per token {rel_t:.2e}), logits max {e_logit:.2e} mean {e_mean:.2e} of scale {scale:.3g}, "
+          f"worst grads {[(round(e, 4), n) for e, n, _ in report[:3]]}")
+    assert rel < LOSS_REL and rel_t < LOSS_REL, (float(loss), float(ps), rel, rel_t)
+    assert e_logit < logit_tol and e_mean < logit_mean_tol, (e_logit, e_mean)
+    assert report[0][0] < grad_tol, f"worst relative grad errors {report[:6]}"
+    return loss, per_tok
+
+
 def test_llama_text_step_matches_oracle():
     import touchnet_amd.specs  # noqa: F401
     from touchnet_amd.bin.train import TrainConfig, Trainer
@@ -38,24 +76,10 @@ def test_llama_text_step_matches_oracle():
     tr = Trainer(TrainConfig(training_model_name="llama_mi355", training_enable_fused_ce=False), cfg,
                  torch.device(DEV))
     batch = text_batch(512, 4, 256, seed=3, max_len=60)
-    data = tr.next_batch(batch)
-    loss, per_tok, acc = tr.forward_loss(data)
-    loss.backward()
     fwd = lambda m, b: m(input_ids=b["input_ids"], position_ids=b["position_ids"], attention_mask=b["attention_mask"])
-    ref, logits, ps, pt = _oracle_run(PackedCausalLM, cfg, tr.model.state_dict(), fwd, batch)
-    rel = abs(float(loss) - float(ps)) / abs(float(ps))
-    assert rel < 1e-2, (float(loss), float(ps), rel)
-    assert abs(float(per_tok) - float(pt)) / abs(float(pt)) < 1e-2
-    worst, report = 0.0, []
-    for (n, p), (_, q) in zip(tr.model.named_parameters(), ref.named_parameters()):
-        g, r = p.grad.float().cpu(), q.grad
-        denom = r.abs().max().clamp_min(1e-6)
-        e = float((g - r).abs().max() / denom)
-        report.append((e, n, float(denom)))
-        worst = max(worst, e)
-    report.sort(reverse=True)
-    assert worst < 8e-2, f"worst relative grad errors {report[:6]}"
-    print(f"loss rel err {rel:.2e}, worst grad rel err {worst:.2e}")
+    loss, per_tok = _device_vs_oracle(tr, PackedCausalLM, cfg, fwd, batch)
+    with torch.no_grad():
+        _, _, acc = tr.forward_loss(tr.next_batch(batch))
     # the fused lm_head+CE path must agree with the unfused one
     tr2 = Trainer(TrainConfig(training_model_name="llama_mi355", training_enable_fused_ce=True), cfg,
                   torch.device(DEV))
@@ -81,16 +105,12 @@ def test_touch_audio_step_with_device_frontend():
                              lr_scheduler_warmup_steps=0, lr_scheduler_lr=1e-3), cfg, torch.device(DEV))
     batch, _, _ = asr_batch_from_device_frontend(512, 2, 512, torch.device(DEV), frontend=F)
     assert batch["input_features"].is_cuda and batch["input_features"].shape == (2, 512, 400)
-    data = tr.next_batch(batch)
-    loss, per_tok, acc = tr.forward_loss(data)
-    loss.backward()
     cpu_batch = dict(batch)
     cpu_batch["input_features"] = batch["input_features"].bfloat16().float()
     fwd = lambda m, b: m(input_ids=b["input_ids"], input_features=b["input_features"], position_ids=b["position_ids"],
                          attention_mask=b["attention_mask"])
-    ref, logits, ps, pt = _oracle_run(TouchAudioForCausalLM, cfg, tr.model.state_dict(), fwd, cpu_batch)
-    rel = abs(float(loss) - float(ps)) / abs(float(ps))
-    assert rel < 1e-2, (float(loss), float(ps), rel)
+    loss, _ = _device_vs_oracle(tr, TouchAudioForCausalLM, cfg, fwd, batch, cpu_batch)     # logits + ALL gradients
+    data = tr.next_batch(batch)
     # 5 optimizer steps run and reduce the loss on a fixed batch
     first = float(loss)
     for _ in range(5):
@@ -150,24 +170,26 @@ def test_fused_adamw_multi_tensor_mixed_shapes():
     torch.manual_seed(1)
     shapes = [(4096, 64), (33,), (1000, 7), (5,), (128, 130), (70000,)]
     flat = torch.randn(100003, device=DEV)
-    ps = [torch.nn.Parameter(torch.randn(*s, device=DEV)) for s in shapes]
+    # every second tensor is a bf16 parameter (bf16 gradient; the optimizer keeps its fp32 master)
+    ps = [torch.nn.Parameter(torch.randn(*s, device=DEV).to(torch.bfloat16 if i % 2 else torch.float32))
+          for i, s in enumerate(shapes)]
     ps.append(torch.nn.Parameter(flat[3:3 + 4097].detach()))          # 4-byte aligned only: scalar path
     ps.append(torch.nn.Parameter(torch.randn(10, device=DEV)))         # never receives a gradient
-    qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    qs = [torch.nn.Parameter(p.detach().float().clone()) for p in ps]
     opt = FusedAdamW(ps, lr=3e-3, max_norm=0.7)
     ref = torch.optim.AdamW(qs, lr=3e-3, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.1)
     for it in range(3):
         for i, (p, q) in enumerate(zip(ps[:-1], qs[:-1])):
             g = torch.randn_like(p) * (0.1 + i)
-            if i % 2:                                                    # bf16 gradients for half of the tensors
-                g = g.bfloat16()
             p.grad, q.grad = g.clone(), g.float().clone()
         norm = opt.step()
         ref_norm = torch.nn.utils.clip_grad_norm_(qs[:-1], 0.7)
         ref.step()
         assert float(norm) == pytest.approx(float(ref_norm), rel=2e-5)
-        for p, q in zip(ps, qs):
-            torch.testing.assert_close(p.data, q.data, rtol=3e-5, atol=3e-6)
+        for st, p, q in zip(opt.state, ps, qs):
+            torch.testing.assert_close(st["master"], q.data, rtol=3e-5, atol=3e-6)
+            if p.dtype == torch.bfloat16:
+                assert torch.equal(p.data, st["master"].bfloat16())    # the shadow the next forward reads
 
 
 def test_qwen2_audio_packed_forward_backward_small():
@@ -200,23 +222,13 @@ def test_qwen2_audio_packed_forward_backward_small():
     batch = {"input_ids": ids, "labels": labels, "position_ids": pos, "attention_mask": doc, "sentence_lens": sl,
              "num_sentence": 3, "input_features": torch.randn(n_audio, 16, Tm, generator=g),
              "audio_positions": torch.cat(apos), "audio_output_lengths": torch.full((n_audio,), 40)}
-    data = tr.next_batch(batch)
-    loss, per_tok, acc = tr.forward_loss(data)
-    loss.backward()
     cpu_batch = dict(batch)
     cpu_batch["input_features"] = batch["input_features"].bfloat16().float()
     fwd = lambda m, b: m(input_ids=b["input_ids"], input_features=b["input_features"],
                          audio_output_lengths=b["audio_output_lengths"], audio_positions=b["audio_positions"],
                          position_ids=b["position_ids"], attention_mask=b["attention_mask"])
-    ref, logits, ps, pt = _oracle_run(Qwen2AudioPackedForConditionalGeneration, cfg, tr.model.state_dict(), fwd,
-                                      cpu_batch)
-    rel = abs(float(loss) - float(ps)) / abs(float(ps))
-    assert rel < 1e-2, (float(loss), float(ps), rel)
-    for (n, p), (_, q) in zip(tr.model.named_parameters(), ref.named_parameters()):
-        if not p.requires_grad:
-            continue
-        assert p.grad is not None, n
-        assert torch.isfinite(p.grad).all(), n
+    # logits on valid rows + EVERY gradient (tower conv stem, encoder layers, projector, decoder) vs the oracle
+    _device_vs_oracle(tr, Qwen2AudioPackedForConditionalGeneration, cfg, fwd, batch, cpu_batch)
 
 
 def test_fsdp2_single_rank_rccl_matches_unsharded():
