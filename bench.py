@@ -140,7 +140,6 @@ def cpu_baseline(workload: "Workload", seconds_budget: float = 20.0):
     cfg = workload.seq_cfg
     cores = min(os.cpu_count() or 1, 64)          # eager fp32 at these widths stops scaling past ~64 threads
     torch.set_num_threads(cores)
-    T = 1024
     H, I, Nh, Nkv, D, V = (cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads,
                            cfg.num_key_value_heads, cfg.head_dim, cfg.vocab_size)
     g = torch.Generator().manual_seed(0)
@@ -150,22 +149,28 @@ def cpu_baseline(workload: "Workload", seconds_budget: float = 20.0):
                       "mlp.gate_proj": (I, H), "mlp.up_proj": (I, H), "mlp.down_proj": (H, I)}.items():
         sd[f"l.{n}.weight"] = (torch.randn(o, i, generator=g) * 0.02).requires_grad_()
     c = dict(num_attention_heads=Nh, num_key_value_heads=Nkv, head_dim=D, rms_norm_eps=cfg.rms_norm_eps)
-    doc = torch.ones(1, T, dtype=torch.int64)
-    pos = torch.arange(T)[None]
     inv = onn.rope_inv_freq(D, cfg.rope_theta, cfg.rope_scaling)
-    cos, sin = onn.rope_cos_sin(pos, inv, torch.float32)
-    allow = onn.doc_causal_allow(doc)
-    x = torch.randn(1, T, H, generator=g).requires_grad_()
+    def time_block(Tn, budget):
+        doc = torch.ones(1, Tn, dtype=torch.int64)
+        cos, sin = onn.rope_cos_sin(torch.arange(Tn)[None], inv, torch.float32)
+        allow = onn.doc_causal_allow(doc)
+        xx = torch.randn(1, Tn, H, generator=g).requires_grad_()
 
-    def block():
-        y = onn.decoder_layer(sd, "l.", c, x, cos, sin, allow)
-        y.sum().backward()
-    block()
-    t0, n = time.perf_counter(), 0
-    while time.perf_counter() - t0 < seconds_budget * 0.6 or n < 2:
+        def block():
+            onn.decoder_layer(sd, "l.", c, xx, cos, sin, allow).sum().backward()
         block()
-        n += 1
-    t_block = (time.perf_counter() - t0) / n / T                       # s per token per layer
+        t0, n = time.perf_counter(), 0
+        while time.perf_counter() - t0 < budget or n < 2:
+            block()
+            n += 1
+        return (time.perf_counter() - t0) / n / Tn                     # s per token per layer
+
+    # eager attention materialises the T x T scores whatever the documents are (the reference's CPU-capable path has no
+    # block sparsity), so its cost per token is a + b*T: two lengths give a and b, evaluated at the workload's T
+    T1, T2 = 1024, 2048
+    t1, t2 = time_block(T1, seconds_budget * 0.25), time_block(T2, seconds_budget * 0.4)
+    slope = max(0.0, (t2 - t1) / (T2 - T1))
+    t_block = t1 + slope * (workload.T - T1)
     Th = 64
     w = (torch.randn(V, H, generator=g) * 0.02).requires_grad_()
     hh = torch.randn(1, Th, H, generator=g).requires_grad_()
@@ -182,9 +187,10 @@ def cpu_baseline(workload: "Workload", seconds_budget: float = 20.0):
     t_head = (time.perf_counter() - t0) / n / Th
     per_token = t_block * cfg.num_hidden_layers + t_head
     return {"value": round(1.0 / per_token, 2), "unit": "tokens/s (extrapolated)", "cores": cores, "kind": "port",
-            "sample": f"oracle fp32 eager: 1 decoder block fwd+bwd on T={T} tokens x{cfg.num_hidden_layers} layers "
-                      f"+ lm_head/CE on {Th} tokens; attention cost at T={T} (not {workload.T}), audio tower and "
-                      f"optimizer excluded -> an upper bound on CPU throughput"}
+            "sample": f"oracle fp32 eager: 1 decoder block fwd+bwd timed at T={T1} and T={T2} "
+                      f"({t1 * 1e3:.3f} / {t2 * 1e3:.3f} ms per token per layer), per-token cost a + b*T evaluated at the "
+                      f"workload's T={workload.T}, x{cfg.num_hidden_layers} layers, + lm_head/CE on {Th} tokens; audio "
+                      f"tower and optimizer excluded -> an upper bound on CPU throughput"}
 
 
 def kernel_rooflines(workload: "Workload"):
@@ -208,21 +214,26 @@ def kernel_rooflines(workload: "Workload"):
         torch.cuda.synchronize()
         return s.elapsed_time(e) / it
 
-    def add(name, ms, bytes_=None, flops=None):
+    L_ = cfg.num_hidden_layers
+
+    def add(name, ms, bytes_=None, flops=None, per_step=0):
+        """per_step = launches of this kernel (at this shape) in one training step of the workload (0 = comparison only)"""
         if bytes_ is not None:
             a = bytes_ / (ms * 1e-3) / 1e9
             out.append({"kernel": name, "bound": "hbm", "ms": round(ms, 4), "achieved": round(a, 1),
-                        "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(a * 1e9 / HBM_PEAK, 3)})
+                        "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(a * 1e9 / HBM_PEAK, 3),
+                        "launches_per_step": per_step})
         else:
             a = flops / (ms * 1e-3) / 1e12
             out.append({"kernel": name, "bound": "mfma", "ms": round(ms, 4), "achieved": round(a, 1),
-                        "peak": MFMA_PEAK / 1e12, "unit": "TFLOP/s", "frac": round(a * 1e12 / MFMA_PEAK, 3)})
+                        "peak": MFMA_PEAK / 1e12, "unit": "TFLOP/s", "frac": round(a * 1e12 / MFMA_PEAK, 3),
+                        "launches_per_step": per_step})
     x = torch.randn(N, H, dtype=bf, device=dev)
     r = torch.randn(N, H, dtype=bf, device=dev)
     w = torch.ones(H, dtype=bf, device=dev)
-    add("add+rmsnorm fwd", t_ms(lambda: F.rms_norm(x, w, 1e-5, residual=r)), bytes_=4 * N * H * 2)
+    add("add+rmsnorm fwd", t_ms(lambda: F.rms_norm(x, w, 1e-5, residual=r)), bytes_=4 * N * H * 2, per_step=2 * L_)
     g_, u_ = torch.randn(N, I, dtype=bf, device=dev), torch.randn(N, I, dtype=bf, device=dev)
-    add("swiglu fwd", t_ms(lambda: F.swiglu(g_, u_)), bytes_=3 * N * I * 2)
+    add("swiglu fwd", t_ms(lambda: F.swiglu(g_, u_)), bytes_=3 * N * I * 2, per_step=L_)
     del g_, u_
     doc = workload.tokens["attention_mask"] if hasattr(workload, "tokens") else torch.ones(B, T, device=dev)
     mask = F.build_packed_mask(doc)
@@ -234,31 +245,33 @@ def kernel_rooflines(workload: "Workload"):
         ids, counts = np.unique(row[row > 0], return_counts=True)
         allowed += int(sum(int(c) * (int(c) + 1) // 2 for c in counts))
     fl = 4.0 * D * Nh * allowed
-    add("packed attention fwd (true masked flops)", t_ms(lambda: F.packed_attention(q, k, v, mask)), flops=fl)
+    add("packed attention fwd (true masked flops)", t_ms(lambda: F.packed_attention(q, k, v, mask)), flops=fl, per_step=L_)
     qg, kg, vg = [t.clone().requires_grad_() for t in (q, k, v)]
     o = F.packed_attention(qg, kg, vg, mask)
     do = torch.randn_like(o)
     add("packed attention bwd (true masked flops)",
-        t_ms(lambda: torch.autograd.grad(o, [qg, kg, vg], do, retain_graph=True)), flops=2.5 * fl)
+        t_ms(lambda: torch.autograd.grad(o, [qg, kg, vg], do, retain_graph=True)), flops=2.5 * fl, per_step=L_)
     del q, k, v, qg, kg, vg, o, do
     # the step's dominant kernels are the library GEMMs (72 % of its time): one of each kind at the MLP shapes, in the
     # operand layouts functional._LinearGroup gives them, plus the transpose that feeds them
     wg = torch.randn(I, H, dtype=bf, device=dev)
     add(f"hipBLASLt GEMM fwd gate_proj [{N}x{H}]x[{I}x{H}]^T", t_ms(lambda: torch.nn.functional.linear(x, wg)),
-        flops=2.0 * N * H * I)
+        flops=2.0 * N * H * I, per_step=3 * L_)        # gate, up, down forward: same flops each
+    add(f"hand-written MFMA GEMM (csrc/gemm.hip), same shape", t_ms(lambda: F.gemm_tn(x, wg)), flops=2.0 * N * H * I)
     dy = torch.randn(N, I, dtype=bf, device=dev)
     wgt = F.transpose_2d(wg)
-    add("hipBLASLt GEMM dgrad gate_proj (W pre-transposed)", t_ms(lambda: torch.mm(dy, wgt.t())), flops=2.0 * N * H * I)
+    add("hipBLASLt GEMM dgrad gate_proj (W pre-transposed)", t_ms(lambda: torch.mm(dy, wgt.t())), flops=2.0 * N * H * I,
+        per_step=3 * L_)
     dyt = torch.empty(2 * I, N, dtype=bf, device=dev)
     F.transpose_2d(dy, out=dyt[:I])
     F.transpose_2d(dy, out=dyt[I:])
     xt = F.transpose_2d(x)
     add("hipBLASLt GEMM wgrad gate+up fused (both operands pre-transposed)", t_ms(lambda: torch.mm(dyt, xt.t())),
-        flops=2.0 * N * H * 2 * I)
+        flops=2.0 * N * H * 2 * I, per_step=L_)
     add("autograd-layout wgrad gate_proj (dY^T X, for comparison)", t_ms(lambda: torch.mm(dy.t(), x)),
         flops=2.0 * N * H * I)
     add("bf16 transpose (tn_transpose_bf16) [N, I]", t_ms(lambda: F.transpose_2d(dy, out=dyt[:I])), bytes_=4 * N * I)
-    return out
+    return out, allowed
 
 
 def main():
@@ -272,6 +285,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-rooflines", action="store_true")
     ap.add_argument("--unfused-ce", action="store_true")
+    ap.add_argument("--ce-chunk", type=int, default=None, help="tokens per lm_head+CE chunk (default: TrainConfig's)")
     ap.add_argument("--compact-lm-head", action="store_true",
                     help="opt-in: lm_head + CE only on labelled positions (exact; one host sync per step)")
     ap.add_argument("--no-gemm-tuning", action="store_true", help="library-default GEMM algorithm selection")
@@ -296,6 +310,8 @@ def main():
     wl = Workload(args.workload, device, rank, args.batch, args.seqlen)
     wl.job.training_enable_fused_ce = not args.unfused_ce
     wl.job.training_ce_compact_rows = args.compact_lm_head
+    if args.ce_chunk:
+        wl.job.training_ce_chunk_tokens = args.ce_chunk
     trainer = Trainer(wl.job, wl.model_config, device, dp_mesh=mesh)
 
     def step():
@@ -356,14 +372,35 @@ def main():
         }
         if not args.no_kernel_rooflines and args.workload != "tiny":
             try:
-                line["kernels"] = kernel_rooflines(wl)
-                # the kernel family the step spends most of its time in (rocprofv3: 72 % in hipBLASLt GEMMs), measured
-                # live above; `roofline` itself stays the whole-step MFU the metric is defined on
-                gemms = [k for k in line["kernels"] if k["kernel"].startswith("hipBLASLt GEMM")]
-                if gemms:
-                    line["roofline"]["dominant_kernel"] = min(gemms, key=lambda k: k["frac"])
+                line["kernels"], allowed_pairs = kernel_rooflines(wl)
+                step_ms = elapsed / args.steps * 1e3
+                for k in line["kernels"]:
+                    k["share_of_step"] = round(k["ms"] * k["launches_per_step"] / step_ms, 4)
+                # the kernel with the LARGEST share of the step (`roofline` itself stays the whole-step MFU the metric
+                # is defined on)
+                line["roofline"]["dominant_kernel"] = max(line["kernels"], key=lambda k: k["share_of_step"])
+                # utilisation on the FLOPs the step actually executes: the formula credits 12*L*H*Dh*T of attention per
+                # token (a full T x T triangle) while packing executes only the per-document triangles, and it counts
+                # the audio tower's parameters once per TEXT token although it runs on its own frames
+                c = wl.seq_cfg
+                dec_attn = 3.5 * 4.0 * c.head_dim * c.num_attention_heads * allowed_pairs * c.num_hidden_layers
+                executed = (fpt - 12 * c.num_hidden_layers * c.num_attention_heads * c.head_dim * wl.T) * wl.B * wl.T + dec_attn
+                if wl.name == "qwen2_audio_7b":
+                    ac = wl.model_config.audio_config
+                    tower_params = sum(p.numel() for p in trainer.model.audio_tower.parameters())
+                    frames = wl.wav.shape[0] * 1500
+                    executed += 6.0 * tower_params * (frames - wl.B * wl.T)          # tower runs on frames, not tokens
+                    executed += 3.5 * 4.0 * 64 * ac.encoder_attention_heads * wl.wav.shape[0] * (1500 * 1501 // 2) * ac.encoder_layers
+                line["step_mfu_executed_flops"] = round(executed / (step_ms * 1e-3) / MFMA_PEAK, 4)
+                line["executed_flops_note"] = ("GEMM terms of the formula (6*N_wo_emb per token; tower on its 1500 frames "
+                                               "per clip) + attention on the allowed (query, key) pairs only, fwd + 2.5x bwd")
             except Exception as e:  # never lose the headline number to a diagnostics failure
                 line["kernels_error"] = repr(e)
+        tfile = os.path.join(ROOT, "profiles", f"r02_step_hbm_traffic_{wl.name}.json")
+        if os.path.exists(tfile):          # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this same command (scripts/step_traffic.sh)
+            t = json.load(open(tfile))
+            line["roofline"]["traffic"] = t["hbm_bytes_per_step"]
+            line["roofline"]["traffic_source"] = t["source"]
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(wl)
         print(json.dumps(line), flush=True)

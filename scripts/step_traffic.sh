@@ -1,0 +1,46 @@
+#!/bin/bash
+# HBM traffic of one training step from the PMC counters (MI355X_MICROARCH.md, HBM section: FETCH_SIZE and WRITE_SIZE
+# in separate passes, kernel trace only; FETCH_SIZE x 2 on gfx950 for wide coalesced streams; both in KiB).
+#   usage (on the GPU box, from the repo root): bash scripts/step_traffic.sh [workload]
+# writes gpurun_out/step_traffic/{fetch,write}/... and gpurun_out/r02_step_hbm_traffic_<workload>.json
+set -e
+wl=${1:-qwen2_audio_7b}
+R=$(pwd)
+cd /tmp; export TMPDIR=/tmp
+STEPS=2; WARM=1
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $c -d $R/gpurun_out/step_traffic/$c --output-format csv -- \
+    python $R/bench.py --workload $wl --steps $STEPS --warmup $WARM --no-cpu-baseline --no-kernel-rooflines > $R/gpurun_out/step_traffic_$c.log 2>&1
+done
+cd $R
+python - "$wl" $STEPS $WARM <<'PY'
+import csv, glob, json, sys
+wl, steps, warm = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+res, per_kernel = {}, {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    f = glob.glob(f"gpurun_out/step_traffic/{c}/**/*counter_collection.csv", recursive=True)[0]
+    rows = sorted((r for r in csv.DictReader(open(f)) if r["Counter_Name"] == c), key=lambda r: int(r["Start_Timestamp"]))
+    # a step ends with its (last) multi-tensor AdamW launch: whole steps = the kernels between consecutive ones
+    marks = [i for i, r in enumerate(rows) if "adamw_multi_kernel" in r["Kernel_Name"]]
+    assert len(marks) >= 2, "need at least two optimizer steps in the trace"
+    n = len(marks) - 1
+    tot = 0.0
+    for r in rows[marks[0] + 1: marks[-1] + 1]:
+        v = float(r["Counter_Value"])
+        tot += v
+        per_kernel.setdefault(r["Kernel_Name"][:60], {}).setdefault(c, 0.0)
+        per_kernel[r["Kernel_Name"][:60]][c] += v / n
+    res[c] = tot / n
+fetch = res["FETCH_SIZE"] * 1024 * 2            # KiB -> bytes, gfx950 doubling
+write = res["WRITE_SIZE"] * 1024
+byt = lambda v: (v.get("FETCH_SIZE", 0) * 2 + v.get("WRITE_SIZE", 0)) * 1024
+top = sorted(per_kernel.items(), key=lambda kv: -byt(kv[1]))[:12]
+out = {"workload": wl, "hbm_bytes_per_step": int(fetch + write), "fetch_bytes_per_step": int(fetch),
+       "write_bytes_per_step": int(write),
+       "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over bench.py --workload {wl} --steps {steps} "
+                 f"--warmup {warm}: kernels between consecutive optimizer steps ({n} whole steps averaged; model init and "
+                 f"the first step excluded); FETCH_SIZE doubled per the gfx950 correction",
+       "top_kernels_GB_per_step": {k: round(byt(v) / 1e9, 2) for k, v in top}}
+json.dump(out, open(f"gpurun_out/r02_step_hbm_traffic_{wl}.json", "w"), indent=1)
+print(json.dumps(out)[:900])
+PY

@@ -41,7 +41,7 @@ class TrainConfig:
     training_compile: bool = False
     training_enable_cpu_offload: bool = False
     training_enable_fused_ce: bool = True      # role of `training_enable_liger_kernel`'s fused-linear-CE branch
-    training_ce_chunk_tokens: int = 16384
+    training_ce_chunk_tokens: int = 4096       # rows of logits alive at once in the fused lm_head + CE (4096 x V x 2 B)
     training_cp_halo_exchange: bool = True     # CP: point-to-point exchange of the K/V chunks a rank can see (else all-gather)
     training_ce_compact_rows: bool = False     # opt-in: lm_head only on labelled positions (one host sync per step)
     lr_scheduler_lr: float = 8e-4

@@ -182,7 +182,7 @@ class PackedCausalLM(nn.Module):
 
     def forward(self, input_ids=None, inputs_embeds=None, position_ids=None, attention_mask=None,
                 labels=None, sentence_lens=None, num_sentence=None, shift_labels=None,
-                ce_chunk_tokens: int = 16384, ce_compact: bool = False, context_parallel=None, **unused):
+                ce_chunk_tokens: int = 4096, ce_compact: bool = False, context_parallel=None, **unused):
         """Without `labels`: returns `.logits` (the reference's default path, loss_fn runs in the trainer).
         With `labels` (+ `sentence_lens`, `num_sentence`): lm_head and the packed CE run fused INSIDE the
         model — the role liger's fused-linear-CE plays in the reference (`pred.loss`, train.py:443-445), but
