@@ -186,6 +186,23 @@ int tn_pcm16_to_f32(const void* pcm_int16, float* out, long long n, void* stream
 int tn_bestrq_tokenize(const float* feat, const float* quantizer, const float* codebook, long long* codes, int T,
                        int F, int E, int V, void* stream);
 
+/* ---- greedy first-fit sequence packing on the device: the placement + scatter of
+ *      touchnet/models/llama/processing_llama.py:24-104 (batch_text) and
+ *      touchnet/models/touch_audio/processing_touch_audio.py:117-214 (batch_pairaudio_pairtext_packed), bit-identical.
+ * plan: lens int32 [n] (slots per segment: tokens + 1, plus feature rows for audio+text) -> row / col / sent (document
+ *       index inside the row, from 1) / batch int32 [n]; counts int32 [3] = {batches with >= 1 segment, segments longer
+ *       than T, error flag (set when such a segment exists and skip_too_long == 0)}; skipped segments get row = -1.
+ * fill: writes the five int64 [B, T] buffers (pad / -100 / 0 / 0 / 1 elsewhere) and, when feats != NULL, the fp32
+ *       [B, T, F] feature buffer of batch `which_batch`; segment i = alen[i] feature rows then bos + ntok[i] tokens
+ *       (labels pre-shifted: tokens + eos); tok_off / feat_off: offsets of segment i in `tokens` / `feat_src` rows. */
+int tn_pack_plan(const int* lens, int n, int B, int T, int skip_too_long, int* row, int* col, int* sent, int* batch,
+                 int* counts, void* stream);
+int tn_pack_fill(const int* row, const int* col, const int* sent, const int* batch, int which_batch, int n,
+                 const int* ntok, const long long* tok_off, const long long* tokens, const int* alen,
+                 const long long* feat_off, const float* feat_src, int F, int B, int T, long long bos, long long eos,
+                 long long pad, long long* input_ids, long long* labels, long long* position_ids, long long* doc,
+                 long long* sentence_lens, float* feats, int* nsent, void* stream);
+
 /* ---- hand-written bf16 MFMA GEMM for the linear layers (q/k/v/o/gate/up/down/lm_head of the decoder blocks,
  *      fc1/fc2/out_proj of the audio tower): replaces torch.nn.functional.linear / liger's MLP swap,
  *      touchnet/models/llama/__init__.py:11-15.

@@ -855,3 +855,95 @@ def test_gemm_tn_deterministic():
     first = F.gemm_tn(a, b).clone()
     for _ in range(5):
         assert torch.equal(F.gemm_tn(a, b), first)
+
+
+# ---------------------------------------------------------------------------------------- device-side packers
+def _split_tokens(flat, lens):
+    out, o = [], 0
+    for n in lens:
+        out.append([int(v) for v in flat[o:o + n]])
+        o += n
+    return out
+
+
+@pytest.mark.parametrize("window", [3, 7, 4096])
+@pytest.mark.parametrize("case", ["overflow", "exactfit", "droplast", "single"])
+def test_device_packer_text_bit_exact_vs_reference_goldens(golden, case, window):
+    """tn_pack_plan + tn_pack_fill == the reference's batch_text on its own golden streams, for any window size
+    (open batches are carried across windows)."""
+    import types
+    from touchnet_amd.data.device_packer import batch_text_device
+    g = golden("packing_text.npz")
+    B, T, drop, nb = [int(v) for v in g[f"{case}/meta"]]
+    sents = _split_tokens(g[f"{case}/tokens"], g[f"{case}/lens"])
+    cfg = types.SimpleNamespace(dataset_batchsize=B, dataset_text_seqlen=T, dataloader_drop_last_batch=bool(drop))
+    tok = types.SimpleNamespace(bos=1, eos=2, pad=0)
+    got = list(batch_text_device(({"input_ids": s} for s in sents), cfg, tok, window=window))
+    assert len(got) == nb
+    for i, b in enumerate(got):
+        for k in ("input_ids", "labels", "position_ids", "attention_mask", "sentence_lens"):
+            assert b[k].is_cuda and b[k].dtype == torch.int64
+            np.testing.assert_array_equal(b[k].cpu().numpy(), g[f"{case}/b{i}/{k}"], err_msg=f"{case} b{i} {k}")
+        assert int(b["num_sentence"]) == int(g[f"{case}/b{i}/num_sentence"])
+
+
+@pytest.mark.parametrize("window", [2, 5, 1024])
+@pytest.mark.parametrize("case", ["mixed", "droplast"])
+def test_device_packer_asr_bit_exact_vs_reference_goldens(golden, case, window):
+    import types
+    from touchnet_amd.data.device_packer import batch_pairaudio_pairtext_packed_device
+    g = golden("packing_asr.npz")
+    B, T, drop, nb, F = [int(v) for v in g[f"{case}/meta"]]
+    ids = _split_tokens(g[f"{case}/tokens"], g[f"{case}/tlens"])
+    feats, o = [], 0
+    for a in g[f"{case}/alens"]:
+        feats.append(torch.from_numpy(g[f"{case}/feats"][o:o + a]).to(DEV))
+        o += a
+    cfg = types.SimpleNamespace(dataset_batchsize=B, dataset_text_seqlen=T, dataset_audio_seqlen=T,
+                                audiofeat_num_mel_bins=F, audiofeat_stack_length=1,
+                                dataloader_drop_last_batch=bool(drop))
+    tok = types.SimpleNamespace(bos=1, eos=2, pad=0)
+    data = ({"audiofeat": f, "input_ids": i} for f, i in zip(feats, ids))
+    got = list(batch_pairaudio_pairtext_packed_device(data, cfg, tok, window=window))
+    assert len(got) == nb
+    for i, b in enumerate(got):
+        for k in ("input_ids", "labels", "position_ids", "attention_mask", "sentence_lens", "input_features",
+                  "shift_labels"):
+            np.testing.assert_array_equal(b[k].cpu().numpy(), g[f"{case}/b{i}/{k}"], err_msg=f"{case} b{i} {k}")
+        assert int(b["num_sentence"]) == int(g[f"{case}/b{i}/num_sentence"])
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_device_packers_equal_host_packers_on_random_streams(seed):
+    """Random B, T, drop_last, lengths incl. exact fits, empty sentences, over-long utterances (skipped) and streams
+    ending on a full buffer: device packers == host packers (which the reference goldens pin), bit for bit."""
+    import types
+    from touchnet_amd.data.device_packer import batch_pairaudio_pairtext_packed_device, batch_text_device
+    from touchnet_amd.models.llama.processing_llama import batch_text
+    from touchnet_amd.models.touch_audio.processing_touch_audio import batch_pairaudio_pairtext_packed
+    rng = np.random.RandomState(500 + seed)
+    B, T = int(rng.randint(1, 5)), int(rng.choice([8, 17, 32, 64, 257]))
+    drop = bool(rng.randint(2))
+    n = int(rng.randint(0, 60))
+    tok = types.SimpleNamespace(bos=1, eos=2, pad=0)
+    sents = [[int(v) for v in rng.randint(3, 50, size=int(rng.randint(0, T)))] for _ in range(n)]
+    cfg = types.SimpleNamespace(dataset_batchsize=B, dataset_text_seqlen=T, dataset_audio_seqlen=T,
+                                audiofeat_num_mel_bins=3, audiofeat_stack_length=2, dataloader_drop_last_batch=drop)
+    keys = ("input_ids", "labels", "position_ids", "attention_mask", "sentence_lens")
+    want = list(batch_text(({"input_ids": s} for s in sents), cfg, tok))
+    got = list(batch_text_device(({"input_ids": s} for s in sents), cfg, tok, window=int(rng.randint(1, 20))))
+    assert len(got) == len(want)
+    for a, b in zip(got, want):
+        for k in keys:
+            assert torch.equal(a[k].cpu(), b[k]), k
+        assert int(a["num_sentence"]) == b["num_sentence"]
+    pairs = [(torch.from_numpy(rng.randn(int(rng.randint(1, T + 3)), 6).astype(np.float32)),
+              [int(v) for v in rng.randint(3, 50, size=int(rng.randint(0, 6)))]) for _ in range(n)]
+    want = list(batch_pairaudio_pairtext_packed(({"audiofeat": f, "input_ids": s} for f, s in pairs), cfg, tok))
+    got = list(batch_pairaudio_pairtext_packed_device(({"audiofeat": f.to(DEV), "input_ids": s} for f, s in pairs), cfg,
+                                                      tok, window=int(rng.randint(1, 20))))
+    assert len(got) == len(want)
+    for a, b in zip(got, want):
+        for k in keys + ("input_features",):
+            assert torch.equal(a[k].cpu(), b[k]), k
+        assert int(a["num_sentence"]) == b["num_sentence"]

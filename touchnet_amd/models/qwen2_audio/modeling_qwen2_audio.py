@@ -197,13 +197,18 @@ class Qwen2AudioPackedForConditionalGeneration(nn.Module):
         if input_features is not None:
             feats = self.multi_modal_projector(self.audio_tower(input_features))        # [n, Ta, H]
             n, Ta, _ = feats.shape
-            if audio_output_lengths is not None:
-                keep = torch.arange(Ta, device=feats.device)[None, :] < audio_output_lengths[:, None]
-                feats = feats[keep]                                                      # `:202-205`
-            else:
-                feats = feats.reshape(n * Ta, H)
-            if audio_positions is None:
+            feats = feats.reshape(n * Ta, H)
+            if audio_positions is None:                      # (costs a host sync: loaders should supply the positions)
                 audio_positions = (input_ids.reshape(-1) == self.config.audio_token_index).nonzero().squeeze(1)
+            if audio_output_lengths is not None:
+                # rows [0, len_i) of clip i, in clip order (`:202-205`'s boolean compaction) WITHOUT a data-dependent
+                # shape: the number of valid rows is the number of AUDIO positions, known from the tensor's size
+                total = audio_positions.numel()
+                ends = torch.cumsum(audio_output_lengths.to(torch.int64), 0)
+                idx = torch.arange(total, device=feats.device)
+                clip = torch.searchsorted(ends, idx, right=True).clamp_(max=n - 1)
+                src = clip * Ta + (idx - (ends - audio_output_lengths)[clip])
+                feats = feats.index_select(0, src.clamp_(0, n * Ta - 1))
             if feats.shape[0] != audio_positions.numel():
                 raise ValueError(f"audio features ({feats.shape[0]}) and audio tokens "
                                  f"({audio_positions.numel()}) mismatch")
