@@ -137,7 +137,7 @@ def test_fsdp2_step_two_ranks_gloo(world):
 CP_CFG = dict(TINY, num_hidden_layers=1)
 
 
-def _cp_reference():
+def _cp_reference(B=1, T=512):
     import oracle.ops as oops
     from touchnet_amd.data.synthetic import text_batch
     from touchnet_amd.models.backend import use_ops
@@ -145,7 +145,7 @@ def _cp_reference():
     torch.manual_seed(11)
     model = PackedCausalLM(DecoderConfig.from_dict(CP_CFG))
     model.post_init()
-    batch = text_batch(16, 1, 512, seed=5, max_len=90)
+    batch = text_batch(16, B, T, seed=5, max_len=90)
     with use_ops(oops):
         out = model(input_ids=batch["input_ids"], position_ids=batch["position_ids"],
                     attention_mask=batch["attention_mask"], labels=batch["labels"],
@@ -180,9 +180,10 @@ def _cp_worker(rank, world, port, ref_state, ref_grads, ref_loss, batch, ret):
                     local = p._local_tensor if hasattr(p, "_local_tensor") else p
                     local.copy_(full.chunk(world, dim=0)[rank] if local.shape != full.shape else full)
             data = tr.next_batch(batch)
-            assert data["input_ids"].shape[1] == 512 // world and data["attention_mask"].shape[1] == 512
+            T = batch["input_ids"].shape[1]
+            assert data["input_ids"].shape[1] == T // world and data["attention_mask"].shape[1] == T
             # head/tail load balancing: rank r holds chunks r and 2cp-1-r
-            Tc = 512 // (2 * world)
+            Tc = T // (2 * world)
             exp = torch.cat([batch["input_ids"][:, rank * Tc:(rank + 1) * Tc],
                              batch["input_ids"][:, (2 * world - 1 - rank) * Tc:(2 * world - rank) * Tc]], dim=1)
             assert torch.equal(data["input_ids"], exp)
@@ -208,9 +209,13 @@ def _cp_worker(rank, world, port, ref_state, ref_grads, ref_loss, batch, ret):
             dist.destroy_process_group()
 
 
-def test_context_parallel_two_ranks_gloo():
-    ref_state, ref_grads, ref_loss, batch = _cp_reference()
-    world = 2
+@pytest.mark.parametrize("world,B,T", [(2, 1, 512), (4, 1, 1024), (2, 2, 512)])
+def test_context_parallel_full_step_gloo(world, B, T):
+    """A full forward + loss + backward under context parallelism (halo exchange issued before the query path, finished
+    in front of the attention; dK/dV returned under the query-path backward) == the single-process run: the loss parts
+    of the cp ranks add up, FSDP-averaged gradients x cp == the reference gradients.  B = 1: chunks are received
+    straight into the global K/V buffers; B = 2: through staging buffers."""
+    ref_state, ref_grads, ref_loss, batch = _cp_reference(B, T)
     with mp.Manager() as mgr:
         ret = mgr.dict()
         mp.spawn(_cp_worker, args=(world, _free_port(), ref_state, ref_grads, ref_loss, batch, ret), nprocs=world,
@@ -315,3 +320,89 @@ def test_halo_exchange_equals_allgather_and_trims(world):
         fwd = sum(bool(need[r, c]) for c in range(C) if c not in mine)            # chunks received in the forward
         bwd = sum(bool(need[p, c]) for p in range(world) if p != r for c in mine)  # gradient pieces coming back
         assert results[r][1]["one_doc"] == (fwd + bwd) * chunk_bytes, (r, results[r][1], fwd, bwd)
+
+
+@pytest.mark.parametrize("cp", [2, 4])
+def test_device_side_halo_table_equals_exact_one_on_packer_ids(cp):
+    """halo_need_ranges (torch ops on chunk-level id ranges, runs on the device without a host round trip) == halo_need
+    (exact, host) for ids that do not decrease along a row — what every packer emits —, and is a SUPERSET of it for
+    arbitrary ids (never drops a chunk a rank needs)."""
+    from touchnet_amd.utils.context_parallel import halo_need, halo_need_ranges
+    rng = np.random.RandomState(cp)
+    T = 2 * cp * 128
+    for trial in range(20):
+        B = int(rng.randint(1, 4))
+        ids = np.zeros((B, T), dtype=np.int64)
+        for b in range(B):
+            t, d = 0, 1
+            end = T - int(rng.randint(0, 200))
+            while t < end:
+                n = int(rng.randint(1, [40, 300, 2000][trial % 3]))
+                ids[b, t:min(t + n, end)] = d
+                t += n
+                d += 1
+        exact = halo_need(ids, cp)
+        got = halo_need_ranges(torch.from_numpy(ids), cp).numpy()
+        assert np.array_equal(got, exact), trial
+        shuffled = ids.copy()
+        perm = rng.permutation(int(ids.max()) + 1)
+        perm = np.concatenate([[0], 1 + rng.permutation(int(ids.max()))])       # relabel documents, keep 0 = pad
+        shuffled = perm[ids]
+        got = halo_need_ranges(torch.from_numpy(shuffled), cp).numpy()
+        assert not (halo_need(shuffled, cp) & ~got).any(), trial
+
+
+def _order_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    try:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import oracle.ops as oops
+        from touchnet_amd.models.backend import use_ops
+        from touchnet_amd.models.llama import DecoderConfig
+        from touchnet_amd.models.llama.modeling_llama import Attention, RotaryEmbedding
+        from touchnet_amd.utils import context_parallel as CP
+        cfg = DecoderConfig(vocab_size=16, hidden_size=64, intermediate_size=128, num_hidden_layers=1,
+                            num_attention_heads=4, num_key_value_heads=2, head_dim=16)
+        T = 512
+        cp = CP.ContextParallel(dist.group.WORLD, T)
+        doc = torch.ones(1, T, dtype=torch.int64)
+        cp.set_documents(doc)
+        order = []
+        for name, cls in (("issue_return", CP._HaloFinish), ("finish_return", CP._HaloStart)):
+            orig = cls.backward
+
+            def wrap(ctx, *a, _o=orig, _n=name):
+                order.append(_n)
+                return _o(ctx, *a)
+            cls.backward = staticmethod(wrap)
+        torch.manual_seed(0)
+        attn = Attention(cfg)
+        attn.q_proj.weight.register_hook(lambda g: order.append("q_proj_backward"))
+        attn.k_proj.weight.register_hook(lambda g: order.append("k_proj_backward"))
+        with use_ops(oops):
+            x = torch.randn(1, T // world, 64, requires_grad=True)
+            cos, sin = RotaryEmbedding(cfg)(cp.shard(torch.arange(T)[None]), torch.float32)
+            mask = oops.build_packed_mask(doc)
+            mask.cp = cp
+            attn(x, cos, sin, mask).sum().backward()
+        ret[rank] = ("ok", order)
+    except Exception as e:
+        import traceback
+        ret[rank] = ("fail", traceback.format_exc(), repr(e))
+    finally:
+        if dist.is_initialized():
+            dist.barrier()
+            dist.destroy_process_group()
+
+
+def test_halo_return_travels_under_the_query_path_backward():
+    """The overlap schedule of utils/context_parallel.py::exchange_kv in the backward pass: the partial dK/dV are SENT
+    as soon as the attention backward has produced them, the query projection's backward runs next, and only then does
+    the owner wait for them — right before the k/v projection backward that consumes them."""
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_order_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+        results = dict(ret)
+    for r in range(2):
+        assert results[r][0] == "ok", results[r][1]
+        assert results[r][1] == ["issue_return", "q_proj_backward", "finish_return", "k_proj_backward"], results[r][1]

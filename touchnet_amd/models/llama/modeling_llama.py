@@ -62,6 +62,9 @@ class Attention(nn.Module):
 
     def forward(self, x, cos, sin, mask):
         B, T, _ = x.shape
+        cp = getattr(mask, "cp", None)
+        if cp is not None and cp.need is not None:
+            return self._forward_context_parallel(x, cos, sin, mask, cp)
         # one autograd node for the three projections of x: their weight gradients run as ONE GEMM in the forward
         # layout (functional._LinearGroup); parameters keep the HF names and shapes
         q, k, v = ops().linear_group(x, [(self.q_proj.weight, self.q_proj.bias), (self.k_proj.weight, self.k_proj.bias),
@@ -70,12 +73,29 @@ class Attention(nn.Module):
         k = k.view(B, T, self.num_kv_heads, self.head_dim)
         v = v.view(B, T, self.num_kv_heads, self.head_dim)
         q, k = ops().apply_rope(q, k, cos, sin)
-        cp = getattr(mask, "cp", None)
-        if cp is not None:            # context parallel: local queries vs all-gathered K/V (utils/context_parallel.py)
+        if cp is not None:            # context parallel, all-gather rotate method (utils/context_parallel.py)
             a = ops().packed_attention_sharded(q, cp.gather_seq(k), cp.gather_seq(v), mask, cp.seq_shard(),
                                                self.scaling)
         else:
             a = ops().packed_attention(q, k, v, mask, self.scaling)
+        return ops().linear_group(a.view(B, T, self.num_heads * self.head_dim), [(self.o_proj.weight, None)])[0]
+
+
+    def _forward_context_parallel(self, x, cos, sin, mask, cp):
+        """Halo-exchange form: K/V first, their exchange is issued, the QUERY path (projection + RoPE) runs while the
+        chunks travel over xGMI, the compute stream waits for them in front of the attention kernel; the backward
+        returns the partial dK/dV under the query-path backward GEMMs (utils/context_parallel.py::exchange_kv)."""
+        from touchnet_amd.utils.context_parallel import exchange_kv
+        B, T, _ = x.shape
+        k, v = ops().linear_group(x, [(self.k_proj.weight, self.k_proj.bias), (self.v_proj.weight, self.v_proj.bias)])
+        k = k.view(B, T, self.num_kv_heads, self.head_dim)
+        v = v.view(B, T, self.num_kv_heads, self.head_dim)
+        k, _ = ops().apply_rope(k, k.new_empty(B, T, 0, self.head_dim), cos, sin)       # rotate K alone
+        finish = exchange_kv(cp, k, v)
+        q = ops().linear_group(x, [(self.q_proj.weight, self.q_proj.bias)])[0].view(B, T, self.num_heads, self.head_dim)
+        q, _ = ops().apply_rope(q, q.new_empty(B, T, 0, self.head_dim), cos, sin)
+        k_full, v_full = finish()
+        a = ops().packed_attention_sharded(q, k_full, v_full, mask, cp.seq_shard(), self.scaling)
         return ops().linear_group(a.view(B, T, self.num_heads * self.head_dim), [(self.o_proj.weight, None)])[0]
 
 

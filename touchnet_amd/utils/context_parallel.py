@@ -16,6 +16,20 @@ over the direct links), zeros elsewhere (the kernels never let a query see them:
 masked); the backward sends the dK/dV partial sums back over the same pairs.  On packed batches of documents much
 shorter than a chunk a rank receives 1-2 neighbour chunks per layer instead of 2*cp - 2.  Without `set_documents`
 the all-gather / reduce-scatter pair (the reference's "allgather" rotate method) is used.
+
+Overlap (`exchange_kv`): K and V of a layer travel in ONE batch of isend/irecv that is only ISSUED when the
+projections are done — the transfers then run on the communication stream of the process group (RCCL's own HIP
+stream: `batch_isend_irecv` returns at once) while the compute stream goes on with the query path (q projection,
+RoPE), and the compute stream waits for them right in front of the attention kernel.  The backward mirrors it: the
+partial dK/dV of the remote chunks are sent back as soon as the attention backward has produced them, the query-path
+backward GEMMs run meanwhile, and the owner adds the returned partial sums just before the k/v projection backward.
+Two autograd nodes per layer make that order happen (the engine runs ready nodes in reverse creation order):
+`_HaloStart` (issue forward / finish backward) is created BEFORE the query path, `_HaloFinish` (finish forward / issue
+backward) after it.  Chunks are received straight into the global K/V buffers when a chunk is contiguous there
+(B = 1: config D), which are left UNINITIALISED elsewhere — the attention kernels only touch tiles whose id range can
+meet the queries', and the halo is computed with the same (conservative) range test, so every tile they touch has
+been received.  `set_documents` derives the halo from chunk-level id ranges ON THE DEVICE and reads back only the
+[cp, 2cp] table, asynchronously (pinned copy + event, waited at the first exchange of the step).
 """
 from __future__ import annotations
 
@@ -71,6 +85,28 @@ def halo_need(ids, cp: int):
     return need
 
 
+def halo_need_ranges(doc_ids: torch.Tensor, cp: int) -> torch.Tensor:
+    """Device-side form of `halo_need` from per-chunk id RANGES: rank r needs chunk c < lc iff the positive-id ranges
+    of c and lc overlap in some batch row (the test the attention kernels use per 64-tile, at chunk granularity).
+    Equal to `halo_need` when ids are non-decreasing along a row (every packer here), a superset otherwise.
+    doc_ids int [B, T] -> bool [cp, 2cp] on the same device; no host synchronisation."""
+    C = 2 * cp
+    B = doc_ids.shape[0]
+    ch = doc_ids.reshape(B, C, -1).to(torch.int64)
+    big = torch.iinfo(torch.int64).max
+    mx = ch.amax(dim=2)                                                 # [B, C] (0 = chunk is all pad)
+    mn = torch.where(ch > 0, ch, torch.full_like(ch, big)).amin(dim=2)  # min positive id (big = none)
+    live = mx > 0
+    # share[b, lc, c]: ranges overlap and both chunks hold a document
+    share = (mx[:, None, :] >= mn[:, :, None]) & (mn[:, None, :] <= mx[:, :, None]) & live[:, None, :] & live[:, :, None]
+    share = share.any(dim=0)                                            # [C (lc), C (c)]
+    idx = torch.arange(C, device=doc_ids.device)
+    earlier = idx[None, :] < idx[:, None]                               # c < lc
+    per_chunk = (share & earlier) | torch.eye(C, dtype=torch.bool, device=doc_ids.device)
+    r = torch.arange(cp, device=doc_ids.device)
+    return per_chunk[r] | per_chunk[C - 1 - r]                          # rank r owns chunks r and 2cp-1-r
+
+
 @dataclass
 class ContextParallel:
     group: object
@@ -82,13 +118,36 @@ class ContextParallel:
         if self.T % (2 * self.cp * 128):
             raise ValueError(f"T={self.T} must be a multiple of 2*cp*128 = {2 * self.cp * 128}")
         self.Tc = self.T // (2 * self.cp)
-        self.need = None                 # bool [cp, 2cp] after set_documents(): rank r needs chunk c
+        self._need = None                # bool [cp, 2cp] after set_documents(): rank r needs chunk c
+        self._need_pending = None        # (pinned host tensor, event) while the device result is on its way
         self.halo_bytes = 0              # bytes this rank received through the halo exchange (diagnostics / tests)
 
     # ---- document-aware halo ---------------------------------------------------------------------------
     def set_documents(self, doc_ids: torch.Tensor) -> None:
-        """doc_ids int [B, T] (0 = pad), identical on every rank: fixes which chunks each rank exchanges (halo_need)."""
-        self.need = halo_need(doc_ids.detach().to("cpu").numpy(), self.cp)
+        """doc_ids int [B, T] (0 = pad), identical on every rank: fixes which chunks each rank exchanges.
+        Host tensor: exact `halo_need`.  Device tensor: `halo_need_ranges` on the device, the [cp, 2cp] table comes
+        back through a pinned buffer without blocking (it is waited for at the first exchange of the step)."""
+        if not doc_ids.is_cuda:
+            self._need, self._need_pending = halo_need(doc_ids.detach().numpy(), self.cp), None
+            return
+        table = halo_need_ranges(doc_ids.detach(), self.cp)
+        host = torch.empty(table.shape, dtype=torch.bool).pin_memory()
+        host.copy_(table, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._need, self._need_pending = None, (host, ev)
+
+    @property
+    def need(self):
+        if self._need_pending is not None:
+            host, ev = self._need_pending
+            ev.synchronize()             # a few hundred bytes issued when the batch arrived: long done by now
+            self._need, self._need_pending = host.numpy().copy(), None
+        return self._need
+
+    @need.setter
+    def need(self, value):
+        self._need, self._need_pending = value, None
 
     def my_chunks(self, r=None):
         r = self.rank if r is None else r
@@ -152,6 +211,136 @@ class ContextParallel:
             rows.append(torch.cat([full.narrow(1, r * self.Tc, self.Tc),
                                    full.narrow(1, (2 * self.cp - 1 - r) * self.Tc, self.Tc)], dim=1))
         return torch.stack(rows, dim=0)
+
+
+class _Transfer:
+    """One batch of point-to-point transfers in flight + what to do with the staging buffers once it has landed."""
+
+    def __init__(self, works, after):
+        self.works, self.after = works, after
+
+    def wait(self):
+        for w in self.works:
+            w.wait()                       # RCCL: the COMPUTE stream waits for the transfer; gloo: the host does
+        for fn in self.after:
+            fn()
+        self.works, self.after = [], []
+
+
+def _contig_chunk(t: torch.Tensor, start: int, n: int):
+    v = t.narrow(1, start, n)
+    return v if v.is_contiguous() else None
+
+
+def _start_forward(cp: "ContextParallel", locals_):
+    """locals_: list of [B, 2Tc, ...] tensors (K and V) -> (list of [B, T, ...] global tensors, _Transfer)."""
+    Tc, me, need = cp.Tc, cp.rank, cp.need
+    mine = cp.my_chunks()
+    fulls = [x.new_empty((x.shape[0], cp.T) + tuple(x.shape[2:])) for x in locals_]
+    ops, after = [], []
+    for x, full in zip(locals_, fulls):
+        for h, c in enumerate(mine):
+            full.narrow(1, c * Tc, Tc).copy_(x.narrow(1, h * Tc, Tc))
+        for p in range(cp.cp):
+            if p == me:
+                continue
+            peer = dist.get_global_rank(cp.group, p)
+            for h, c in enumerate(mine):                          # my chunks p needs
+                if need[p, c]:
+                    src = _contig_chunk(x, h * Tc, Tc)
+                    ops.append(dist.P2POp(dist.isend, src if src is not None else x.narrow(1, h * Tc, Tc).contiguous(),
+                                          peer, group=cp.group))
+            for c in cp.my_chunks(p):                             # p's chunks I need
+                if need[me, c]:
+                    dst = _contig_chunk(full, c * Tc, Tc)
+                    if dst is None:                               # B > 1: a chunk is strided in [B, T, ...]: stage it
+                        stage = x.new_empty((x.shape[0], Tc) + tuple(x.shape[2:]))
+                        after.append(lambda f=full, c=c, s=stage: f.narrow(1, c * Tc, Tc).copy_(s))
+                        dst = stage
+                    cp.halo_bytes += dst.numel() * dst.element_size()
+                    ops.append(dist.P2POp(dist.irecv, dst, peer, group=cp.group))
+    works = dist.batch_isend_irecv(ops) if ops else []
+    return fulls, _Transfer(works, after)
+
+
+def _start_backward(cp: "ContextParallel", g_fulls):
+    """Partial dK/dV of the remote chunks go back to their owners; returns (list of local grads [B, 2Tc, ...] holding
+    this rank's own contribution, _Transfer whose completion adds the peers' partial sums)."""
+    Tc, me, need = cp.Tc, cp.rank, cp.need
+    mine = cp.my_chunks()
+    g_locals = [torch.cat([g.narrow(1, c * Tc, Tc) for c in mine], dim=1).contiguous() for g in g_fulls]
+    ops, after = [], []
+    for g, gl in zip(g_fulls, g_locals):
+        for p in range(cp.cp):
+            if p == me:
+                continue
+            peer = dist.get_global_rank(cp.group, p)
+            for c in cp.my_chunks(p):                             # chunks of p this rank used: their grads go back
+                if need[me, c]:
+                    src = _contig_chunk(g, c * Tc, Tc)
+                    ops.append(dist.P2POp(dist.isend, src if src is not None else g.narrow(1, c * Tc, Tc).contiguous(),
+                                          peer, group=cp.group))
+            for h, c in enumerate(mine):                          # p used these chunks of mine
+                if need[p, c]:
+                    stage = gl.new_empty((gl.shape[0], Tc) + tuple(gl.shape[2:]))
+                    after.append(lambda gl=gl, h=h, s=stage: gl.narrow(1, h * Tc, Tc).add_(s))
+                    ops.append(dist.P2POp(dist.irecv, stage, peer, group=cp.group))
+    works = dist.batch_isend_irecv(ops) if ops else []
+    return g_locals, _Transfer(works, after)
+
+
+class _Link:
+    """Shared by the two autograd nodes of one layer's exchange."""
+
+    def __init__(self, cp):
+        self.cp, self.fwd, self.bwd, self.g_locals = cp, None, None, None
+
+
+class _HaloStart(torch.autograd.Function):
+    """forward: ISSUE the K/V halo exchange (returns the global buffers before the data has landed);
+    backward: FINISH the dK/dV return exchange issued by _HaloFinish.backward."""
+
+    @staticmethod
+    def forward(ctx, k_local, v_local, link: _Link):
+        fulls, link.fwd = _start_forward(link.cp, [k_local, v_local])
+        ctx.link = link
+        return fulls[0], fulls[1]
+
+    @staticmethod
+    def backward(ctx, _gk, _gv):
+        link = ctx.link
+        link.bwd.wait()
+        gk, gv = link.g_locals
+        link.bwd = link.g_locals = None
+        return gk, gv, None
+
+
+class _HaloFinish(torch.autograd.Function):
+    """forward: WAIT for the K/V exchange right in front of the attention kernel;
+    backward: ISSUE the return of the partial dK/dV (the query-path backward runs while they travel)."""
+
+    @staticmethod
+    def forward(ctx, k_full, v_full, link: _Link):
+        link.fwd.wait()
+        link.fwd = None
+        ctx.link = link
+        ctx.mark_dirty(k_full, v_full)
+        return k_full, v_full
+
+    @staticmethod
+    def backward(ctx, gk_full, gv_full):
+        link = ctx.link
+        link.g_locals, link.bwd = _start_backward(link.cp, [gk_full.contiguous(), gv_full.contiguous()])
+        return gk_full, gv_full, None
+
+
+def exchange_kv(cp: ContextParallel, k_local: torch.Tensor, v_local: torch.Tensor):
+    """Start the halo exchange of a layer's K/V.  Returns `finish`: call it AFTER the query-path work has been issued,
+    it returns the global (k_full, v_full) ready for `packed_attention_sharded`.  Needs `cp.set_documents` (the
+    all-gather fallback has nothing to overlap with: use `cp.gather_seq`)."""
+    link = _Link(cp)
+    k_full, v_full = _HaloStart.apply(k_local, v_local, link)
+    return lambda: _HaloFinish.apply(k_full, v_full, link)
 
 
 class _GatherSeq(torch.autograd.Function):
