@@ -287,7 +287,9 @@ def main():
     ap.add_argument("--unfused-ce", action="store_true")
     ap.add_argument("--ce-chunk", type=int, default=None, help="tokens per lm_head+CE chunk (default: TrainConfig's)")
     ap.add_argument("--compact-lm-head", action="store_true",
-                    help="opt-in: lm_head + CE only on labelled positions (exact; one host sync per step)")
+                    help="lm_head + CE on labelled positions with the EXACT count read back (one host sync per step)")
+    ap.add_argument("--all-rows-lm-head", action="store_true",
+                    help="A/B switch: ignore the loader's labelled-row bound and run lm_head + CE on all B*T positions")
     ap.add_argument("--no-gemm-tuning", action="store_true", help="library-default GEMM algorithm selection")
     args = ap.parse_args()
 
@@ -310,6 +312,8 @@ def main():
     wl = Workload(args.workload, device, rank, args.batch, args.seqlen)
     wl.job.training_enable_fused_ce = not args.unfused_ce
     wl.job.training_ce_compact_rows = args.compact_lm_head
+    if args.all_rows_lm_head and hasattr(wl, "tokens"):
+        wl.tokens.pop("labelled_rows_max", None)
     if args.ce_chunk:
         wl.job.training_ce_chunk_tokens = args.ce_chunk
     trainer = Trainer(wl.job, wl.model_config, device, dp_mesh=mesh)
@@ -357,7 +361,9 @@ def main():
                        "seq_len": wl.T, "parallelism": f"fsdp2-dp{world}" if (world > 1 or forced) else "single-gpu",
                        "params": trainer.num_params, "flop_per_token": fpt,
                        "fused_linear_ce": wl.job.training_enable_fused_ce,
-                       "lm_head_rows": "labelled only (opt-in)" if args.compact_lm_head else "all B*T positions",
+                       "lm_head_rows": ("labelled only (exact count, host sync)" if args.compact_lm_head else
+                                        f"labelled only: static bound {wl.tokens['labelled_rows_max']} from the loader, no host sync"
+                                        if hasattr(wl, "tokens") and "labelled_rows_max" in wl.tokens else "all B*T positions"),
                        "gemm_algorithms": "TunableOp replay (touchnet_amd/tuning)" if tuned else "library default"},
             "step_mfu": round(mfu, 4),
             "mfu_convention": "6*N_wo_emb + 12*L*H*Dh*T per token (touchnet/models/*/__init__.py), no causal/packing "

@@ -947,3 +947,51 @@ def test_device_packers_equal_host_packers_on_random_streams(seed):
         for k in keys + ("input_features",):
             assert torch.equal(a[k].cpu(), b[k]), k
         assert int(a["num_sentence"]) == b["num_sentence"]
+
+
+def test_fused_linear_ce_static_compact_rows_equals_full_and_fails_loudly():
+    """lm_head + CE on the labelled rows only, with the loader's static upper bound (no host sync): same loss, stats and
+    gradients as the all-rows path; a bound that is too small turns the loss into NaN instead of dropping labels."""
+    F = _f()
+    g = torch.Generator().manual_seed(3)
+    n, H, V = 1024, 256, 3000
+    h = torch.randn(2, n // 2, H, generator=g).bfloat16().to(DEV)
+    w = (torch.randn(V, H, generator=g) * 0.05).bfloat16().to(DEV)
+    labels = torch.full((2, n // 2), -100)
+    idx = torch.randperm(n, generator=g)[:137]
+    labels.view(-1)[idx] = torch.randint(0, V, (137,), generator=g)
+    labels = labels.to(DEV)
+    sl = torch.randint(1, 9, (2, n // 2), generator=g).to(DEV)
+
+    def run(compact):
+        hh, ww = h.clone().requires_grad_(), w.clone().requires_grad_()
+        loss, stats = F.fused_linear_cross_entropy(hh, ww, labels, sl, 7, -100, 256, compact=compact)
+        loss.backward()
+        return loss.detach(), stats, hh.grad, ww.grad
+    full = run(False)
+    for bound in (137, 256, 1024, 5000):
+        got = run(bound)
+        assert float(got[0]) == pytest.approx(float(full[0]), rel=1e-6), bound
+        torch.testing.assert_close(got[1], full[1], rtol=1e-6, atol=1e-7)
+        _close(got[2], full[2], 1e-6, 1e-2, f"dh, bound {bound}")
+        _close(got[3], full[3], 4e-3, 2e-2, f"dW, bound {bound}")     # (bf16 accumulation over a different chunking: 1 ulp)
+    exact = run(True)
+    assert float(exact[0]) == pytest.approx(float(full[0]), rel=1e-6)
+    poisoned = run(100)                                  # 137 labels do not fit 100 rows
+    assert torch.isnan(poisoned[0]) and torch.isnan(poisoned[1]).all()
+
+
+def test_rope_on_one_tensor_alone():
+    """The context-parallel attention rotates K before Q exists (K/V travel while the query path runs): a call with a
+    zero-head second operand == the joint call."""
+    F = _f()
+    g = torch.Generator().manual_seed(2)
+    B, T, D = 2, 96, 64
+    q = torch.randn(B, T, 4, D, generator=g).bfloat16().to(DEV)
+    k = torch.randn(B, T, 2, D, generator=g).bfloat16().to(DEV)
+    pos = torch.arange(T).repeat(B, 1).to(DEV)
+    cos, sin = F.rope_tables(pos, F.rope_inv_freq(D, 10000.0, None, device=DEV), torch.bfloat16)
+    qj, kj = F.apply_rope(q, k, cos, sin)
+    k1, e = F.apply_rope(k, k.new_empty(B, T, 0, D), cos, sin)
+    q1, _ = F.apply_rope(q, q.new_empty(B, T, 0, D), cos, sin)
+    assert torch.equal(k1, kj) and torch.equal(q1, qj) and e.numel() == 0

@@ -89,7 +89,7 @@ def qwen2_audio_plan(vocab: int, audio_token: int, batchsize: int, seqlen: int, 
     position_ids = np.zeros((B, T), dtype=np.int64)
     doc = np.zeros((B, T), dtype=np.int64)
     sentence_lens = np.ones((B, T), dtype=np.int64)
-    audio_pos, n_sent = [], 0
+    audio_pos, n_sent, n_lab = [], 0, 0
     for b in range(B):
         col, d = 0, 1
         while True:
@@ -112,8 +112,10 @@ def qwen2_audio_plan(vocab: int, audio_token: int, batchsize: int, seqlen: int, 
             col += tot
             d += 1
             n_sent += 1
+            n_lab += nresp + 1
     t = torch.from_numpy
     return {"input_ids": t(input_ids), "labels": t(labels), "position_ids": t(position_ids),
             "attention_mask": t(doc), "sentence_lens": t(sentence_lens), "num_sentence": n_sent,
             "audio_positions": t(np.concatenate(audio_pos)),
-            "audio_output_lengths": torch.full((n_sent,), audio_tokens, dtype=torch.int64)}, n_sent
+            "audio_output_lengths": torch.full((n_sent,), audio_tokens, dtype=torch.int64),
+            "labelled_rows_max": n_lab}, n_sent

@@ -193,18 +193,32 @@ class _FusedLinearCE(torch.autograd.Function):
         lab = labels.reshape(-1).to(torch.int64).contiguous()
         sl = sentence_lens.reshape(-1).to(torch.int64).contiguous()
         rows = None
-        if compact:
-            # OPT-IN: positions whose label is ignore_index contribute exactly 0 to the loss, to d(hidden) and to
-            # d(weight) — the CE kernels already never read their logits; with `compact` the lm_head GEMMs skip them
-            # too (ASR-SFT batches: >90 % of the positions are audio/prompt).  Same loss and gradients up to GEMM
-            # summation order.  Costs one host sync per step (the row count sizes the GEMM), hence not the default.
-            rows = torch.nonzero(lab != ignore_index).squeeze(1)
+        overflow = None
+        if compact is not False and compact is not None:
+            # Positions whose label is ignore_index contribute exactly 0 to the loss, to d(hidden) and to d(weight) —
+            # the CE kernels already never read their logits; here the lm_head GEMMs skip them too (ASR-SFT batches:
+            # > 90 % of the positions are audio / prompt).  Same loss and gradients up to GEMM summation order.
+            #   compact = int   upper bound of the labelled positions, known to the data loader (the packers emit
+            #                   `labelled_rows_max`): static shapes, NO host synchronisation — rows beyond the real count
+            #                   are given the label ignore_index; a bound that is too small poisons the loss with NaN
+            #                   (decided on the device) instead of silently dropping labels
+            #   compact = True  exact count read back from the device (one host sync per step)
             n_all = h2.shape[0]
-            h2, lab, sl = h2.index_select(0, rows), lab.index_select(0, rows), sl.index_select(0, rows)
+            labelled = lab != ignore_index
+            if compact is True:
+                rows = torch.nonzero(labelled).squeeze(1)
+            else:
+                n_max = min(int(compact), n_all)
+                rows = torch.nonzero_static(labelled, size=max(n_max, 1), fill_value=0).squeeze(1)
+                count = labelled.sum()
+                valid = torch.arange(rows.numel(), device=lab.device) < count
+                overflow = count > n_max
             if rows.numel() == 0:                              # nothing labelled: zero loss, zero gradients
                 rows = None
-                h2, lab, sl = hidden.reshape(-1, H), labels.reshape(-1).to(torch.int64).contiguous(), \
-                    sentence_lens.reshape(-1).to(torch.int64).contiguous()
+            else:
+                h2, lab, sl = h2.index_select(0, rows), lab.index_select(0, rows), sl.index_select(0, rows)
+                if compact is not True:
+                    lab = torch.where(valid, lab, torch.full_like(lab, ignore_index))
         n, V = h2.shape[0], weight.shape[0]
         ns = _num_sentence_dev(num_sentence, hidden.device)
         one = torch.ones(1, dtype=torch.float32, device=hidden.device)
@@ -227,7 +241,10 @@ class _FusedLinearCE(torch.autograd.Function):
         hit = torch.cat([b for _, b in parts]) if len(parts) > 1 else parts[0][1]
         out = L.ce_reduce(nll, hit, lab, sl, ns, int(ignore_index))
         if rows is not None:                                   # scatter d(hidden) back; ignored rows stay 0
-            dh = torch.zeros(n_all, H, dtype=dh.dtype, device=dh.device).index_copy_(0, rows, dh)
+            # (index_add: the filler rows of the static form repeat index 0 and carry exact zeros)
+            dh = torch.zeros(n_all, H, dtype=dh.dtype, device=dh.device).index_add_(0, rows, dh)
+        if overflow is not None:
+            out = torch.where(overflow, torch.full_like(out, float("nan")), out)
         ctx.save_for_backward(dh, dw)
         ctx.hshape, ctx.wdtype = hidden.shape, weight.dtype
         ctx.mark_non_differentiable(out)
@@ -243,7 +260,8 @@ class _FusedLinearCE(torch.autograd.Function):
 def fused_linear_cross_entropy(hidden, weight, labels, sentence_lens, num_sentence, ignore_index=-100,
                                chunk_tokens=4096, compact=False):
     """Returns ``(loss_per_sample [differentiable], stats)`` like packed_cross_entropy, from hidden states.
-    ``compact=True``: run lm_head only on the labelled positions (see _FusedLinearCE.forward)."""
+    ``compact``: run lm_head only on the labelled positions — an int upper bound from the data loader (no host sync)
+    or True (exact, one sync); see _FusedLinearCE.forward."""
     return _FusedLinearCE.apply(hidden, weight, labels, sentence_lens, num_sentence, ignore_index, chunk_tokens,
                                 compact)
 

@@ -202,7 +202,8 @@ class PackedCausalLM(nn.Module):
 
     def forward(self, input_ids=None, inputs_embeds=None, position_ids=None, attention_mask=None,
                 labels=None, sentence_lens=None, num_sentence=None, shift_labels=None,
-                ce_chunk_tokens: int = 4096, ce_compact: bool = False, context_parallel=None, **unused):
+                ce_chunk_tokens: int = 4096, ce_compact=False, labelled_rows_max=None, context_parallel=None,
+                **unused):
         """Without `labels`: returns `.logits` (the reference's default path, loss_fn runs in the trainer).
         With `labels` (+ `sentence_lens`, `num_sentence`): lm_head and the packed CE run fused INSIDE the
         model — the role liger's fused-linear-CE plays in the reference (`pred.loss`, train.py:443-445), but
@@ -210,6 +211,10 @@ class PackedCausalLM(nn.Module):
         with `.logits = None`.  Being inside forward keeps lm_head under FSDP2's unshard/reshard hooks."""
         h = self.model(input_ids=input_ids, inputs_embeds=inputs_embeds, position_ids=position_ids,
                        attention_mask=attention_mask, context_parallel=context_parallel)
+        if labelled_rows_max is not None and ce_compact is not True and context_parallel is None:
+            # the packers know how many positions carry a label: lm_head + CE run on those rows only, without a host
+            # sync (functional._FusedLinearCE); rounded up so that the GEMM shapes repeat from step to step
+            ce_compact = (int(labelled_rows_max) + 255) // 256 * 256
         if labels is None and shift_labels is not None:
             # The reference's liger branch (train.py:434-445 with training_enable_liger_kernel): the trainer pops
             # labels / sentence_lens / num_sentence and passes only `shift_labels`; `.loss` is then the MEAN over the

@@ -91,7 +91,8 @@ def _emit_text(buf: PackBuffer, sentences, bos, eos, pad):
         del starts
     t = lambda a: torch.from_numpy(a.reshape(B, T))
     return {"input_ids": t(input_ids), "inputs_embeds": None, "labels": t(labels), "position_ids": t(position_ids),
-            "attention_mask": t(attention_mask), "sentence_lens": t(sentence_lens), "num_sentence": len(buf)}
+            "attention_mask": t(attention_mask), "sentence_lens": t(sentence_lens), "num_sentence": len(buf),
+            "labelled_rows_max": int(sum(buf.lens))}          # every non-pad slot carries a label (host int: no sync)
 
 
 def batch_text(data, config, tokenizer):

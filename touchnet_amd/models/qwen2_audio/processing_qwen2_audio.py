@@ -74,7 +74,8 @@ def _emit(buf: PackBuffer, segs, mels, valid, pad_id: int, audio_token: int):
     return {"input_ids": t(input_ids), "labels": lab_t, "shift_labels": lab_t, "position_ids": t(position_ids),
             "attention_mask": t(doc), "sentence_lens": t(sentence_lens), "num_sentence": len(buf),
             "input_features": feats, "audio_positions": torch.from_numpy(audio_positions),
-            "audio_output_lengths": torch.tensor([audio_token_count(v) for v in valid], dtype=torch.int64)}
+            "audio_output_lengths": torch.tensor([audio_token_count(v) for v in valid], dtype=torch.int64),
+            "labelled_rows_max": int(sum(len(r) + 1 for _, r, _ in segs))}           # response + eos (host int: no sync)
 
 
 def batch_qwen2_audio_packed(data, config, processor):

@@ -52,7 +52,8 @@ def _emit_asr(buf: PackBuffer, feats, sentences, feat_dim, bos, eos, pad):
     lab_t = t(labels)
     return {"input_ids": t(input_ids), "input_features": input_features, "labels": lab_t,
             "position_ids": t(position_ids), "attention_mask": t(attention_mask),
-            "sentence_lens": t(sentence_lens), "num_sentence": len(buf), "shift_labels": lab_t}
+            "sentence_lens": t(sentence_lens), "num_sentence": len(buf), "shift_labels": lab_t,
+            "labelled_rows_max": int(sum(len(s) + 1 for s in sentences))}       # text slots only (host int: no sync)
 
 
 def batch_pairaudio_pairtext_packed(data, config, tokenizer):
