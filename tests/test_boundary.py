@@ -62,6 +62,20 @@ def test_registered_hooks_accept_the_reference_trainers_calls(name):
                 raise AssertionError(f"{name}.{hook} cannot be called as train.py:{site['line']} does: {e}") from None
 
 
+def test_integration_shim_builds_the_references_dataclass_from_our_specs():
+    """`TrainSpec(**fields of our spec)` into a dataclass with the REFERENCE's field list (positional
+    construction in its order works too)."""
+    import touchnet_amd.specs  # noqa: F401
+    from touchnet_amd.utils.train_spec import get_train_spec
+    RefSpec = dataclasses.make_dataclass("TrainSpec", [(n, object) for n in B["train_spec_fields"]])
+    for name in ("llama_mi355", "touch_audio_mi355", "qwen2_audio_mi355"):
+        ours = get_train_spec(name)
+        kw = {f.name: getattr(ours, f.name) for f in dataclasses.fields(ours)}
+        ref = RefSpec(**kw)
+        assert ref.name == name and ref.parallelize_fn is ours.parallelize_fn
+        assert RefSpec(*[kw[n] for n in B["train_spec_fields"]]) == ref
+
+
 def test_parallel_dims_surface_and_mesh_names():
     from touchnet_amd.utils.distributed import ParallelDims
     assert [f.name for f in dataclasses.fields(ParallelDims)] == B["parallel_dims"]["fields"]
