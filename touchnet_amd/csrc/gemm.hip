@@ -338,55 +338,18 @@ __device__ __forceinline__ void mainloop_ring5(const Ctx& c, Acc& acc) {
   }
 }
 
-template <bool HAS_CT, int LOOP>
-__global__ __launch_bounds__(NT, 2) void gemm_tn_kernel(const Params p) {
-  __shared__ __attribute__((aligned(1024))) char smem[LDS_BYTES];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 2, wc = wave & 3;   // 2 x 4 waves
+// Epilogue through LDS: the wave parks its 128 x (32 NJ) tile, 64 columns at a time, in its own XOR-swizzled LDS
+// region ([128 rows][64 cols] bf16, 128-byte rows, chunk ^= row & 7) and writes full 128-byte lines.
+template <bool HAS_CT, int NJ>
+__device__ __forceinline__ void epilogue(const Params& p, f32x16_t (&acc)[4][NJ], char* park_base, int wm0, int wn0_base,
+                                         int lane) {
   const int l31 = lane & 31, hi = lane >> 5;
-
-  int tm, tn;
-  tile_of_block(blockIdx.x, p.nbm, p.nbn, tm, tn);
-  const int m0 = tm * BM, n0 = tn * BN;
-
-  // ---- DMA source descriptors: one per operand, based at the tile's first row (offsets stay < 2^31) ----------
-  const long long a_left = (long long)(p.M - m0) * p.lda * 2, b_left = (long long)(p.N - n0) * p.ldb * 2;
-  Ctx c;
-  c.smem = smem;
-  c.ra = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (long long)m0 * p.lda), 0,
-                                           (int)min(a_left, 0x7fffffffLL), 0x00020000);
-  c.rb = __builtin_amdgcn_make_buffer_rsrc((void*)(p.B + (long long)n0 * p.ldb), 0,
-                                           (int)min(b_left, 0x7fffffffLL), 0x00020000);
-  c.lda2 = p.lda * 2;
-  c.ldb2 = p.ldb * 2;
-  c.wave = wave; c.wr = wr; c.wc = wc; c.lane = lane; c.l31 = l31; c.hi = hi;
-  c.K = p.K;
-
-  Acc acc;
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-#ifdef TN_GEMM_SKEW
-  // experiment: de-phase the workgroups of an XCD (they all start together and would burst their DMA in lockstep)
-  for (int i = ((blockIdx.x >> 3) & 31) * TN_GEMM_SKEW; i > 0; --i) __builtin_amdgcn_s_sleep(1);
-#endif
-  if constexpr (LOOP == 1)
-    mainloop_pair64(c, acc);
-  else
-    mainloop_ring5(c, acc);
-
-  // ---- epilogue: park the wave's 128 x 64 tile in LDS, write full lines -------------------------------------------
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the dead tail DMAs must not land on the parked tile
   __builtin_amdgcn_s_barrier();
-  char* park = smem + wave * 16384;                      // [128 rows][64 cols] bf16, 128-byte rows, chunk ^= row & 7
-  const int wm0 = m0 + wr * 128, wn0 = n0 + wc * 64;
+#pragma unroll
+  for (int half = 0; half < NJ / 2; ++half) {
+  char* park = park_base + half * 16384;
+  const int wn0 = wn0_base + half * 64;
   float bias_v[2][4][4];
   if (p.bias != nullptr) {
 #pragma unroll
@@ -410,7 +373,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_tn_kernel(const Params p) {
       for (int g = 0; g < 4; ++g) {
         float v[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] + (p.bias != nullptr ? bias_v[j][g][e] : 0.f);
+        for (int e = 0; e < 4; ++e) v[e] = acc[i][half * 2 + j][4 * g + e] + (p.bias != nullptr ? bias_v[j][g][e] : 0.f);
         const int chunk = (j * 4 + g) ^ (row & 7);
         *reinterpret_cast<uint2*>(park + row * 128 + chunk * 16 + hi * 8) =
             make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
@@ -466,6 +429,54 @@ __global__ __launch_bounds__(NT, 2) void gemm_tn_kernel(const Params p) {
         *reinterpret_cast<uint4*>(p.Ct + (long long)n * p.ldct + m) = make_uint4(w[0], w[1], w[2], w[3]);
     }
   }
+  }
+}
+
+template <bool HAS_CT, int LOOP>
+__global__ __launch_bounds__(NT, 2) void gemm_tn_kernel(const Params p) {
+  __shared__ __attribute__((aligned(1024))) char smem[LDS_BYTES];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;   // 2 x 4 waves
+  const int l31 = lane & 31, hi = lane >> 5;
+
+  int tm, tn;
+  tile_of_block(blockIdx.x, p.nbm, p.nbn, tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  // ---- DMA source descriptors: one per operand, based at the tile's first row (offsets stay < 2^31) ----------
+  const long long a_left = (long long)(p.M - m0) * p.lda * 2, b_left = (long long)(p.N - n0) * p.ldb * 2;
+  Ctx c;
+  c.smem = smem;
+  c.ra = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (long long)m0 * p.lda), 0,
+                                           (int)min(a_left, 0x7fffffffLL), 0x00020000);
+  c.rb = __builtin_amdgcn_make_buffer_rsrc((void*)(p.B + (long long)n0 * p.ldb), 0,
+                                           (int)min(b_left, 0x7fffffffLL), 0x00020000);
+  c.lda2 = p.lda * 2;
+  c.ldb2 = p.ldb * 2;
+  c.wave = wave; c.wr = wr; c.wc = wc; c.lane = lane; c.l31 = l31; c.hi = hi;
+  c.K = p.K;
+
+  Acc acc;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+#ifdef TN_GEMM_SKEW
+  // experiment: de-phase the workgroups of an XCD (they all start together and would burst their DMA in lockstep)
+  for (int i = ((blockIdx.x >> 3) & 31) * TN_GEMM_SKEW; i > 0; --i) __builtin_amdgcn_s_sleep(1);
+#endif
+  if constexpr (LOOP == 1)
+    mainloop_pair64(c, acc);
+  else
+    mainloop_ring5(c, acc);
+
+  epilogue<HAS_CT, 2>(p, acc, smem + wave * 16384, m0 + wr * 128, n0 + wc * 64, lane);
 }
 
 }  // namespace gemm
