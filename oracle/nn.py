@@ -182,3 +182,34 @@ def qwen2_audio_tower(sd, acfg, mel, prefix="audio_tower."):
         h = whisper_layer(sd, f"{prefix}layers.{i}.", h, acfg["encoder_attention_heads"], None)
     h = F.avg_pool1d(h.permute(0, 2, 1), 2, 2).permute(0, 2, 1)
     return layer_norm(h, g("layer_norm.weight"), g("layer_norm.bias"))
+
+
+# ------------------------------------------------------------------ Kimi-Audio decoder (config E)
+def kimi_audio_forward(sd, cfg, audio_input_ids, text_input_ids, doc_ids, position_ids, with_mimo=True):
+    """MoonshotKimiaForCausalLM.forward + MoonshotKimiaModel.forward restated
+    (touchnet/models/kimi_audio/modeling_kimi_audio.py:1026-1068 and :486-537; the layers are Qwen2 decoder layers,
+    `decoder_layer` above): inputs = embed(audio ids) + embed(text ids); after layer `kimia_mimo_transformer_from_layer_index`
+    the hidden state is CLONED into the mimo branch (`:506-507`), which runs `kimia_mimo_layers` more layers and its own
+    final norm; returns (text_logits, audio_logits).  PARITY UNPINNED against the reference's own module: it does not
+    import under the installed transformers 5.x, so this follows the source by hand."""
+    emb_w = sd["model.embed_tokens.weight"]
+    h = F.embedding(audio_input_ids, emb_w)
+    if text_input_ids is not None:
+        h = h + F.embedding(text_input_ids, emb_w)
+    inv = rope_inv_freq(cfg["head_dim"], cfg["rope_theta"], cfg.get("rope_scaling")).to(h.device)
+    cos, sin = rope_cos_sin(position_ids, inv, h.dtype)
+    allow = doc_causal_allow(doc_ids) if doc_ids is not None else None
+    mimo = None
+    for i in range(cfg["num_hidden_layers"]):
+        h = decoder_layer(sd, f"model.layers.{i}.", cfg, h, cos, sin, allow)
+        if i == cfg["kimia_mimo_transformer_from_layer_index"]:
+            mimo = h.clone()
+    h = rms_norm(h, sd["model.norm.weight"], cfg["rms_norm_eps"])
+    text_logits = F.linear(h, sd["lm_head.weight"])
+    audio_logits = None
+    if with_mimo:
+        for i in range(cfg["kimia_mimo_layers"]):
+            mimo = decoder_layer(sd, f"model.mimo_layers.{i}.", cfg, mimo, cos, sin, allow)
+        mimo = rms_norm(mimo, sd["model.mimo_norm.weight"], cfg["rms_norm_eps"])
+        audio_logits = F.linear(mimo, sd["mimo_output.weight"])
+    return text_logits, audio_logits

@@ -406,3 +406,99 @@ def test_halo_return_travels_under_the_query_path_backward():
     for r in range(2):
         assert results[r][0] == "ok", results[r][1]
         assert results[r][1] == ["issue_return", "q_proj_backward", "finish_return", "k_proj_backward"], results[r][1]
+
+
+# ------------------------------------------------------------------------------------------------ tensor parallel
+KIMI_TINY = dict(vocab_size=64, hidden_size=64, intermediate_size=128, num_hidden_layers=3, num_attention_heads=4,
+                 num_key_value_heads=2, head_dim=16, rms_norm_eps=1e-6, rope_theta=1e6, kimia_mimo_layers=1,
+                 kimia_mimo_transformer_from_layer_index=1)
+
+
+def _tp_batch():
+    g = torch.Generator().manual_seed(4)
+    B, T = 2, 48
+    a, t = torch.randint(0, 64, (B, T), generator=g), torch.randint(0, 64, (B, T), generator=g)
+    doc = torch.cat([torch.ones(B, 20), 2 * torch.ones(B, 20), torch.zeros(B, 8)], 1).long()
+    pos = torch.cat([torch.arange(20), torch.arange(20), torch.zeros(8, dtype=torch.long)]).repeat(B, 1)
+    labels = torch.where(doc > 0, torch.randint(0, 64, (B, T), generator=g), torch.full((B, T), -100))
+    sl = torch.where(doc > 0, torch.full((B, T), 20), torch.ones(B, T, dtype=torch.long))
+    return dict(text_input_ids=t, audio_input_ids=a, attention_mask=doc, position_ids=pos), labels, sl
+
+
+def _tp_model():
+    from touchnet_amd.models.kimi_audio import KimiAudioConfig, KimiAudioPackedForCausalLM
+    torch.manual_seed(21)
+    m = KimiAudioPackedForCausalLM(KimiAudioConfig(**KIMI_TINY))
+    m.post_init()
+    for n, p in m.named_parameters():
+        if n.endswith("bias"):
+            torch.nn.init.normal_(p, std=0.05)
+    return m
+
+
+def _tp_worker(rank, world, port, ref_logits, ref_grads, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    try:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import oracle.ops as oops
+        from torch.distributed.device_mesh import init_device_mesh
+        from touchnet_amd.loss.cross_entropy import cross_entropy_loss
+        from touchnet_amd.models.backend import use_ops
+        from touchnet_amd.models.parallelize import parallelize_packed
+        from touchnet_amd.utils.distributed import ParallelDims
+        mesh = init_device_mesh("cpu", (world,), mesh_dim_names=("tp",))
+        model = _tp_model()                                           # the SAME full weights on every rank ...
+        job = types.SimpleNamespace(training_activation_checkpoint_mode="none", training_compile=False,
+                                    training_enable_cpu_offload=False)
+        model = parallelize_packed(model, mesh, ParallelDims(1, 1, 1, world, 1, world, False), job)   # ... sharded here
+        inputs, labels, sl = _tp_batch()
+        with use_ops(oops):
+            out = model(**inputs)
+            loss, _ = cross_entropy_loss(out.logits, labels, sl, 4)
+            loss.backward()
+        err = float((out.logits - ref_logits).abs().max())
+        worst = 0.0
+        sharded = model._tn_tp["sharded_names"]
+        for n, p in model.named_parameters():
+            if p.grad is None:                                        # mimo branch: not executed in training
+                assert "mimo" in n, n
+                continue
+            ref = ref_grads[n]
+            if n in sharded:
+                dim = 1 if ("o_proj" in n or "down_proj" in n) else 0
+                ref = ref.chunk(world, dim=dim)[rank]
+            assert p.grad.shape == ref.shape, (n, p.grad.shape, ref.shape)
+            worst = max(worst, float((p.grad - ref).abs().max()))
+        ret[rank] = ("ok", err, worst, len(sharded))
+    except Exception as e:
+        import traceback
+        ret[rank] = ("fail", traceback.format_exc(), repr(e))
+    finally:
+        if dist.is_initialized():
+            dist.barrier()
+            dist.destroy_process_group()
+
+
+def test_tensor_parallel_two_ranks_equals_single_process():
+    """Config E's TP = 2 plan on the Kimi-Audio decoder (heads and MLP columns split over 2 ranks, one all-reduce per
+    attention / MLP output, mirrored in backward) through `parallelize_fn(model, world_mesh, parallel_dims, job)`:
+    logits identical to the unsharded model, gradients of tp-sharded parameters == the matching slices of the
+    unsharded gradients, replicated parameters' gradients equal."""
+    import oracle.ops as oops
+    from touchnet_amd.loss.cross_entropy import cross_entropy_loss
+    from touchnet_amd.models.backend import use_ops
+    ref = _tp_model()
+    inputs, labels, sl = _tp_batch()
+    with use_ops(oops):
+        out = ref(**inputs)
+        loss, _ = cross_entropy_loss(out.logits, labels, sl, 4)
+        loss.backward()
+    ref_grads = {n: p.grad.clone() for n, p in ref.named_parameters() if p.grad is not None}
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_tp_worker, args=(2, _free_port(), out.logits.detach(), ref_grads, ret), nprocs=2, join=True)
+        results = dict(ret)
+    for r in range(2):
+        assert results[r][0] == "ok", results[r][1]
+        assert results[r][1] < 2e-5 and results[r][2] < 2e-5, results[r]
+        assert results[r][3] == 4 * 10                               # 3 + 1 mimo blocks x (7 weights + 3 biases)

@@ -235,3 +235,39 @@ def test_liger_branch_shift_labels_returns_token_mean_loss():
     assert float(out.loss) == pytest.approx(float(want), rel=1e-5)
     out.loss.backward()
     assert m.lm_head.weight.grad is not None and torch.isfinite(m.lm_head.weight.grad).all()
+
+
+def test_kimi_audio_decoder_wiring_equals_oracle_restatement():
+    """Config E groundwork: the Kimi-Audio decoder (audio + text embedding sum, Qwen2 stack with q/k/v bias, mimo branch
+    tapped after layer `kimia_mimo_transformer_from_layer_index`, two heads) on the oracle op set == the restatement of
+    MoonshotKimiaModel / MoonshotKimiaForCausalLM (oracle/nn.py::kimi_audio_forward, by hand from
+    modeling_kimi_audio.py:486-537, 1026-1068 — the reference module itself cannot be imported here), logits of both
+    heads and the flop / parameter formulas of kimi_audio/__init__.py:63-93."""
+    from oracle import nn as onn
+    from touchnet_amd.models.kimi_audio import (KimiAudioConfig, KimiAudioPackedForCausalLM, get_num_flop_per_token,
+                                                get_num_params)
+    kw = dict(vocab_size=64, hidden_size=64, intermediate_size=128, num_hidden_layers=4, num_attention_heads=4,
+              num_key_value_heads=2, head_dim=16, rms_norm_eps=1e-6, rope_theta=1e6, kimia_mimo_layers=2,
+              kimia_mimo_transformer_from_layer_index=1)
+    cfg = KimiAudioConfig(**kw)
+    torch.manual_seed(0)
+    m = KimiAudioPackedForCausalLM(cfg)
+    m.post_init()
+    for n, p in m.named_parameters():
+        if n.endswith("bias"):
+            torch.nn.init.normal_(p, std=0.05)
+    B, T = 2, 48
+    a, t = torch.randint(0, 64, (B, T)), torch.randint(0, 64, (B, T))
+    doc = torch.cat([torch.ones(B, 20), 2 * torch.ones(B, 20), torch.zeros(B, 8)], 1).long()
+    pos = torch.cat([torch.arange(20), torch.arange(20), torch.zeros(8, dtype=torch.long)]).repeat(B, 1)
+    with use_ops(oops), torch.no_grad():
+        out = m(text_input_ids=t, audio_input_ids=a, attention_mask=doc, position_ids=pos, compute_audio_logits=True)
+        only_text = m(text_input_ids=t, audio_input_ids=a, attention_mask=doc, position_ids=pos)
+    tl, al = onn.kimi_audio_forward(dict(m.state_dict()), kw, a, t, doc, pos)
+    v = doc > 0
+    assert float((out.logits - tl)[v].abs().max()) < 2e-5 and float((out.audio_logits - al)[v].abs().max()) < 2e-5
+    assert only_text.audio_logits is None and torch.equal(only_text.logits, out.logits)
+    n_wo = get_num_params(m, exclude_embedding=True)
+    assert get_num_params(m) - n_wo == 64 * 64
+    assert get_num_flop_per_token(n_wo, cfg, 48) == 6 * n_wo + 12 * (4 + 2) * 4 * 16 * 48
+    assert any("q_proj.bias" in n for n, _ in m.named_parameters())          # Qwen2DecoderLayer: biased q/k/v

@@ -28,6 +28,8 @@ def block_groups(model: nn.Module):
     groups = []
     lm = getattr(model, "language_model", model)
     groups.append(list(lm.model.layers))
+    if hasattr(lm.model, "mimo_layers"):                   # Kimi-Audio's second stack (parallelize_kimi_audio.py)
+        groups.append(list(lm.model.mimo_layers))
     if hasattr(model, "audio_tower"):
         groups.append(list(model.audio_tower.layers))
     return groups

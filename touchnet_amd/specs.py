@@ -4,11 +4,12 @@ Model families are selected by `training_model_name`, like in the reference:
     llama_mi355         <- "llama"        (packed text pre-training; LlamaForCausalLM / Qwen2ForCausalLM shapes)
     touch_audio_mi355   <- "touch_audio"  (LlamaForASR: projector + packed ASR pairs)
     qwen2_audio_mi355   <- "qwen2_audio"  (Qwen2-Audio-7B, packed variant)
+    kimi_audio_mi355    <- "kimi_audio"   (Kimi-Audio-7B decoder: Qwen2 stack + mimo branch, text-logit CE; config E groundwork)
 INTEGRATION.md shows the three-line shim that puts these into TouchNet's own registry.
 """
 from touchnet_amd.data.dataloader import build_dataloader
 from touchnet_amd.loss.cross_entropy import cross_entropy_loss
-from touchnet_amd.models import llama, qwen2_audio, touch_audio
+from touchnet_amd.models import kimi_audio, llama, qwen2_audio, touch_audio
 from touchnet_amd.models.parallelize import parallelize_packed
 from touchnet_amd.utils.metrics import MI355X_BF16_DENSE_PEAK, accuracy
 from touchnet_amd.utils.optimizer import FusedAdamW, LRScheduler
@@ -16,9 +17,11 @@ from touchnet_amd.utils.train_spec import TrainSpec, _train_specs, get_train_spe
 
 
 def _build_optimizers(model_parts, job):
+    from touchnet_amd.models.tensor_parallel import tp_param_ids
     params = [p for m in model_parts for p in m.parameters()]
+    tp_group, tp_ids = tp_param_ids(model_parts)
     return FusedAdamW(params, lr=job.lr_scheduler_lr, weight_decay=job.optimizer_weight_decay,
-                      max_norm=job.training_max_norm)
+                      max_norm=job.training_max_norm, tp_group=tp_group, tp_param_ids=tp_ids)
 
 
 def _build_lr(optimizers, job):
@@ -64,6 +67,7 @@ def register_all():
         _spec("touch_audio_mi355", touch_audio, touch_audio.TouchAudioForCausalLM, touch_audio.TouchAudioConfig),
         _spec("qwen2_audio_mi355", qwen2_audio, qwen2_audio.Qwen2AudioPackedForConditionalGeneration,
               qwen2_audio.Qwen2AudioConfig),
+        _spec("kimi_audio_mi355", kimi_audio, kimi_audio.KimiAudioPackedForCausalLM, kimi_audio.KimiAudioConfig),
     ):
         if spec.name not in _train_specs:
             register_train_spec(spec)

@@ -46,8 +46,12 @@ def _shard_groups(params) -> List[Any]:
 
 class FusedAdamW:
     def __init__(self, params: Iterable[torch.nn.Parameter], lr=8e-4, betas=(0.9, 0.95), eps=1e-8,
-                 weight_decay=0.1, max_norm: float = 1.0, process_group=None):
+                 weight_decay=0.1, max_norm: float = 1.0, process_group=None, tp_group=None, tp_param_ids=()):
+        """`tp_group` / `tp_param_ids` (models.tensor_parallel.tp_param_ids): parameters sharded over the tensor-parallel
+        group — their squared gradient norm is summed over it, the replicated parameters' is not."""
         self.params = [p for p in params if p.requires_grad]
+        self.tp_group = tp_group
+        self._tp_index = {i for i, p in enumerate(self.params) if id(p) in set(tp_param_ids)}
         self.lr, self.betas, self.eps, self.weight_decay, self.max_norm = lr, betas, eps, weight_decay, max_norm
         # explicit group (bin/train.py: the flattened dp x cp mesh) or the groups read off the DTensor placements
         self.groups = [process_group] if process_group is not None else _shard_groups(self.params)
@@ -109,7 +113,16 @@ class FusedAdamW:
             g = _local(p.grad).contiguous()
             if g.numel():
                 by_dtype.setdefault(g.dtype, []).append((i, g))
-        keep = self._sumsq(by_dtype)
+        if self.tp_group is not None and self._tp_index:
+            # sum over the tp ranks for the tp-sharded parameters only, then add the replicated ones' (counted once)
+            pick = lambda inside: {dt: [it for it in items if (it[0] in self._tp_index) == inside]
+                                   for dt, items in by_dtype.items()}
+            drop_empty = lambda d: {dt: v for dt, v in d.items() if v}
+            keep = self._sumsq(drop_empty(pick(True)))
+            torch.distributed.all_reduce(self.norm_sq, group=self.tp_group)
+            keep += self._sumsq(drop_empty(pick(False)))
+        else:
+            keep = self._sumsq(by_dtype)
         for grp in self.groups:
             torch.distributed.all_reduce(self.norm_sq, group=grp)
         _C.check(lib.tn_adamw_prepare(p_(self.norm_sq), p_(self.step_state), b1, b2, float(self.max_norm), st()),
