@@ -350,6 +350,7 @@ def main():
     fpt = trainer.spec.get_num_flop_per_token_fn(trainer.num_params_wo_emb, wl.model_config, wl.T)
     mfu = fpt * (tps / world) / MFMA_PEAK
     nonpad = int((wl.tokens["attention_mask"] > 0).sum()) if hasattr(wl, "tokens") else None
+    lrm = None if args.all_rows_lm_head else wl.make_batch().get("labelled_rows_max")     # what the packer told the model
     loss = float(stats["loss_per_sample"])
     if rank == 0:
         line = {
@@ -362,8 +363,8 @@ def main():
                        "params": trainer.num_params, "flop_per_token": fpt,
                        "fused_linear_ce": wl.job.training_enable_fused_ce,
                        "lm_head_rows": ("labelled only (exact count, host sync)" if args.compact_lm_head else
-                                        f"labelled only: static bound {wl.tokens['labelled_rows_max']} from the loader, no host sync"
-                                        if hasattr(wl, "tokens") and "labelled_rows_max" in wl.tokens else "all B*T positions"),
+                                        f"labelled only: static bound {lrm} from the packer, no host sync"
+                                        if (lrm is not None and wl.job.training_enable_fused_ce) else "all B*T positions"),
                        "gemm_algorithms": "TunableOp replay (touchnet_amd/tuning)" if tuned else "library default"},
             "step_mfu": round(mfu, 4),
             "mfu_convention": "6*N_wo_emb + 12*L*H*Dh*T per token (touchnet/models/*/__init__.py), no causal/packing "
@@ -397,9 +398,13 @@ def main():
                     frames = wl.wav.shape[0] * 1500
                     executed += 6.0 * tower_params * (frames - wl.B * wl.T)          # tower runs on frames, not tokens
                     executed += 3.5 * 4.0 * 64 * ac.encoder_attention_heads * wl.wav.shape[0] * (1500 * 1501 // 2) * ac.encoder_layers
+                if lrm is not None and wl.job.training_enable_fused_ce and not c.tie_word_embeddings:
+                    rows = min(wl.B * wl.T, (int(lrm) + 255) // 256 * 256)           # lm_head + CE run on these rows only
+                    executed -= 6.0 * c.vocab_size * c.hidden_size * (wl.B * wl.T - rows)
                 line["step_mfu_executed_flops"] = round(executed / (step_ms * 1e-3) / MFMA_PEAK, 4)
                 line["executed_flops_note"] = ("GEMM terms of the formula (6*N_wo_emb per token; tower on its 1500 frames "
-                                               "per clip) + attention on the allowed (query, key) pairs only, fwd + 2.5x bwd")
+                                               "per clip; an untied lm_head only on the rows it runs on) + attention on "
+                                               "the allowed (query, key) pairs only, fwd + 2.5x bwd")
             except Exception as e:  # never lose the headline number to a diagnostics failure
                 line["kernels_error"] = repr(e)
         tfile = os.path.join(ROOT, "profiles", f"r02_step_hbm_traffic_{wl.name}.json")

@@ -110,11 +110,6 @@ int tn_attn_bwd_seg(const void* q, const void* k, const void* v, const void* o, 
                     int B, int T, int Nh, int Nkv, int D, float scale, int nseg, const int* host_segs,
                     int rows_per_batch, void* stream);
 
-/* Timing experiments only (scripts/attn_ablate.py): the D=128 forward with one piece removed
- * (1 staging, 2 softmax VALU, 3 P.V MFMAs, 4 QK^T MFMAs, 5 barrier).  Output is garbage for ablation != 0. */
-int tn_attn_fwd_ablate(const void* q, const void* k, const void* v, void* o, float* lse2, const int* doc,
-                       const int* meta, int B, int T, int Nh, int Nkv, float scale, int ablation, void* stream);
-
 /* ---- audio frontend on device — touchnet/data/functions.py:117-134 (kaldi fbank),
  *      :159-190 (whisper log-mel), :258-286 (stack / stride / normalise).
  * fbank:  wav fp32 [n_samples] in [-1,1) -> feat fp32 [tn_fbank_frames(n_samples), n_mels]

@@ -41,7 +41,6 @@ PROTOTYPES = {
     "tn_attn_fwd_seg": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _i, _vp],
     "tn_attn_bwd_seg": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp,
                         _i, _vp],
-    "tn_attn_fwd_ablate": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp],
     "tn_fbank_frames": [_i],
     "tn_kaldi_fbank": [_vp, _vp, _i, _i, _vp],
     "tn_log_mel": [_vp, _vp, _vp, _vp, _i, _i, _vp],
@@ -69,6 +68,11 @@ PROTOTYPES = {
 _RESTYPE = {"tn_version": C.c_char_p, "tn_sumsq_multi_chunk": C.c_longlong, "tn_adamw_multi_chunk": C.c_longlong,
             "tn_colsum_workspace_floats": C.c_longlong}
 
+# kernel-development entry points: exported by the library, deliberately NOT part of the C ABI (include/touchnet_amd.h)
+DEV_PROTOTYPES = {
+    "tn_attn_fwd_ablate": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp],   # scripts/attn_ablate.py
+}
+
 _lib = None
 
 
@@ -85,7 +89,7 @@ def lib() -> C.CDLL:
                 f"{LIB_PATH} not found: build it with `python -m touchnet_amd.build` "
                 "(touchnet_amd has no fallback path; the HIP extension is mandatory)")
         handle = C.CDLL(LIB_PATH)
-        for name, argtypes in PROTOTYPES.items():
+        for name, argtypes in {**PROTOTYPES, **DEV_PROTOTYPES}.items():
             fn = getattr(handle, name)      # AttributeError if the ABI and this stub ever drift
             fn.argtypes = argtypes
             fn.restype = _RESTYPE.get(name, C.c_int)

@@ -380,6 +380,7 @@ int tn_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse
 }
 
 // Timing experiments only (D = 128): the forward with one piece removed, see ABL above.  Output is garbage.
+// Development entry point: exported, but NOT declared in include/touchnet_amd.h (not part of the C ABI).
 int tn_attn_fwd_ablate(const void* q, const void* k, const void* v, void* o, float* lse2, const int* doc,
                        const int* meta, int B, int T, int Nh, int Nkv, float scale, int ablation, void* stream) {
   const int nt = (T + kTile - 1) / kTile, n = B * nt;
