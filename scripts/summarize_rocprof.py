@@ -25,7 +25,7 @@ def main(path, out):
     rows = list(csv.DictReader(open(path)))
     for r in rows:
         r["s"], r["e"] = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
-    adam = sorted((r for r in rows if "adamw_kernel" in r["Kernel_Name"]), key=lambda r: r["s"])
+    adam = sorted((r for r in rows if "adamw_kernel" in r["Kernel_Name"] or "adamw_multi_kernel" in r["Kernel_Name"]), key=lambda r: r["s"])
     # step boundaries = gaps > 50 ms between adamw launches
     ends, prev = [], None
     for r in adam:
