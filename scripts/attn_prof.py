@@ -36,6 +36,10 @@ def run(B, T, Nh, Nkv, D, doc, iters=3):
     torch.cuda.synchronize()
 
 
-run(2, 8192, 32, 32, 128, docs(2, 8192, 790))
-run(2, 8192, 32, 32, 128, torch.ones(2, 8192, dtype=torch.int64))
-run(20, 1500, 20, 20, 64, torch.ones(20, 1500, dtype=torch.int64))
+which = sys.argv[1] if len(sys.argv) > 1 else "all"      # docs | causal | tower | all
+if which in ("docs", "all"):
+    run(2, 8192, 32, 32, 128, docs(2, 8192, 790))
+if which in ("causal", "all"):
+    run(2, 8192, 32, 32, 128, torch.ones(2, 8192, dtype=torch.int64))
+if which in ("tower", "all"):
+    run(20, 1500, 20, 20, 64, torch.ones(20, 1500, dtype=torch.int64))

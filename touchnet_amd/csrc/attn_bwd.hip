@@ -19,6 +19,19 @@
 // flex_attention backward has the same two-loop structure (inductor-generated Triton template).
 #include "attn_common.h"
 
+// Timing experiments only (scripts/build_variant.sh <name> -DTN_BWD_ABL=n; results are wrong for n != 0):
+//   1 no in-loop global loads / LDS stores   2 = 1 and no barriers   3 no MFMA / softmax work (staging skeleton only)
+#ifndef TN_BWD_ABL
+#define TN_BWD_ABL 0
+#endif
+// dK/dV stream: query rows per stage (32 or 64) and ring depth
+#ifndef TN_KV_BQ
+#define TN_KV_BQ 64
+#endif
+#ifndef TN_KV_NST
+#define TN_KV_NST 2
+#endif
+
 namespace tn {
 
 // ------------------------------------------------------------------------------------------------
@@ -50,7 +63,32 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
 
 // ------------------------------------------------------------------------------------------------
 // dK / dV.   MODE 0: dV only   1: dK only   2: both
+//
+// The (query head of the GQA group, 32-row query stage) pairs a workgroup meets form ONE stream of stages; each stage
+// = {Q rows, dO rows, lse, delta, doc ids} travels global -> LDS by LDS-DMA (buffer_load ... lds, no staging
+// registers, no LDS store instructions) into a ring of NST slots, NST - 1 stages ahead of the one being computed, with
+// counted vmcnt waits and ONE raw barrier per stage.  Why: with register staging the prefetch distance was one tile
+// and the per-tile {wait for HBM/L2, store, 2 barriers} skeleton alone took 134 of the dV kernel's 281 us on the
+// headline workload (scripts/attn_ktimes.sh, -DTN_BWD_ABL variants of the previous kernel: no loads/stores 224 us, no
+// barriers either 206 us, no MFMA/softmax 134 us).  The per-tile document-id statistics come from an LDS window
+// filled once per workgroup instead of dependent scalar loads per tile.
 // ------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+struct QStage {      // one stage of the stream; every field is wave-uniform (SGPRs)
+  int valid;
+  int qsb;           // global position of the stage's first query row
+  int lrow;          // its row in the local Q / dO / LSE / delta buffers
+  int left;          // valid rows (1..32)
+  int h;             // query head
+  int mn, mx, mp;    // document-id statistics of the 64-position tile the stage lies in
+};
+
 template <int D, int MODE>
 __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(
     const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
@@ -58,22 +96,23 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(
     bf16_t* __restrict__ dK, bf16_t* __restrict__ dV, const int* __restrict__ doc, AttnMeta meta, QView qv, int T,
     int Nh, int Nkv, float scale, float scale_log2) {
   constexpr bool DO_DV = MODE != 1, DO_DK = MODE != 0;
-  constexpr int BNK = 128, BQ = 64;
-  constexpr int KSTEPS = D / 16, DBLK = D / 32, LD = D + 8, TS = TLds<BQ>::STRIDE;
-  // LDS images of the current 64-row query tile:
-  //   Qs  row-major  (always: A operand of S = Q K^T)      dOs row-major  (dK: A operand of dP = dO V^T)
-  //   Qt  transposed (dK: A operand of dK^T += Q^T dS)     dOt transposed (dV: A operand of dV^T += dO^T P)
-  constexpr int N_RM = DO_DK ? 2 : 1, N_TR = (DO_DK ? 1 : 0) + (DO_DV ? 1 : 0);
-  __shared__ __attribute__((aligned(16))) bf16_t smem[N_RM * BQ * LD + N_TR * D * TS + 6 * BQ];
-  bf16_t* Qs = smem;
-  bf16_t* dOs = Qs + BQ * LD;                       // valid only when DO_DK
-  bf16_t* Qt = smem + N_RM * BQ * LD;               // valid only when DO_DK
-  bf16_t* dOt = Qt + (DO_DK ? D * TS : 0);          // valid only when DO_DV
-  float* lse_s = reinterpret_cast<float*>(smem + N_RM * BQ * LD + N_TR * D * TS);
-  float* delta_s = lse_s + BQ;
-  int* docq = reinterpret_cast<int*>(delta_s + BQ);
+  constexpr int BNK = 128, BQ = TN_KV_BQ, NST = TN_KV_NST, SPT = kTile / BQ;   // SPT stages per 64-position q tile
+  constexpr int KSTEPS = D / 16, DBLK = D / 32;
+  using Tile = PTile<BQ, D>;
+  constexpr int IMGB = Tile::SIZE * 2;          // bytes of one panel image
+  constexpr int NPC = Tile::NP * (BQ / 16);     // 1-KiB DMA pieces per image: 16 rows of one panel each
+  constexpr int PPW = NPC / 4;                  // pieces per wave and image
+  constexpr int IPS = 2 * PPW + 1;              // DMA instructions per wave and stage (Q, dO pieces + one aux row)
+  constexpr int STAGEB = 2 * IMGB + 4 * 256;    // {Q image | dO image | lse[64] | delta[64] | doc[64] | spare[64]}
+  constexpr int WIN = 256;                      // q tiles after the kv block whose statistics are kept in LDS
+  // ONE LDS variable on purpose: with two, hipcc's module-LDS lowering attaches alias scopes to every access and the
+  // waitcnt insertion then puts `s_waitcnt vmcnt(0)` in front of the first LDS read that may alias a pending LDS-DMA
+  // (= every read of the ring), which serialises the ring (see attn_common.h, i32x4_t).
+  __shared__ __attribute__((aligned(1024))) char smem[NST * STAGEB + WIN * 16];
+  i32x4_t* qstat = reinterpret_cast<i32x4_t*>(smem + NST * STAGEB);
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, hi = lane >> 5;
   const int kt = blockIdx.y, hk = blockIdx.x, b = blockIdx.z;   // (see head_of_slot: head in x, heavy tiles first)
   const int G = Nh / Nkv;
@@ -97,48 +136,122 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(
     }
   }
   const int dkdoc = kvalid ? doc[(size_t)b * T + kvrow] : 0;
-  int wminpos, wmax;
-  wave_id_range(dkdoc, wminpos, wmax);
-  const bool w_uniform = (wminpos == wmax) && !__any(dkdoc == 0);   // all 32 kv rows in one document
 
   const int* m_min = meta.tmin + (size_t)b * meta.nt;
   const int* m_max = meta.tmax + (size_t)b * meta.nt;
   const int* m_minpos = meta.tminpos + (size_t)b * meta.nt;
+  const int qt_lo = k0 / kTile;                               // first 64-position query tile (q >= kv), global index
+  for (int i = tid; i < WIN; i += 256) {
+    const int t = qt_lo + i;
+    if (t < meta.nt) qstat[i] = i32x4_t{m_minpos[t], m_max[t], m_min[t], 0};
+  }
   const int t0 = 2 * kt, t1 = min(2 * kt + 1, meta.nt - 1);
   const int bminpos = min(m_minpos[t0], m_minpos[t1]);
   const int bmax = max(m_max[t0], m_max[t1]);
   const int qhi64 = max(meta.kv_hi[(size_t)b * meta.nt + t0], meta.kv_hi[(size_t)b * meta.nt + t1]);
-  const int qt_lo = k0 / BQ;                                  // first 64-row query tile (q >= kv), global index
   const int qt_end = min(qhi64 + 1, meta.nt);                 // exclusive
+  int wminpos, wmax;
+  wave_id_range(dkdoc, wminpos, wmax);
+  const bool w_uniform = (wminpos == wmax) && !__any(dkdoc == 0);   // all 32 kv rows in one document
   // query tiles this launch owns: per segment, the global 64-tile range clipped to [qt_lo, qt_end)
   int seg_lo[2], seg_n[2];
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
-    const int first = qv.off[s] / BQ, cnt = qv.tiles(s, BQ);
+    const int first = qv.off[s] / kTile, cnt = qv.tiles(s, kTile);
     seg_lo[s] = max(qt_lo, first);
     seg_n[s] = max(min(qt_end, first + cnt) - seg_lo[s], 0);
   }
   const int nqt = seg_n[0] + seg_n[1];
-  const int n_it = nqt * G;                                   // flattened (head-in-group, q tile)
-  auto tile_of = [&](int it, int& t64, int& lrow0, int& left) {   // global tile, local first row, rows left
-    const int idx = it % nqt;
-    const int s = idx >= seg_n[0] ? 1 : 0;
-    t64 = seg_lo[s] + idx - (s ? seg_n[0] : 0);
-    const int lt = t64 - qv.off[s] / BQ;
-    lrow0 = qv.row0[s] + lt * BQ;
-    left = min(qv.rows[s] - lt * BQ, T - t64 * BQ);
-  };
-  auto advance = [&](int it) {
-    while (it < n_it) {
-      int t64, l0, left;
-      tile_of(it, t64, l0, left);
-      if (tile_may_interact(m_minpos[t64], m_max[t64], bminpos, bmax)) break;
-      ++it;
+  __syncthreads();                                            // the statistics window is visible
+
+  // {min positive id, max id, min id} of q tile t64 >= win_lo.  Called by all waves at the same points with the same
+  // arguments (the scan below is workgroup-uniform), so the rare window refill may synchronise the workgroup.
+  int win_lo = qt_lo;
+  auto stat = [&](int t64) {
+    if (t64 >= win_lo + WIN) {
+      __syncthreads();
+      win_lo = t64;
+      for (int i = tid; i < WIN; i += 256) {
+        const int t = win_lo + i;
+        if (t < meta.nt) qstat[i] = i32x4_t{m_minpos[t], m_max[t], m_min[t], 0};
+      }
+      __syncthreads();
     }
-    return it;
+    return scalarize(qstat[t64 - win_lo]);
+  };
+  // ---- the stream of stages: (head in group, 32-row half of a 64-row q tile), skipping what cannot interact
+  int sc_g = 0, sc_i = 0;
+  auto next = [&]() {
+    QStage d = {0, 0, 0, 0, 0, 0, 0, 0};
+    while (sc_g < G) {
+      if (sc_i >= SPT * nqt) {
+        sc_i = 0;
+        ++sc_g;
+        continue;
+      }
+      const int idx = sc_i / SPT, half = sc_i % SPT;
+      ++sc_i;
+      const int s = idx >= seg_n[0] ? 1 : 0;
+      const int t64 = seg_lo[s] + idx - (s ? seg_n[0] : 0);
+      const int lt = t64 - qv.off[s] / kTile;
+      const int left = min(qv.rows[s] - lt * kTile, T - t64 * kTile) - BQ * half;
+      if (left <= 0) continue;
+      const int4 st = stat(t64);
+      if (!tile_may_interact(st.x, st.y, bminpos, bmax)) continue;
+      d.valid = 1;
+      d.qsb = t64 * kTile + BQ * half;
+      d.lrow = qv.row0[s] + lt * kTile + BQ * half;
+      d.left = min(left, BQ);
+      d.h = hk * G + sc_g;
+      d.mp = st.x;
+      d.mx = st.y;
+      d.mn = st.z;
+      break;
+    }
+    return d;
   };
 
-  f32x16_t dkacc[DO_DK ? DBLK : 1], dvacc[DO_DV ? DBLK : 1];
+  // ---- LDS-DMA sources: descriptors over this batch row's slices, lane part of the offsets
+  const size_t qrow_elems = (size_t)Nh * D;
+  const uint32_t q_bytes = (uint32_t)min((size_t)qv.rpb * qrow_elems * 2, (size_t)0x7fffffff);
+  const __amdgpu_buffer_rsrc_t rq =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(Q + (size_t)b * qv.rpb * qrow_elems), 0, q_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rdo =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(dO + (size_t)b * qv.rpb * qrow_elems), 0, q_bytes, 0x00020000);
+  const uint32_t s_bytes = (uint32_t)((size_t)Nh * qv.rpb * 4);
+  const __amdgpu_buffer_rsrc_t rlse =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(LSE2 + (size_t)b * Nh * qv.rpb), 0, s_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rdelta =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(Delta + (size_t)b * Nh * qv.rpb), 0, s_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rdoc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(doc + (size_t)b * T), 0, (uint32_t)T * 4, 0x00020000);
+  // lane L of a piece writes LDS chunk L = (row L >> 2, physical chunk L & 3) of a 16-row x 64-byte panel slab
+  const int rr = lane >> 2;
+  const uint32_t voff = (uint32_t)(((size_t)rr * qrow_elems + 8 * ((lane & 3) ^ ((rr >> 2) & 3))) * 2);
+  constexpr uint32_t OOB = 0x80000000u;       // >= num_records: the load returns 0 and touches no memory
+  // Always IPS instructions (the vmcnt arithmetic of the ring stays uniform): an invalid stage has left = 0, every
+  // lane is out of range, nothing is read and its slot is filled with zeros that nobody looks at.
+  auto issue = [&](const QStage& d, int slot) {
+    char* st = smem + slot * STAGEB;
+    const uint32_t base = (uint32_t)(((size_t)d.lrow * Nh + d.h) * D * 2);
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int pc = wave + 4 * i, panel = pc % Tile::NP, rh = pc / Tile::NP;
+      const uint32_t vo = (16 * rh + rr < d.left) ? voff : OOB;
+      const uint32_t so = base + (uint32_t)((16 * rh * qrow_elems + 32 * panel) * 2);
+      char* dst = st + panel * (Tile::PSTRIDE * 2) + rh * 1024;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (lds_ptr_t)dst, 16, vo, so, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rdo, (lds_ptr_t)(dst + IMGB), 16, vo, so, 0, 0);
+    }
+    const uint32_t va = lane < d.left ? (uint32_t)lane * 4 : OOB;
+    char* aux = st + 2 * IMGB;
+    const uint32_t srow = (uint32_t)(((size_t)d.h * qv.rpb + d.lrow) * 4);
+    if (wave == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rlse, (lds_ptr_t)aux, 4, va, srow, 0, 0);
+    else if (wave == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rdelta, (lds_ptr_t)(aux + 256), 4, va, srow, 0, 0);
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rdoc, (lds_ptr_t)(aux + 256 * wave), 4, va, (uint32_t)d.qsb * 4, 0, 0);
+  };
+
+  f32x16_t dkacc[DBLK], dvacc[DBLK];     // (the unused one of a single-output MODE is dead code)
 #pragma unroll
   for (int i = 0; i < DBLK; ++i)
 #pragma unroll
@@ -147,126 +260,115 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(
       if (DO_DV) dvacc[i][r] = 0.f;
     }
 
-  const TLdsReader<BQ> trd(l31, hi);
+  const PRowReader<BQ, D> rrd(l31, hi);
+  const PTrReader<BQ, D> trd(lane);
   const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  TransposeStage<BQ, D, 256> qst, dost;   // one register image serves both LDS images of a tile
-  float lse_st = 0.f, delta_st = 0.f;
-  int doc_st = 0;
-  const size_t qld = (size_t)Nh * D;
-  auto issue = [&](int it) {
-    int t64, lrow0, left;
-    tile_of(it, t64, lrow0, left);
-    const int h = hk * G + it / nqt;
-    const size_t base = (((size_t)b * qv.rpb + lrow0) * Nh + h) * D;
-    qst.load(Q + base, qld, left, tid);
-    dost.load(dO + base, qld, left, tid);
-    if (tid < BQ) {
-      const bool ok = tid < left;
-      const size_t si = ((size_t)b * Nh + h) * qv.rpb + lrow0 + (ok ? tid : 0);
-      lse_st = ok ? LSE2[si] : INFINITY;
-      delta_st = ok ? Delta[si] : 0.f;
-      doc_st = ok ? doc[(size_t)b * T + t64 * BQ + tid] : 0;
-    }
-  };
 
-  int it = advance(0);
-  if (it < n_it) issue(it);
-  while (it < n_it) {
-    const int itn = advance(it + 1);
-    __syncthreads();
-    qst.store_rowmajor(Qs, tid);
-    if (DO_DK) {
-      qst.store(Qt, tid);
-      dost.store_rowmajor(dOs, tid);
-    }
-    if (DO_DV) dost.store(dOt, tid);
-    if (tid < BQ) {
-      lse_s[tid] = lse_st;
-      delta_s[tid] = delta_st;
-      docq[tid] = doc_st;
-    }
-    __syncthreads();
-    if (itn < n_it) issue(itn);
+  // ring[0] = the stage being computed, ring[1 .. NST - 2] = the stages in flight behind it
+  QStage ring[NST - 1];
+#pragma unroll
+  for (int i = 0; i < NST - 1; ++i) {
+    ring[i] = next();
+    issue(ring[i], i);
+  }
+  int slot = 0;
+  while (ring[0].valid) {
+    const QStage cur = ring[0];
+    const QStage ahead = next();                 // scalar scan, off the critical path (before the wait)
+    // my pieces of `cur` have landed (the NST - 2 stages after it may stay in flight) ...
+    wait_vmcnt<(NST - 2) * IPS>();
+    // ... everybody's have, and everybody has left the previous stage: its slot takes the stage NST - 1 ahead
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    issue(ahead, (slot + NST - 1) % NST);
 
-    int t64, lrow0_unused, left_unused;
-    tile_of(it, t64, lrow0_unused, left_unused);
-    const int qb = t64 * BQ;
-    if (uniform(qb + BQ - 1 >= wk0 && tile_may_interact(m_minpos[t64], m_max[t64], wminpos, wmax))) {
-      const bool q_uniform = w_uniform && m_min[t64] == m_max[t64] && m_max[t64] == wmax;
+    const bf16_t* Qs = reinterpret_cast<const bf16_t*>(smem + slot * STAGEB);
+    const bf16_t* dOs = Qs + Tile::SIZE;
+    const float* lse_s = reinterpret_cast<const float*>(smem + slot * STAGEB + 2 * IMGB);
+    const float* delta_s = lse_s + 64;
+    const int* docq = reinterpret_cast<const int*>(lse_s + 128);
+    if (uniform(TN_BWD_ABL != 3 && cur.qsb + BQ - 1 >= wk0 && tile_may_interact(cur.mp, cur.mx, wminpos, wmax))) {
+      const bool q_uniform = w_uniform && cur.mn == cur.mx && cur.mx == wmax && cur.left == BQ;
+      // The work on one 32-row half (qs) of the stage, in pieces.  (Issuing both halves of an interior stage as ONE
+      // straight-line block — S of half 1 under the exponentials of half 0 — measured 3-9 % SLOWER: 226 -> 242 VGPRs.)
+      auto s_of = [&](int qs) {          // S[q, kv] = Q K^T: rows = q in registers, column = this lane's kv
+        f32x16_t a = mfma32(rrd.operand(Qs, 32 * qs, 0), kreg[0], zero16);
 #pragma unroll
-      for (int qs = 0; qs < 2; ++qs) {
-        const int qsb = qb + 32 * qs;
-        if (uniform(qsb + 31 >= wk0)) {                       // else: every q of this half precedes the kv rows
-          const bool need_mask = uniform(!(q_uniform && qsb >= wk0 + 31));
-          // ---- S[q, kv] = Q K^T (; dP[q, kv] = dO V^T)   rows = q in registers, column = this lane's kv
-          const bf16_t* qp = Qs + (32 * qs + l31) * LD + 8 * hi;
-          f32x16_t sacc = mfma32(as_bf16x8(*reinterpret_cast<const uint4*>(qp)), kreg[0], zero16);
+        for (int s = 1; s < KSTEPS; ++s) a = mfma32(rrd.operand(Qs, 32 * qs, s), kreg[s], a);
+        return a;
+      };
+      auto dp_of = [&](int qs) {         // dP[q, kv] = dO V^T
+        f32x16_t a = mfma32(rrd.operand(dOs, 32 * qs, 0), vreg[0], zero16);
 #pragma unroll
-          for (int s = 1; s < KSTEPS; ++s)
-            sacc = mfma32(as_bf16x8(*reinterpret_cast<const uint4*>(qp + 16 * s)), kreg[s], sacc);
-          f32x16_t dpacc = zero16;
-          if (DO_DK) {
-            const bf16_t* dop = dOs + (32 * qs + l31) * LD + 8 * hi;
+        for (int s = 1; s < KSTEPS; ++s) a = mfma32(rrd.operand(dOs, 32 * qs, s), vreg[DO_DK ? s : 0], a);
+        return a;
+      };
+      auto probs = [&](int qs, const f32x16_t& sacc, float (&p)[16], auto masked) {
+        constexpr bool MASK = decltype(masked)::value;
 #pragma unroll
-            for (int s = 0; s < KSTEPS; ++s)
-              dpacc = mfma32(as_bf16x8(*reinterpret_cast<const uint4*>(dop + 16 * s)), vreg[s], dpacc);
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const int o = 32 * qs + 8 * r4 + 4 * hi;
+          const f32x4_t l4 = *reinterpret_cast<const f32x4_t*>(lse_s + o);
+          const float le[4] = {l4.x, l4.y, l4.z, l4.w};
+          int qd[4] = {0, 0, 0, 0};
+          if (MASK) {
+            const i32x4_t q4 = *reinterpret_cast<const i32x4_t*>(docq + o);
+            qd[0] = q4.x; qd[1] = q4.y; qd[2] = q4.z; qd[3] = q4.w;
           }
-          float p[16];
-          auto probs = [&](auto masked) {
-            constexpr bool MASK = decltype(masked)::value;
 #pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-              const int o = 32 * qs + 8 * r4 + 4 * hi;
-              const float4 l4 = *reinterpret_cast<const float4*>(lse_s + o);
-              const float le[4] = {l4.x, l4.y, l4.z, l4.w};
-              int qd[4] = {0, 0, 0, 0};
-              if (MASK) {
-                const int4 q4 = *reinterpret_cast<const int4*>(docq + o);
-                qd[0] = q4.x; qd[1] = q4.y; qd[2] = q4.z; qd[3] = q4.w;
-              }
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                float pv = fast_exp2(sacc[4 * r4 + e] * scale_log2 - le[e]);
-                if (MASK) pv = ((kvrow <= qb + o + e) & (qd[e] == dkdoc) & (dkdoc > 0)) ? pv : 0.f;
-                p[4 * r4 + e] = pv;
-              }
-            }
-          };
-          if (need_mask) probs(std::true_type{}); else probs(std::false_type{});
-          if (DO_DV) {
-#pragma unroll
-            for (int sp = 0; sp < 2; ++sp) {
-              const u32x4_t t = {pack2bf(p[8 * sp + 0], p[8 * sp + 1]), pack2bf(p[8 * sp + 2], p[8 * sp + 3]),
-                                 pack2bf(p[8 * sp + 4], p[8 * sp + 5]), pack2bf(p[8 * sp + 6], p[8 * sp + 7])};
-              const bf16x8_t pb = __builtin_bit_cast(bf16x8_t, t);
-#pragma unroll
-              for (int db = 0; db < DBLK; ++db)     // dV^T[d, kv] += dO^T[d, q] P[q, kv]
-                dvacc[db] = mfma32(trd.operand(dOt, db, 8 * qs + 4 * sp), pb, dvacc[db]);
-            }
+          for (int e = 0; e < 4; ++e) {
+            float pv = fast_exp2(sacc[4 * r4 + e] * scale_log2 - le[e]);
+            if (MASK) pv = ((kvrow <= cur.qsb + o + e) & (qd[e] == dkdoc) & (dkdoc > 0)) ? pv : 0.f;
+            p[4 * r4 + e] = pv;
           }
-          if (DO_DK) {
+        }
+      };
+      auto packed = [&](const float (&p)[16], int sp) {
+        const u32x4_t t = {pack2bf(p[8 * sp + 0], p[8 * sp + 1]), pack2bf(p[8 * sp + 2], p[8 * sp + 3]),
+                           pack2bf(p[8 * sp + 4], p[8 * sp + 5]), pack2bf(p[8 * sp + 6], p[8 * sp + 7])};
+        return __builtin_bit_cast(bf16x8_t, t);
+      };
+      // acc += IMG^T[d, q] X[q, kv] over the 32 q rows of half qs (X = P or dS in registers, IMG^T by transpose reads)
+      auto acc_tr = [&](int qs, const bf16_t* img, f32x16_t (&acc)[DBLK], const float (&p)[16]) {
 #pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-              const float4 d4 = *reinterpret_cast<const float4*>(delta_s + 32 * qs + 8 * r4 + 4 * hi);
-              const float de[4] = {d4.x, d4.y, d4.z, d4.w};
+        for (int sp = 0; sp < 2; ++sp) {
+          const bf16x8_t x = packed(p, sp);
 #pragma unroll
-              for (int e = 0; e < 4; ++e) p[4 * r4 + e] *= dpacc[4 * r4 + e] - de[e];   // p becomes dS
-            }
+          for (int db = 0; db < DBLK; ++db) acc[db] = mfma32(trd.operand(img, db, 32 * qs + 16 * sp), x, acc[db]);
+        }
+      };
+      auto to_ds = [&](int qs, float (&p)[16], const f32x16_t& dpacc) {   // p becomes dS = P o (dP - delta)
 #pragma unroll
-            for (int sp = 0; sp < 2; ++sp) {
-              const u32x4_t u = {pack2bf(p[8 * sp + 0], p[8 * sp + 1]), pack2bf(p[8 * sp + 2], p[8 * sp + 3]),
-                                 pack2bf(p[8 * sp + 4], p[8 * sp + 5]), pack2bf(p[8 * sp + 6], p[8 * sp + 7])};
-              const bf16x8_t dsb = __builtin_bit_cast(bf16x8_t, u);
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const f32x4_t d4 = *reinterpret_cast<const f32x4_t*>(delta_s + 32 * qs + 8 * r4 + 4 * hi);
+          const float de[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
-              for (int db = 0; db < DBLK; ++db)     // dK^T[d, kv] += Q^T[d, q] dS[q, kv]
-                dkacc[db] = mfma32(trd.operand(Qt, db, 8 * qs + 4 * sp), dsb, dkacc[db]);
-            }
-          }
+          for (int e = 0; e < 4; ++e) p[4 * r4 + e] *= dpacc[4 * r4 + e] - de[e];
+        }
+      };
+#pragma unroll
+      for (int qs = 0; qs < BQ / 32; ++qs) {
+        const int qsb = cur.qsb + 32 * qs;
+        if (!uniform(qsb + 31 >= wk0)) continue;                // every q of this half precedes the kv rows
+        const bool need_mask = uniform(!(q_uniform && qsb >= wk0 + 31));
+        const f32x16_t sacc = s_of(qs);
+        f32x16_t dpacc = zero16;
+        if (DO_DK) dpacc = dp_of(qs);
+        float p[16];
+        if (need_mask) probs(qs, sacc, p, std::true_type{}); else probs(qs, sacc, p, std::false_type{});
+        if (DO_DV) acc_tr(qs, dOs, dvacc, p);
+        if (DO_DK) {
+          to_ds(qs, p, dpacc);
+          acc_tr(qs, Qs, dkacc, p);
         }
       }
     }
-    it = itn;
+#pragma unroll
+    for (int i = 0; i + 1 < NST - 1; ++i) ring[i] = ring[i + 1];
+    ring[NST - 2] = ahead;
+    slot = (slot + 1) % NST;
   }
+  wait_vmcnt<0>();      // (the zero-fill tail DMAs)
 
   if (kvalid) {
     const size_t off = (((size_t)b * T + kvrow) * Nkv + hk) * D;
@@ -299,15 +401,23 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(
     const bf16_t* __restrict__ dO, const float* __restrict__ LSE2, const float* __restrict__ Delta,
     bf16_t* __restrict__ dQ, const int* __restrict__ doc, AttnMeta meta, QView qv, int T, int Nh, int Nkv,
     float scale, float scale_log2) {
-  constexpr int BM = 128, BN = 64;
-  constexpr int KSTEPS = D / 16, DBLK = D / 32, LD = D + 8, TS = TLds<BN>::STRIDE;
-  __shared__ __attribute__((aligned(16))) bf16_t smem[2 * BN * LD + D * TS + 2 * BN];
-  bf16_t* Ks = smem;
-  bf16_t* Vs = Ks + BN * LD;
-  bf16_t* Kt = Vs + BN * LD;
-  int* docs = reinterpret_cast<int*>(Kt + D * TS);
+  constexpr int BM = 128, BN = 64, NST = 2;
+  constexpr int KSTEPS = D / 16, DBLK = D / 32;
+  using Tile = PTile<BN, D>;
+  constexpr int IMGB = Tile::SIZE * 2;          // bytes of one panel image
+  constexpr int NPC = Tile::NP * (BN / 16);     // 1-KiB DMA pieces per image
+  constexpr int PPW = NPC / 4;                  // pieces per wave and image
+  constexpr int IPS = 2 * PPW + 1;              // DMA instructions per wave and stage
+  constexpr int STAGEB = 2 * IMGB + 4 * 256;    // {K image | V image | doc ids[64] | 3 spare rows}
+  constexpr int WIN = 256;                      // kv tiles whose statistics are kept in LDS
+  // K image: rows -> A of S^T = K Q^T, transposed -> A of dQ^T += K^T dS^T;  V image: rows -> A of dP^T = V dO^T.
+  // Stages = the kv tiles this workgroup meets, streamed by LDS-DMA exactly like the dK/dV kernel's (one LDS variable,
+  // see there).
+  __shared__ __attribute__((aligned(1024))) char smem[NST * STAGEB + WIN * 16];
+  i32x4_t* kstat = reinterpret_cast<i32x4_t*>(smem + NST * STAGEB);
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, hi = lane >> 5;
   const int h = head_of_slot(blockIdx.x, Nh, Nkv), b = blockIdx.z;
   const int hk = h / (Nh / Nkv);
@@ -335,23 +445,85 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(
   const int dq = qvalid ? doc[(size_t)b * T + qrow] : 0;
   const float lse2 = qvalid ? LSE2[((size_t)b * Nh + h) * qv.rpb + lrow] : INFINITY;
   const float delta = qvalid ? Delta[((size_t)b * Nh + h) * qv.rpb + lrow] : 0.f;
-  int wminpos, wmax;
-  wave_id_range(dq, wminpos, wmax);
-  const bool w_has_zero = __any(dq == 0);
 
   const int* m_min = meta.tmin + (size_t)b * meta.nt;
   const int* m_max = meta.tmax + (size_t)b * meta.nt;
   const int* m_minpos = meta.tminpos + (size_t)b * meta.nt;
   const int t0 = q0 / kTile, t1 = min(t0 + 1, meta.nt - 1);
+  const int j_hi = t1;
+  // statistics window: the WIN tiles that END at the diagonal are the ones a packed batch needs; a longer reach (plain
+  // causal beyond 16 k positions) starts below it and refills the window on the way up
+  const int j_lo = min(meta.q_lo[(size_t)b * meta.nt + t0], meta.q_lo[(size_t)b * meta.nt + t1]);
+  int win_lo = max(j_lo, 0);
+  auto fill_window = [&]() {
+    for (int i = tid; i < WIN; i += 256) {
+      const int t = win_lo + i;
+      if (t < meta.nt) kstat[i] = i32x4_t{m_minpos[t], m_max[t], m_min[t], 0};
+    }
+  };
+  fill_window();
   const int bminpos = min(m_minpos[t0], m_minpos[t1]);
   const int bmax = max(m_max[t0], m_max[t1]);
-  const int j_hi = t1;
-  int j = min(meta.q_lo[(size_t)b * meta.nt + t0], meta.q_lo[(size_t)b * meta.nt + t1]);
-  auto advance = [&](int jj) {
-    while (jj <= j_hi && !tile_may_interact(bminpos, bmax, m_minpos[jj], m_max[jj])) ++jj;
-    return jj;
+  int wminpos, wmax;
+  wave_id_range(dq, wminpos, wmax);
+  const bool w_has_zero = __any(dq == 0);
+  __syncthreads();
+
+  struct KStage {
+    int valid, j, mn, mx, mp;
   };
-  j = advance(j);
+  int sc_j = j_lo;
+  auto next = [&]() {
+    KStage d = {0, 0, 0, 0, 0};
+    while (sc_j <= j_hi) {
+      const int jj = sc_j++;
+      if (jj >= win_lo + WIN) {            // (workgroup-uniform: every wave runs the same scan)
+        __syncthreads();
+        win_lo = jj;
+        fill_window();
+        __syncthreads();
+      }
+      const int4 st = scalarize(kstat[jj - win_lo]);
+      if (!tile_may_interact(bminpos, bmax, st.x, st.y)) continue;
+      d.valid = 1;
+      d.j = jj;
+      d.mp = st.x;
+      d.mx = st.y;
+      d.mn = st.z;
+      break;
+    }
+    return d;
+  };
+
+  const size_t krow_elems = (size_t)Nkv * D;
+  const uint32_t k_bytes = (uint32_t)min((size_t)T * krow_elems * 2, (size_t)0x7fffffff);
+  const __amdgpu_buffer_rsrc_t rk =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(K + (size_t)b * T * krow_elems), 0, k_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(V + (size_t)b * T * krow_elems), 0, k_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rdoc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(doc + (size_t)b * T), 0, (uint32_t)T * 4, 0x00020000);
+  const int rr = lane >> 2;
+  const uint32_t voff = (uint32_t)(((size_t)rr * krow_elems + 8 * ((lane & 3) ^ ((rr >> 2) & 3))) * 2);
+  constexpr uint32_t OOB = 0x80000000u;
+  auto issue = [&](const KStage& d, int slot) {      // always IPS instructions; an invalid stage reads nothing
+    char* st = smem + slot * STAGEB;
+    const int k0 = d.j * BN;
+    const int left = d.valid ? min(T - k0, BN) : 0;
+    const uint32_t base = (uint32_t)(((size_t)k0 * Nkv + hk) * D * 2);
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int pc = wave + 4 * i, panel = pc % Tile::NP, rh = pc / Tile::NP;
+      const uint32_t vo = (16 * rh + rr < left) ? voff : OOB;
+      const uint32_t so = base + (uint32_t)((16 * rh * krow_elems + 32 * panel) * 2);
+      char* dst = st + panel * (Tile::PSTRIDE * 2) + rh * 1024;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (lds_ptr_t)dst, 16, vo, so, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lds_ptr_t)(dst + IMGB), 16, vo, so, 0, 0);
+    }
+    const uint32_t va = lane < left ? (uint32_t)lane * 4 : OOB;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rdoc, (lds_ptr_t)(st + 2 * IMGB + 256 * wave), 4, va, (uint32_t)k0 * 4, 0,
+                                             0);
+  };
 
   f32x16_t dqacc[DBLK];
 #pragma unroll
@@ -359,46 +531,41 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) dqacc[i][r] = 0.f;
 
-  const TLdsReader<BN> trd(l31, hi);
+  const PRowReader<BN, D> rrd(l31, hi);
+  const PTrReader<BN, D> trd(lane);
   const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  TransposeStage<BN, D, 256> kst;   // K: written row-major AND transposed from the same registers
-  RowMajorStage<BN, D, 256> vst;
-  int dstage = 0;
-  const size_t kvld = (size_t)Nkv * D;
-  auto issue = [&](int jj) {
-    const int k0 = jj * BN;
-    const size_t base = (((size_t)b * T + k0) * Nkv + hk) * D;
-    kst.load(K + base, kvld, T - k0, tid);
-    vst.load(V + base, kvld, T - k0, tid);
-    if (tid < BN) dstage = (k0 + tid < T) ? doc[(size_t)b * T + k0 + tid] : 0;
-  };
-  if (j <= j_hi) issue(j);
 
-  while (j <= j_hi) {
-    const int jn = advance(j + 1);
-    __syncthreads();
-    kst.store_rowmajor(Ks, tid);
-    kst.store(Kt, tid);
-    vst.store(Vs, tid);
-    if (tid < BN) docs[tid] = dstage;
-    __syncthreads();
-    if (jn <= j_hi) issue(jn);
+  KStage ring[NST - 1];
+#pragma unroll
+  for (int i = 0; i < NST - 1; ++i) {
+    ring[i] = next();
+    issue(ring[i], i);
+  }
+  int slot = 0;
+  while (ring[0].valid) {
+    const KStage cur = ring[0];
+    const KStage ahead = next();
+    wait_vmcnt<(NST - 2) * IPS>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    issue(ahead, (slot + NST - 1) % NST);
 
-    const int k0 = j * BN;
-    if (uniform(k0 <= wq0 + 31 && tile_may_interact(wminpos, wmax, m_minpos[j], m_max[j]))) {
-      const bool need_mask = uniform(!(m_min[j] == m_max[j] && m_max[j] == wminpos && wminpos == wmax &&
-                                       !w_has_zero && (k0 + BN - 1 <= wq0)));
+    const bf16_t* Ks = reinterpret_cast<const bf16_t*>(smem + slot * STAGEB);
+    const bf16_t* Vs = Ks + Tile::SIZE;
+    const int* docs = reinterpret_cast<const int*>(smem + slot * STAGEB + 2 * IMGB);
+    const int k0 = cur.j * BN;
+    if (uniform(TN_BWD_ABL != 3 && k0 <= wq0 + 31 && tile_may_interact(wminpos, wmax, cur.mp, cur.mx))) {
+      const bool need_mask = uniform(!(cur.mn == cur.mx && cur.mx == wminpos && wminpos == wmax && !w_has_zero &&
+                                       (k0 + BN - 1 <= wq0)));
 #pragma unroll
       for (int blk = 0; blk < 2; ++blk) {
         if (uniform(k0 + 32 * blk <= wq0 + 31)) {             // else: this 32-row KV block is above the diagonal
-          const bf16_t* kp = Ks + (32 * blk + l31) * LD + 8 * hi;
-          const bf16_t* vp = Vs + (32 * blk + l31) * LD + 8 * hi;
-          f32x16_t sacc = mfma32(as_bf16x8(*reinterpret_cast<const uint4*>(kp)), qreg[0], zero16);
-          f32x16_t dpacc = mfma32(as_bf16x8(*reinterpret_cast<const uint4*>(vp)), doreg[0], zero16);
+          f32x16_t sacc = mfma32(rrd.operand(Ks, 32 * blk, 0), qreg[0], zero16);
+          f32x16_t dpacc = mfma32(rrd.operand(Vs, 32 * blk, 0), doreg[0], zero16);
 #pragma unroll
           for (int s = 1; s < KSTEPS; ++s) {
-            sacc = mfma32(as_bf16x8(*reinterpret_cast<const uint4*>(kp + 16 * s)), qreg[s], sacc);
-            dpacc = mfma32(as_bf16x8(*reinterpret_cast<const uint4*>(vp + 16 * s)), doreg[s], dpacc);
+            sacc = mfma32(rrd.operand(Ks, 32 * blk, s), qreg[s], sacc);
+            dpacc = mfma32(rrd.operand(Vs, 32 * blk, s), doreg[s], dpacc);
           }
           float ds[16];
           auto dscore = [&](auto masked) {
@@ -407,7 +574,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(
             for (int r4 = 0; r4 < 4; ++r4) {
               int dkk[4] = {0, 0, 0, 0};
               if (MASK) {
-                const int4 dk = *reinterpret_cast<const int4*>(docs + 32 * blk + 8 * r4 + 4 * hi);
+                const i32x4_t dk = *reinterpret_cast<const i32x4_t*>(docs + 32 * blk + 8 * r4 + 4 * hi);
                 dkk[0] = dk.x; dkk[1] = dk.y; dkk[2] = dk.z; dkk[3] = dk.w;
               }
 #pragma unroll
@@ -430,13 +597,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(
             const bf16x8_t dsb = __builtin_bit_cast(bf16x8_t, u);
 #pragma unroll
             for (int db = 0; db < DBLK; ++db)       // dQ^T[d, q] += K^T[d, kv] dS^T[kv, q]
-              dqacc[db] = mfma32(trd.operand(Kt, db, 8 * blk + 4 * sp), dsb, dqacc[db]);
+              dqacc[db] = mfma32(trd.operand(Ks, db, 32 * blk + 16 * sp), dsb, dqacc[db]);
           }
         }
       }
     }
-    j = jn;
+#pragma unroll
+    for (int i = 0; i + 1 < NST - 1; ++i) ring[i] = ring[i + 1];
+    ring[NST - 2] = ahead;
+    slot = (slot + 1) % NST;
   }
+  wait_vmcnt<0>();      // (the zero-fill tail DMAs)
 
   if (qvalid) {
     bf16_t* op = dQ + (((size_t)b * qv.rpb + lrow) * Nh + h) * D;

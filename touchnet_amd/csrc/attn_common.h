@@ -20,6 +20,13 @@
 namespace tn {
 
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+// LDS reads in kernels that fill LDS by LDS-DMA (buffer_load ... lds) must go through these ext_vector_type pointers,
+// NOT through HIP's uint4 / int4 / float4 structs: hipcc's waitcnt insertion puts an `s_waitcnt vmcnt(0)` in front of
+// any LDS access that carries no alias metadata while an LDS-DMA is pending (it cannot tell the slots of a ring apart),
+// which silently serialises a hand-counted vmcnt(N) pipeline; loads through vector-typed pointers carry TBAA metadata
+// and are left alone (checked in the ISA: scripts/check_dma_waits.sh).
 
 __device__ __forceinline__ f32x16_t mfma32(bf16x8_t a, bf16x8_t b, f32x16_t c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
@@ -150,6 +157,10 @@ __device__ __forceinline__ int4 list_entry(const int4* list, int i) {
   return make_int4(__builtin_amdgcn_readfirstlane(e.x), __builtin_amdgcn_readfirstlane(e.y),
                    __builtin_amdgcn_readfirstlane(e.z), __builtin_amdgcn_readfirstlane(e.w));
 }
+__device__ __forceinline__ int4 scalarize(i32x4_t e) {
+  return make_int4(__builtin_amdgcn_readfirstlane(e.x), __builtin_amdgcn_readfirstlane(e.y),
+                   __builtin_amdgcn_readfirstlane(e.z), __builtin_amdgcn_readfirstlane(e.w));
+}
 __device__ __forceinline__ int4 scalarize(int4 e) {
   return make_int4(__builtin_amdgcn_readfirstlane(e.x), __builtin_amdgcn_readfirstlane(e.y),
                    __builtin_amdgcn_readfirstlane(e.z), __builtin_amdgcn_readfirstlane(e.w));
@@ -223,6 +234,73 @@ struct TLdsReader {
     return __builtin_bit_cast(bf16x8_t, t);
   }
 };
+
+// ---- Panel image: ONE LDS copy of an [R rows][D] bf16 tile that serves both MFMA operand shapes ------------------
+// The tile is cut into D/32 column panels of [R][32] (64-byte rows, panel stride R*64 + 64 bytes); inside a row the
+// four 16-byte chunks are permuted by XOR with (row >> 2) & 3:
+//   element (r, d) lives at  (d >> 5) * PSTRIDE + r * 32 + 8 * (((d >> 3) & 3) ^ ((r >> 2) & 3)) + (d & 7)
+// * "row" operand (lane = tile row, 8 consecutive d per contraction slot group): one ds_read_b128; the 16 lanes of a
+//   b128 service group hold 16 distinct (r & 15) -> 16 distinct 16-byte slots of the 256-byte bank row;
+// * "transposed" operand (lane = d, contraction slots = tile rows): two ds_read_b64_tr_b16 (gfx950 transpose read: the
+//   16 lanes of a group each point at 4 consecutive d of one row, rows 4 apart in groups of 4; lane i of the group
+//   receives column i of the [4 rows][16 d] block — measured with scripts/microbench/tr_read_probe.hip).  The 32 lanes
+//   of a service group cover 4 consecutive rows x 64 bytes = one contiguous 256-byte bank row: conflict free;
+// * fill: 16-byte stores; 8 consecutive lanes write chunks 8p..8p+7 of one row = two neighbouring panels, whose
+//   addresses differ by 64 bytes mod 128: conflict free for ds_write_b128's 8-lane groups.
+// Replaces the row-major + transposed image pairs (the transposed ones were written with 8-byte transposing stores:
+// 16 v_perm per 4x8 unit and 24-36 % LDS bank-conflict cycles, profiles/r02_attention_pmc_final.md).
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+
+template <int R, int D>
+struct PTile {
+  static constexpr int NP = D / 32, PSTRIDE = R * 32 + 32, SIZE = NP * PSTRIDE;   // elements
+  static __device__ __forceinline__ int chunk_off(int r, int c) {                  // c = d >> 3
+    return (c >> 2) * PSTRIDE + r * 32 + 8 * ((c & 3) ^ ((r >> 2) & 3));
+  }
+};
+
+// "row" operand reads: zero address VALU inside the tile loops (lane part: two VGPRs; the rest is a compile-time offset)
+template <int R, int D>
+struct PRowReader {
+  int a[2];
+  __device__ __forceinline__ PRowReader(int l31, int hi) {
+    const int x = (l31 >> 2) & 3;
+    a[0] = l31 * 32 + 8 * (hi ^ x);
+    a[1] = l31 * 32 + 8 * ((2 + hi) ^ x);
+  }
+  // contraction slots d = 16 * s + 8 * hi + (0..7) of row rb + l31 (rb a multiple of 16)
+  __device__ __forceinline__ bf16x8_t operand(const bf16_t* img, int rb, int s) const {
+    return __builtin_bit_cast(
+        bf16x8_t, *reinterpret_cast<const u32x4_t*>(img + (s >> 1) * PTile<R, D>::PSTRIDE + rb * 32 + a[s & 1]));
+  }
+};
+
+// "transposed" operand reads: lane = d (32 * db + (lane & 31)), slots (hi, i) = rows kb + 8 * (i >> 2) + 4 * hi + (i & 3)
+// (kb a multiple of 16) — exactly the rows a lane of a 32x32 MFMA result holds in registers 8 * sp .. 8 * sp + 7.
+template <int R, int D>
+struct PTrReader {
+  int t[2];
+  __device__ __forceinline__ PTrReader(int lane) {
+    const int s4 = lane & 15, half = (lane >> 4) & 1, hi = lane >> 5;
+    const int j = s4 >> 2, q = 2 * half + ((s4 & 3) >> 1);
+    t[0] = (4 * hi + j) * 32 + 8 * (q ^ hi) + 4 * (s4 & 1);
+    t[1] = (4 * hi + j) * 32 + 8 * ((q ^ hi) ^ 2) + 4 * (s4 & 1);
+  }
+  static __device__ __forceinline__ s16x4_t tr(const bf16_t* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p);
+  }
+  __device__ __forceinline__ bf16x8_t operand(const bf16_t* img, int db, int kb) const {
+    const bf16_t* base = img + db * PTile<R, D>::PSTRIDE + kb * 32;
+    const s16x4_t lo = tr(base + t[(kb >> 3) & 1]);
+    const s16x4_t up = tr(base + 8 * 32 + t[((kb >> 3) & 1) ^ 1]);
+    return __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(lo, up, 0, 1, 2, 3, 4, 5, 6, 7));
+  }
+};
+
+// (With LDS-DMA in flight hipcc puts `s_waitcnt vmcnt(0)` in front of the transpose-read builtin as well — the builtin
+// carries no alias metadata.  At the prefetch distance the dK/dV kernel can afford, one stage, that wait costs nothing;
+// an inline-asm read with hand-placed lgkmcnt waits removes it and measured 1-5 % slower, so the builtin stays.)
 
 // Wave-uniform buffer descriptor over the first `rows_valid` rows of a [rows][ld] bf16 tile starting at
 // `base`: loads past the last valid row return 0 in hardware (no exec-mask branches around tile edges).
@@ -322,6 +400,33 @@ struct TransposeStage {
           lds_store64(dst + TLds<R>::off(c8 * 8 + dd, r4), (uint64_t)o.x | ((uint64_t)o.y << 32));
         }
       }
+    }
+  }
+};
+
+// Stage a [R rows][D] bf16 tile (source row stride `ld` elements, rows >= rows_valid zero-filled) into a PTile image:
+// full-row coalesced 16-byte global loads now, 16-byte LDS stores later.
+template <int R, int D, int NT>
+struct PStage {
+  static constexpr int CPR = D / 8;
+  static constexpr int N = (R * CPR + NT - 1) / NT;
+  static constexpr bool EXACT = (R * CPR) % NT == 0;
+  uint4 v[N];
+  __device__ __forceinline__ void load(const bf16_t* src, size_t ld, int rows_valid, int tid) {
+    const __amdgpu_buffer_rsrc_t rs = tile_rsrc(src, ld, rows_valid < R ? rows_valid : R, D);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const int c = tid + i * NT;
+      const int r = c / CPR, cc = c % CPR;
+      v[i] = buf_load16(rs, (EXACT || c < R * CPR) ? (uint32_t)((r * ld + cc * 8) * 2) : 0xffffffffu);
+    }
+  }
+  __device__ __forceinline__ void store(bf16_t* dst, int tid) const {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const int c = tid + i * NT;
+      const int r = c / CPR, cc = c % CPR;
+      if (EXACT || c < R * CPR) *reinterpret_cast<uint4*>(dst + PTile<R, D>::chunk_off(r, cc)) = v[i];
     }
   }
 };

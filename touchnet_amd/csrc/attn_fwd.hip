@@ -18,7 +18,8 @@
 //
 // Per KV tile and wave:  S^T = K Q^T (A = K from LDS, B = Q in registers) so that every lane owns ONE
 // query column: softmax statistics are lane-local (one cross-half shuffle), P never leaves registers and
-// feeds O^T += V^T P^T directly as the B operand (A = V^T from a transposed, swizzled LDS image).
+// feeds O^T += V^T P^T directly as the B operand (A = V^T, read with the gfx950 transpose read from the SAME kind of
+// row-major panel image K uses: attn_common.h PTile).
 #include <stdlib.h>
 
 #include "attn_common.h"
@@ -73,7 +74,7 @@ __global__ void attn_meta_range_kernel(const int* __restrict__ tmax, const int* 
 // ABL (ablation, timing experiments only — results are wrong for ABL != 0; reached through tn_attn_fwd_ablate):
 //   1 no in-loop global loads / LDS stores   2 no softmax VALU   3 no P.V MFMAs   4 no QK^T MFMAs   5 no barrier
 template <int D, int ABL = 0, int NW = 4>
-__global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+__global__ __launch_bounds__(64 * NW, D == 64 ? 3 : 2) void attn_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                        const bf16_t* __restrict__ V, bf16_t* __restrict__ O,
                                                        float* __restrict__ LSE2, const int* __restrict__ doc,
                                                        AttnMeta meta, QView qv, int T, int Nh, int Nkv,
@@ -81,10 +82,10 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(const bf16_t* __re
   constexpr int BM = 32 * NW, BN = 64, NT = 64 * NW;   // NW waves x 32 query rows
   constexpr int KSTEPS = D / 16;   // MFMA k-steps over the head dim
   constexpr int DBLK = D / 32;     // 32-wide output blocks over the head dim
-  constexpr int KLD = D + 8;       // row-major K image leading dim (elements)
-  // two LDS buffers {K row-major | V^T swizzled | doc ids}: tile j+1 is written while tile j is being consumed,
-  // ONE barrier per KV tile (2 x 38 KB at D=128 -> still two workgroups per CU)
-  constexpr int BUF = BN * KLD + D * TLds<BN>::STRIDE + 2 * BN;
+  using Tile = PTile<BN, D>;
+  // two LDS buffers {K image | V image | doc ids}: tile j+1 is written while tile j is being consumed,
+  // ONE barrier per KV tile (2 x 33.5 KB at D=128 -> two workgroups per CU)
+  constexpr int BUF = 2 * Tile::SIZE + 2 * BN;
   __shared__ __attribute__((aligned(16))) bf16_t smem[2 * BUF];
   constexpr int CAP = 192;            // list chunk: 3 KB, keeps two workgroups per CU at D = 128 (2 x 79.4 KB)
   __shared__ __attribute__((aligned(16))) int4 tlist[CAP + 4];        // interacting KV tiles (attn_common.h)
@@ -136,11 +137,11 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(const bf16_t* __re
 #pragma unroll
     for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
   float m_run = -1e30f, l_run = 0.f;
-  const TLdsReader<BN> vrd(l31, hi);
+  const PRowReader<BN, D> krd(l31, hi);
+  const PTrReader<BN, D> vrd(lane);
   const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
-  RowMajorStage<BN, D, NT> kst;
-  TransposeStage<BN, D, NT> vst;
+  PStage<BN, D, NT> kst, vst;
   int dstage = 0;
   const size_t kvld = (size_t)Nkv * D;
   auto issue = [&](int jj) {
@@ -153,8 +154,8 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(const bf16_t* __re
   auto stage_store = [&](int buf) {
     bf16_t* base = smem + buf * BUF;
     kst.store(base, tid);
-    vst.store(base + BN * KLD, tid);
-    if (tid < BN) reinterpret_cast<int*>(base + BN * KLD + D * TLds<BN>::STRIDE)[tid] = dstage;
+    vst.store(base + Tile::SIZE, tid);
+    if (tid < BN) reinterpret_cast<int*>(base + 2 * Tile::SIZE)[tid] = dstage;
   };
   // The tiles of [j_lo, j_hi] are walked in chunks of CAP through the LDS list.
   int cur = 0;
@@ -170,8 +171,8 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(const bf16_t* __re
     for (int i = 0; i < n; ++i) {
       const int4 e_nn = tlist[i + 2];       // (vector read now, scalarised at the hand-over)
       const bf16_t* Ks = smem + cur * BUF;
-      const bf16_t* Vt = Ks + BN * KLD;
-      const int* docs = reinterpret_cast<const int*>(Vt + D * TLds<BN>::STRIDE);
+      const bf16_t* Vs = Ks + Tile::SIZE;
+      const int* docs = reinterpret_cast<const int*>(Vs + Tile::SIZE);
       const int j = e_cur.x, kmin = e_cur.y, kmax = e_cur.z, kminpos = e_cur.w;
       const int k0 = j * BN;
     if (uniform(k0 <= wq0 + 31 && tile_may_interact(wminpos, wmax, kminpos, kmax))) {
@@ -181,11 +182,10 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(const bf16_t* __re
       f32x16_t sacc[2];
 #pragma unroll
       for (int blk = 0; blk < 2; ++blk) {
-        const bf16_t* kp = Ks + (32 * blk + l31) * KLD + 8 * hi;
-        sacc[blk] = mfma32(as_bf16x8(*reinterpret_cast<const uint4*>(kp)), qreg[0], zero16);
+        sacc[blk] = mfma32(krd.operand(Ks, 32 * blk, 0), qreg[0], zero16);
 #pragma unroll
         for (int s = 1; s < (ABL == 4 ? 1 : KSTEPS); ++s)
-          sacc[blk] = mfma32(as_bf16x8(*reinterpret_cast<const uint4*>(kp + 16 * s)), qreg[s], sacc[blk]);
+          sacc[blk] = mfma32(krd.operand(Ks, 32 * blk, s), qreg[s], sacc[blk]);
       }
       // ---- mask, online softmax (lane-local: this lane's query column).  Scores stay RAW in the accumulator;
       // the softmax scale rides in the exponent's fma: p = exp2(s * c - m), m tracked in the scaled domain.
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(const bf16_t* __re
               asm volatile("" ::"v"(pb[blk][sp]));      // keep P live so its producers are not dead code
               continue;
             }
-            oacc[db] = mfma32(vrd.operand(Vt, db, 8 * blk + 4 * sp), pb[blk][sp], oacc[db]);
+            oacc[db] = mfma32(vrd.operand(Vs, db, 32 * blk + 16 * sp), pb[blk][sp], oacc[db]);
           }
         }
       }
