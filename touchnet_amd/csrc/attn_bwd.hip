@@ -104,12 +104,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(
   constexpr int PPW = NPC / 4;                  // pieces per wave and image
   constexpr int IPS = 2 * PPW + 1;              // DMA instructions per wave and stage (Q, dO pieces + one aux row)
   constexpr int STAGEB = 2 * IMGB + 4 * 256;    // {Q image | dO image | lse[64] | delta[64] | doc[64] | spare[64]}
-  constexpr int WIN = 256;                      // q tiles after the kv block whose statistics are kept in LDS
+  constexpr int LCAP = 256;                     // stage-list chunk: one candidate stage per thread
   // ONE LDS variable on purpose: with two, hipcc's module-LDS lowering attaches alias scopes to every access and the
   // waitcnt insertion then puts `s_waitcnt vmcnt(0)` in front of the first LDS read that may alias a pending LDS-DMA
   // (= every read of the ring), which serialises the ring (see attn_common.h, i32x4_t).
-  __shared__ __attribute__((aligned(1024))) char smem[NST * STAGEB + WIN * 16];
-  i32x4_t* qstat = reinterpret_cast<i32x4_t*>(smem + NST * STAGEB);
+  __shared__ __attribute__((aligned(1024))) char smem[NST * STAGEB + (LCAP + NST) * 32 + 16];
+  i32x4_t* slist = reinterpret_cast<i32x4_t*>(smem + NST * STAGEB);     // entry e = {slist[2e], slist[2e + 1]}
+  int* wcount = reinterpret_cast<int*>(smem + NST * STAGEB + (LCAP + NST) * 32);
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -141,10 +142,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(
   const int* m_max = meta.tmax + (size_t)b * meta.nt;
   const int* m_minpos = meta.tminpos + (size_t)b * meta.nt;
   const int qt_lo = k0 / kTile;                               // first 64-position query tile (q >= kv), global index
-  for (int i = tid; i < WIN; i += 256) {
-    const int t = qt_lo + i;
-    if (t < meta.nt) qstat[i] = i32x4_t{m_minpos[t], m_max[t], m_min[t], 0};
-  }
   const int t0 = 2 * kt, t1 = min(2 * kt + 1, meta.nt - 1);
   const int bminpos = min(m_minpos[t0], m_minpos[t1]);
   const int bmax = max(m_max[t0], m_max[t1]);
@@ -162,52 +159,57 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(
     seg_n[s] = max(min(qt_end, first + cnt) - seg_lo[s], 0);
   }
   const int nqt = seg_n[0] + seg_n[1];
-  __syncthreads();                                            // the statistics window is visible
-
-  // {min positive id, max id, min id} of q tile t64 >= win_lo.  Called by all waves at the same points with the same
-  // arguments (the scan below is workgroup-uniform), so the rare window refill may synchronise the workgroup.
-  int win_lo = qt_lo;
-  auto stat = [&](int t64) {
-    if (t64 >= win_lo + WIN) {
-      __syncthreads();
-      win_lo = t64;
-      for (int i = tid; i < WIN; i += 256) {
-        const int t = win_lo + i;
-        if (t < meta.nt) qstat[i] = i32x4_t{m_minpos[t], m_max[t], m_min[t], 0};
-      }
-      __syncthreads();
-    }
-    return scalarize(qstat[t64 - win_lo]);
-  };
-  // ---- the stream of stages: (head in group, 32-row half of a 64-row q tile), skipping what cannot interact
-  int sc_g = 0, sc_i = 0;
-  auto next = [&]() {
+  // ---- the stream of stages: (head in group, BQ-row part of a 64-row q tile), skipping what cannot interact.
+  // The per-stage bookkeeping used to be a scalar scan every wave ran between two stages (≈100 SALU instructions per
+  // stage and wave: 7 SALU per MFMA in the dV kernel's PMC); now the workgroup compacts LCAP candidate stages at a time
+  // into an LDS list — one candidate per thread, ballot compaction as in attn_common.h — and the loop reads entries.
+  const int per_head = SPT * nqt, total_c = per_head * G;
+  auto build_list = [&](int cb) {       // candidates [cb, cb + LCAP) -> n entries (+ NST invalid ones behind them)
+    const int c = cb + tid;
     QStage d = {0, 0, 0, 0, 0, 0, 0, 0};
-    while (sc_g < G) {
-      if (sc_i >= SPT * nqt) {
-        sc_i = 0;
-        ++sc_g;
-        continue;
-      }
-      const int idx = sc_i / SPT, half = sc_i % SPT;
-      ++sc_i;
-      const int s = idx >= seg_n[0] ? 1 : 0;
-      const int t64 = seg_lo[s] + idx - (s ? seg_n[0] : 0);
-      const int lt = t64 - qv.off[s] / kTile;
-      const int left = min(qv.rows[s] - lt * kTile, T - t64 * kTile) - BQ * half;
-      if (left <= 0) continue;
-      const int4 st = stat(t64);
-      if (!tile_may_interact(st.x, st.y, bminpos, bmax)) continue;
-      d.valid = 1;
-      d.qsb = t64 * kTile + BQ * half;
-      d.lrow = qv.row0[s] + lt * kTile + BQ * half;
+    if (c < total_c) {
+      const int g = c / per_head, r = c - g * per_head;
+      const int idx = r / SPT, part = r % SPT;
+      const int sg = idx >= seg_n[0] ? 1 : 0;
+      const int t64 = seg_lo[sg] + idx - (sg ? seg_n[0] : 0);
+      const int lt = t64 - qv.off[sg] / kTile;
+      const int left = min(qv.rows[sg] - lt * kTile, T - t64 * kTile) - BQ * part;
+      d.mp = m_minpos[t64];
+      d.mx = m_max[t64];
+      d.mn = m_min[t64];
+      d.valid = left > 0 && tile_may_interact(d.mp, d.mx, bminpos, bmax);
+      d.qsb = t64 * kTile + BQ * part;
+      d.lrow = qv.row0[sg] + lt * kTile + BQ * part;
       d.left = min(left, BQ);
-      d.h = hk * G + sc_g;
-      d.mp = st.x;
-      d.mx = st.y;
-      d.mn = st.z;
-      break;
+      d.h = hk * G + g;
     }
+    const int wv = tid >> 6;
+    const unsigned long long bal = __ballot(d.valid != 0);
+    if (lane == 0) wcount[wv] = __popcll(bal);
+    __syncthreads();
+    int before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const int cnt = wcount[w];
+      before += w < wv ? cnt : 0;
+      total += cnt;
+    }
+    if (d.valid) {
+      const int e = before + __popcll(bal & ((1ull << lane) - 1ull));
+      slist[2 * e] = i32x4_t{d.qsb, d.lrow, d.left, d.h};
+      slist[2 * e + 1] = i32x4_t{d.mp, d.mx, d.mn, 1};
+    }
+    const int n = __builtin_amdgcn_readfirstlane(total);
+    if (tid < NST) {                    // what the ring reads past the end: stages that load nothing
+      slist[2 * (n + tid)] = i32x4_t{0, 0, 0, 0};
+      slist[2 * (n + tid) + 1] = i32x4_t{0, 0, 0, 0};
+    }
+    __syncthreads();
+    return n;
+  };
+  auto entry = [&](int e) {
+    const int4 a = scalarize(slist[2 * e]), c = scalarize(slist[2 * e + 1]);
+    QStage d = {c.w, a.x, a.y, a.z, a.w, c.z, c.y, c.x};
     return d;
   };
 
@@ -264,17 +266,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(
   const PTrReader<BQ, D> trd(lane);
   const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
-  // ring[0] = the stage being computed, ring[1 .. NST - 2] = the stages in flight behind it
-  QStage ring[NST - 1];
-#pragma unroll
-  for (int i = 0; i < NST - 1; ++i) {
-    ring[i] = next();
-    issue(ring[i], i);
-  }
   int slot = 0;
-  while (ring[0].valid) {
+  for (int cb = 0; cb < total_c; cb += LCAP) {
+   const int n = build_list(cb);
+   // ring[0] = the stage being computed, ring[1 .. NST - 2] = the stages in flight behind it
+   QStage ring[NST - 1];
+#pragma unroll
+   for (int i = 0; i < NST - 1; ++i) {
+     ring[i] = entry(i);
+     issue(ring[i], (slot + i) % NST);
+   }
+   for (int it = 0; it < n; ++it) {
     const QStage cur = ring[0];
-    const QStage ahead = next();                 // scalar scan, off the critical path (before the wait)
+    const QStage ahead = entry(it + NST - 1);    // (LDS read, off the critical path: before the wait)
     // my pieces of `cur` have landed (the NST - 2 stages after it may stay in flight) ...
     wait_vmcnt<(NST - 2) * IPS>();
     // ... everybody's have, and everybody has left the previous stage: its slot takes the stage NST - 1 ahead
@@ -367,8 +371,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(
     for (int i = 0; i + 1 < NST - 1; ++i) ring[i] = ring[i + 1];
     ring[NST - 2] = ahead;
     slot = (slot + 1) % NST;
+   }
+   wait_vmcnt<0>();      // (the zero-fill tail DMAs must not land on the next chunk's stages)
+   __syncthreads();
   }
-  wait_vmcnt<0>();      // (the zero-fill tail DMAs)
 
   if (kvalid) {
     const size_t off = (((size_t)b * T + kvrow) * Nkv + hk) * D;
