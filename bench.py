@@ -291,7 +291,13 @@ def main():
     ap.add_argument("--all-rows-lm-head", action="store_true",
                     help="A/B switch: ignore the loader's labelled-row bound and run lm_head + CE on all B*T positions")
     ap.add_argument("--no-gemm-tuning", action="store_true", help="library-default GEMM algorithm selection")
+    ap.add_argument("--linear-gemm", choices=("lib", "own"), default=None,
+                    help="own = the linear layers' forward-layout GEMMs on the hand-written MFMA kernel (csrc/gemm.hip) "
+                         "instead of hipBLASLt (default: TN_LINEAR_GEMM or lib)")
     args = ap.parse_args()
+    if args.linear_gemm:
+        import touchnet_amd.functional as _F
+        _F.LINEAR_GEMM = args.linear_gemm
 
     from touchnet_amd.utils import gemm_tuning
     tuned = (not args.no_gemm_tuning) and gemm_tuning.enable()
@@ -365,7 +371,10 @@ def main():
                        "lm_head_rows": ("labelled only (exact count, host sync)" if args.compact_lm_head else
                                         f"labelled only: static bound {lrm} from the packer, no host sync"
                                         if (lrm is not None and wl.job.training_enable_fused_ce) else "all B*T positions"),
-                       "gemm_algorithms": "TunableOp replay (touchnet_amd/tuning)" if tuned else "library default"},
+                       "gemm_algorithms": "TunableOp replay (touchnet_amd/tuning)" if tuned else "library default",
+                       "linear_layer_gemm": ("hand-written MFMA kernel (csrc/gemm.hip) where its shape constraints hold"
+                                             if __import__("touchnet_amd.functional", fromlist=["x"]).LINEAR_GEMM == "own"
+                                             else "hipBLASLt")},
             "step_mfu": round(mfu, 4),
             "mfu_convention": "6*N_wo_emb + 12*L*H*Dh*T per token (touchnet/models/*/__init__.py), no causal/packing "
                               "discount, no recompute credit, tokens = all B*T slots incl. pad",

@@ -678,6 +678,48 @@ def test_linear_group_matches_autograd(M, K, Ns, bias, wtn):
             torch.testing.assert_close(a.float().cpu(), b, rtol=2e-2, atol=2e-2 * float(b.abs().max()))
 
 
+def test_linear_layers_on_the_hand_written_gemm_match_the_library(monkeypatch):
+    """TN_LINEAR_GEMM=own (`bench.py --linear-gemm own`): every forward-layout product of linear_group and of the fused
+    SwiGLU MLP node runs on csrc/gemm.hip instead of hipBLASLt.  Same bf16 inputs, fp32 accumulation in both: outputs
+    and all gradients agree to bf16 rounding of differently ordered sums, and the kernel really is the one that ran."""
+    F = _f()
+    from touchnet_amd import _C
+    g = torch.Generator(device="cpu").manual_seed(5)
+    M, H, I = 1024, 256, 512
+    x = (torch.randn(2, M // 2, H, generator=g) * 0.5).bfloat16().to(DEV)
+    ws = [(torch.randn(n, k, generator=g) * k ** -0.5).bfloat16().to(DEV) for n, k in ((I, H), (I, H), (H, I))]
+    qkv = [((torch.randn(n, H, generator=g) * H ** -0.5).bfloat16().to(DEV), (torch.randn(n, generator=g) * 0.1).bfloat16().to(DEV))
+           for n in (256, 128, 128)]
+    dy = torch.randn(2, M // 2, H, generator=g).bfloat16().to(DEV)
+    dq = [torch.randn(2, M // 2, n, generator=g).bfloat16().to(DEV) for n in (256, 128, 128)]
+
+    def run(mode):
+        monkeypatch.setattr(F, "LINEAR_GEMM", mode)
+        calls = []
+        real = _C.lib().tn_gemm_bf16_tn
+        if mode == "own":
+            monkeypatch.setattr(F, "gemm_tn", lambda *a, **k: (calls.append(1), _orig(*a, **k))[1])
+        xx = x.clone().requires_grad_()
+        ww = [w.clone().requires_grad_() for w in ws]
+        y = F.swiglu_mlp(xx, *ww)
+        y.backward(dy)
+        x2 = x.clone().requires_grad_()
+        lw = [(w.clone().requires_grad_(), b.clone().requires_grad_()) for w, b in qkv]
+        outs = F.linear_group(x2, lw)
+        torch.autograd.backward(outs, dq)
+        res = [y, xx.grad] + [w.grad for w in ww] + list(outs) + [x2.grad] + [w.grad for w, _ in lw] + [b.grad for _, b in lw]
+        del real
+        return [r.float() for r in res], len(calls)
+
+    _orig = F.gemm_tn
+    lib, n_lib = run("lib")
+    own, n_own = run("own")
+    assert n_lib == 0 and n_own == 3 + 1 + 1 + 2 + 1 + 3 + 3 + 1, n_own      # MLP: 3 fwd, dWd, dact, dx(2), dWgu; group: 3 fwd, 3 dx, dW
+    for i, (a, b) in enumerate(zip(own, lib)):
+        scale = float(b.abs().max())
+        assert float((a - b).abs().max()) <= 1.6e-2 * scale + 1e-6, (i, float((a - b).abs().max()), scale)
+
+
 # ------------------------------------------------------------------------------------ BEST-RQ tokenizer (§8f-4)
 @pytest.mark.parametrize("case", ["recipe", "default", "small"])
 def test_bestrq_tokenize_matches_reference_codes(golden, case):

@@ -318,6 +318,31 @@ def _tn_ok(M: int, K: int, Ns) -> bool:
     return M % 8 == 0 and K % 8 == 0 and all(n % 8 == 0 for n in Ns)
 
 
+# Which GEMM runs the forward-layout products of the linear layers below: "lib" (default) = hipBLASLt through torch,
+# "own" = the hand-written MFMA kernel of csrc/gemm.hip wherever its shape constraints hold (TN_LINEAR_GEMM=own or
+# `bench.py --linear-gemm own`).  The library stays the default because it is 10-20 % faster on the step's shapes
+# (profiles/r02_gemm_own_vs_hipblaslt.md); the switch exists so that the WHOLE step can be measured on hand-written
+# GEMMs and so that parity of the two is tested at model level (tests/test_models_gpu.py).
+LINEAR_GEMM = os.environ.get("TN_LINEAR_GEMM", "lib")
+
+
+def _mm_tn(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+           accumulate: bool = False) -> torch.Tensor:
+    """``a @ b.T (+ bias)`` (``out += ...`` if accumulate) for contraction-contiguous a [M, K], b [N, K]."""
+    M, K = a.shape
+    N = b.shape[0]
+    own = (LINEAR_GEMM == "own" and a.is_cuda and a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16
+           and a.stride(1) == 1 and b.stride(1) == 1 and gemm_tn_supported(M, N, K)
+           and (bias is None or bias.dtype == torch.bfloat16))
+    if own:
+        return gemm_tn(a, b, bias=bias, out=out, accumulate=accumulate)
+    if accumulate:
+        return out.addmm_(a, b.t())
+    if out is not None:
+        return torch.mm(a, b.t(), out=out) if bias is None else torch.addmm(bias, a, b.t(), out=out)
+    return torch.nn.functional.linear(a, b, bias)
+
+
 class _LinearGroup(torch.autograd.Function):
     """``y_i = x W_i^T + b_i`` for a group of linear layers that share their input (q/k/v, gate/up, or one layer).
 
@@ -340,6 +365,9 @@ class _LinearGroup(torch.autograd.Function):
         ctx.save_for_backward(x, *ws)
         ctx.has_bias = [b is not None for b in bs]
         ctx.wgrad, ctx.dgrad_tn = wgrad, dgrad_tn
+        if LINEAR_GEMM == "own" and x.is_cuda:
+            x2 = _c(x.reshape(-1, x.shape[-1]))
+            return tuple(_mm_tn(x2, _c(w), b).view(*x.shape[:-1], w.shape[0]) for w, b in zip(ws, bs))
         return tuple(torch.nn.functional.linear(x, w, b) for w, b in zip(ws, bs))
 
     @staticmethod
@@ -356,12 +384,17 @@ class _LinearGroup(torch.autograd.Function):
         hip_ok = x.dtype == torch.bfloat16 and (x.is_cuda or x.is_meta) and _tn_ok(M, K, Ns)
         dx = None
         if need_x:
-            wv = [transpose_2d(_c(w)).t() for w in ws] if (hip_ok and ctx.dgrad_tn) else ws   # [N, K] views of W^T
-            dx = torch.mm(dys[0], wv[0])
-            for d, w in zip(dys[1:], wv[1:]):
-                dx.addmm_(d, w)
+            if hip_ok and ctx.dgrad_tn:
+                wts = [transpose_2d(_c(w)) for w in ws]                                # W^T [K, N]: forward layout
+                dx = _mm_tn(dys[0], wts[0])
+                for d, wt in zip(dys[1:], wts[1:]):
+                    _mm_tn(d, wt, out=dx, accumulate=True)
+                del wts
+            else:
+                dx = torch.mm(dys[0], ws[0])
+                for d, w in zip(dys[1:], ws[1:]):
+                    dx.addmm_(d, w)
             dx = dx.view(x.shape)
-            del wv
         dws = [None] * n
         if any(need_w):
             if ctx.wgrad == "nt_fused" and n > 1:
@@ -373,7 +406,7 @@ class _LinearGroup(torch.autograd.Function):
                 for d, N in zip(dys, Ns):
                     transpose_2d(d, out=dyt[o:o + N])
                     o += N
-                dw = torch.mm(dyt, xt.t())                                         # TN: both contraction-contiguous
+                dw = _mm_tn(dyt, xt)                                               # TN: both contraction-contiguous
                 dws = list(torch.split(dw, Ns, dim=0))
             else:
                 dws = [torch.mm(d.t(), x2) for d in dys]
@@ -408,9 +441,9 @@ class _SwiGLUMLP(torch.autograd.Function):
         K, I = x.shape[-1], wg.shape[0]
         x2 = _c(x.reshape(-1, K))
         M = x2.shape[0]
-        gate, up = torch.mm(x2, wg.t()), torch.mm(x2, wu.t())
+        gate, up = _mm_tn(x2, _c(wg)), _mm_tn(x2, _c(wu))
         act, act_t = L.swiglu_fwd_t(gate, up)
-        y = torch.mm(act, wd.t())
+        y = _mm_tn(act, _c(wd))
         ctx.save_for_backward(x2, gate, up, act_t, wg, wu, wd)
         ctx.xshape = x.shape
         return y.view(*x.shape[:-1], wd.shape[0])
@@ -422,18 +455,18 @@ class _SwiGLUMLP(torch.autograd.Function):
         I, H = wg.shape[0], wd.shape[0]
         dy2 = _c(dy).reshape(M, H)
         nx, ng, nu, nd = ctx.needs_input_grad
-        dwd = torch.mm(transpose_2d(dy2), act_t.t()) if nd else None               # [H, I], forward layout
-        dact = torch.mm(dy2, transpose_2d(_c(wd)).t())                              # [M, I]
+        dwd = _mm_tn(transpose_2d(dy2), act_t) if nd else None                      # [H, I], forward layout
+        dact = _mm_tn(dy2, transpose_2d(_c(wd)))                                    # [M, I]
         dgate, dup, dgu_t = L.swiglu_bwd_t(dact, gate, up)
         del dact
         dx = None
         if nx:
-            dx = torch.mm(dgate, transpose_2d(_c(wg)).t())
-            dx.addmm_(dup, transpose_2d(_c(wu)).t())
+            dx = _mm_tn(dgate, transpose_2d(_c(wg)))
+            _mm_tn(dup, transpose_2d(_c(wu)), out=dx, accumulate=True)
             dx = dx.view(ctx.xshape)
         dwg = dwu = None
         if ng or nu:
-            dwg, dwu = torch.split(torch.mm(dgu_t, transpose_2d(x2).t()), [I, I], dim=0)
+            dwg, dwu = torch.split(_mm_tn(dgu_t, transpose_2d(x2)), [I, I], dim=0)
         return dx, dwg if ng else None, dwu if nu else None, dwd
 
 
