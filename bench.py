@@ -12,6 +12,9 @@ buffers) are resident in HBM before it starts.
 
 Workloads (BASELINE.json `configs`):
     qwen2_audio_7b  (default) Qwen2-Audio-7B ASR SFT, packed B=2 x T=8192 per GPU   <- the metric's config
+    qwen2_audio_7b_short      same model and packing, utterances of U[2, 14.5] s whose AUDIO-token count follows the valid
+                              length like in the reference's processor (64 clips per GPU instead of 20): shows the audio
+                              tower running on the kept frames only (TN_TOWER_VALID_FRAMES=0: the reference's schedule)
     llama_asr_1b              LlamaForASR-1B, fbank-80 stack5/stride4, packed B=1 x T=8192
     tiny                      2-layer d=256 smoke configuration
 Weights are random-init (HF init, seed 2025), data is synthetic: there is no network for checkpoints/datasets.
@@ -81,25 +84,33 @@ class Workload:
         self.name, self.device, self.F = name, device, F
         seed = 2025 + rank
         self.job = TrainConfig()
-        if name == "qwen2_audio_7b":
+        if name in ("qwen2_audio_7b", "qwen2_audio_7b_short"):
+            short = name.endswith("_short")
             self.B, self.T = B or 2, T or 8192
             self.job.training_model_name = "qwen2_audio_mi355"
             self.job.lr_scheduler_lr = 2e-5
             self.model_config = qwen2_audio_7b_config()
             self.seq_cfg = self.model_config.text_config
             tok, n_audio = synthetic.qwen2_audio_plan(self.seq_cfg.vocab_size, self.model_config.audio_token_index,
-                                                      self.B, self.T, seed)
+                                                      self.B, self.T, seed, audio_seconds=(2.0, 14.5) if short else None)
             g = torch.Generator().manual_seed(seed)
             # 30 s-padded utterances (WhisperFeatureExtractor padding="max_length"): speech-shaped noise for
             # U[2, 14.5] s, zeros to 30 s.  The frontend runs on all 480 000 samples, like the reference.
+            # qwen2_audio_7b (the metric's workload): every clip fills its 750 AUDIO tokens;  qwen2_audio_7b_short: the
+            # token count follows the valid length like in the reference's processor (WenetSpeech-length utterances).
             wav = torch.zeros(n_audio, 480000)
             for i in range(n_audio):
-                n = int(float(torch.empty(1).uniform_(2.0, 14.5, generator=g)) * 16000)
+                n = (tok["audio_samples"][i] if short
+                     else int(float(torch.empty(1).uniform_(2.0, 14.5, generator=g)) * 16000))
                 wav[i, :n] = (torch.randn(n, generator=g) * 0.1).clamp_(-1, 1)
             self.wav = wav.to(device)
-            self.tokens = {k: (v.to(device) if isinstance(v, torch.Tensor) else v) for k, v in tok.items()}
-            self.data_desc = (f"synthetic: {n_audio} x 30 s-padded 16 kHz clips/GPU -> 750 audio tokens each, "
-                              f"~14-token prompt, U{{5..40}}-token transcripts, packed B={self.B} x T={self.T}")
+            self.tokens = {k: (v.to(device) if isinstance(v, torch.Tensor) else v) for k, v in tok.items()
+                           if k != "audio_samples"}
+            n_tok = int(tok["audio_positions"].numel())
+            self.data_desc = (f"synthetic: {n_audio} x 30 s-padded 16 kHz clips/GPU -> "
+                              + (f"{n_tok} audio tokens in all (U[2, 14.5] s utterances, token count from the valid length)"
+                                 if short else "750 audio tokens each")
+                              + f", ~14-token prompt, U{{5..40}}-token transcripts, packed B={self.B} x T={self.T}")
         elif name in ("llama_asr_1b", "tiny"):
             text = llama_1b_text_config() if name == "llama_asr_1b" else tiny_text_config()
             self.B, self.T = B or 1, T or (8192 if name == "llama_asr_1b" else 512)
@@ -118,7 +129,7 @@ class Workload:
     def make_batch(self):
         """Runs the device frontend and returns the batch dict (everything already on the device)."""
         F = self.F
-        if self.name == "qwen2_audio_7b":
+        if self.name.startswith("qwen2_audio_7b"):
             mel = torch.stack([F.log_mel_spectrogram(w, 128) for w in self.wav])       # [n, 3000, 128]
             batch = dict(self.tokens)
             batch["input_features"] = mel.transpose(1, 2)                              # [n, 128, 3000]
@@ -401,7 +412,7 @@ def main():
                 c = wl.seq_cfg
                 dec_attn = 3.5 * 4.0 * c.head_dim * c.num_attention_heads * allowed_pairs * c.num_hidden_layers
                 executed = (fpt - 12 * c.num_hidden_layers * c.num_attention_heads * c.head_dim * wl.T) * wl.B * wl.T + dec_attn
-                if wl.name == "qwen2_audio_7b":
+                if wl.name == "qwen2_audio_7b":        # (the short-utterance workload reports the formula MFU only)
                     ac = wl.model_config.audio_config
                     tower_params = sum(p.numel() for p in trainer.model.audio_tower.parameters())
                     frames = wl.wav.shape[0] * 1500

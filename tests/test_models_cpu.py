@@ -74,6 +74,33 @@ def test_qwen2_audio_tower_matches_reference(golden):
     np.testing.assert_allclose(out.numpy(), g["out"], atol=2e-5)
 
 
+def test_qwen2_audio_tower_on_kept_frames_only_equals_the_padded_schedule(golden):
+    """forward_valid (the encoder layers on frames [0, 2 len_i) of every clip, packed with one document id per clip)
+    must return exactly the rows the reference's schedule keeps: the padded forward (checked against the reference
+    above) followed by `:202-205`'s compaction.  Exact because the tower's attention is forced causal."""
+    g = golden("qwen2_audio_tower.npz")
+    tower = Qwen2AudioEncoder(AudioEncoderConfig(num_mel_bins=8, d_model=32, encoder_layers=2,
+                                                 encoder_attention_heads=4, encoder_ffn_dim=64,
+                                                 max_source_positions=10))
+    sd = {k[len("param/"):]: torch.tensor(g[k]) for k in g.files if k.startswith("param/")}
+    sd["embed_positions.weight"] = torch.tensor(g["embed_positions"])
+    tower.load_state_dict(sd, strict=True)
+    mel = torch.tensor(g["mel"])
+    gen = torch.Generator().manual_seed(3)
+    mel = torch.cat([mel, torch.randn(3, *mel.shape[1:], generator=gen)])       # more clips than the golden has
+    with use_ops(oops), torch.no_grad():
+        full = tower(mel)                                                       # [n, Ta, C]
+        n, Ta, _ = full.shape
+        for lens in ([Ta] * n, [max(Ta - 1 - i, 0) for i in range(n)], [1] + [0] * (n - 2) + [Ta]):
+            lens_t = torch.tensor(lens)
+            if int(lens_t.sum()) == 0:
+                continue
+            got = tower.forward_valid(mel, lens_t, int(lens_t.sum()))
+            want = torch.cat([full[i, :l] for i, l in enumerate(lens)])
+            assert got.shape == want.shape
+            np.testing.assert_allclose(got.numpy(), want.numpy(), atol=2e-6)
+
+
 def test_meta_device_construction_and_counts():
     cfg = DecoderConfig.from_dict(TINY)
     with torch.device("meta"):

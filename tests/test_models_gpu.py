@@ -192,7 +192,11 @@ def test_fused_adamw_multi_tensor_mixed_shapes():
                 assert torch.equal(p.data, st["master"].bfloat16())    # the shadow the next forward reads
 
 
-def test_qwen2_audio_packed_forward_backward_small():
+@pytest.mark.parametrize("lens", [(40, 40, 40), (40, 17, 28)])
+def test_qwen2_audio_packed_forward_backward_small(lens):
+    """lens = audio tokens per clip.  (40, 40, 40): every frame of the padded clips reaches the decoder, the tower runs per
+    clip.  (40, 17, 28): clips shorter than their padding — the product tower runs on the kept frames only, packed
+    (Qwen2AudioEncoder.forward_valid), while the oracle follows the reference: all frames, then `:202-205`'s compaction."""
     import touchnet_amd.specs  # noqa: F401
     from touchnet_amd.bin.train import TrainConfig, Trainer
     from touchnet_amd.models.qwen2_audio import Qwen2AudioConfig, Qwen2AudioPackedForConditionalGeneration
@@ -213,20 +217,28 @@ def test_qwen2_audio_packed_forward_backward_small():
     spans = [(0, 0, 60), (0, 60, 120), (1, 0, 70)]
     apos = []
     for d, (b, s, e) in enumerate(spans):
-        ids[b, s + 4:s + 44] = 500
-        apos.append(b * T + s + 4 + torch.arange(40))
+        ids[b, s + 4:s + 4 + lens[d]] = 500
+        apos.append(b * T + s + 4 + torch.arange(lens[d]))
         doc[b, s:e] = (d % 2) + 1 if b == 0 else 1
         pos[b, s:e] = torch.arange(e - s)
         labels[b, s + 50:e] = ids[b, s + 50:e].roll(-1)
         sl[b, s:e] = e - s - 50
     batch = {"input_ids": ids, "labels": labels, "position_ids": pos, "attention_mask": doc, "sentence_lens": sl,
              "num_sentence": 3, "input_features": torch.randn(n_audio, 16, Tm, generator=g),
-             "audio_positions": torch.cat(apos), "audio_output_lengths": torch.full((n_audio,), 40)}
+             "audio_positions": torch.cat(apos), "audio_output_lengths": torch.tensor(lens)}
     cpu_batch = dict(batch)
     cpu_batch["input_features"] = batch["input_features"].bfloat16().float()
-    fwd = lambda m, b: m(input_ids=b["input_ids"], input_features=b["input_features"],
-                         audio_output_lengths=b["audio_output_lengths"], audio_positions=b["audio_positions"],
-                         position_ids=b["position_ids"], attention_mask=b["attention_mask"])
+    import touchnet_amd.models.qwen2_audio.modeling_qwen2_audio as mq
+
+    def fwd(m, b):        # (the ORACLE side only: the reference's schedule — every padded frame through the tower)
+        old, mq.TOWER_VALID_FRAMES_ONLY = mq.TOWER_VALID_FRAMES_ONLY, False
+        try:
+            return m(input_ids=b["input_ids"], input_features=b["input_features"],
+                     audio_output_lengths=b["audio_output_lengths"], audio_positions=b["audio_positions"],
+                     position_ids=b["position_ids"], attention_mask=b["attention_mask"])
+        finally:
+            mq.TOWER_VALID_FRAMES_ONLY = old
+    assert mq.TOWER_VALID_FRAMES_ONLY
     # logits on valid rows + EVERY gradient (tower conv stem, encoder layers, projector, decoder) vs the oracle
     _device_vs_oracle(tr, Qwen2AudioPackedForConditionalGeneration, cfg, fwd, batch, cpu_batch)
 

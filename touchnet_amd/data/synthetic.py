@@ -73,14 +73,25 @@ def asr_batch_from_device_frontend(vocab: int, batchsize: int, seqlen: int, devi
     return batch, wavs, utts
 
 
+def qwen2_audio_tokens_of(n_samples: int) -> int:
+    """AUDIO placeholder tokens of an utterance of n_samples at 16 kHz (touchnet/models/qwen2_audio/
+    processing_qwen2_audio.py:78-82: valid mel frames of WhisperFeatureExtractor's mask -> conv stride 2 -> pool 2)."""
+    mel = min(-(-n_samples // 160), 3000)
+    inp = (mel - 1) // 2 + 1
+    return (inp - 2) // 2 + 1
+
+
 def qwen2_audio_plan(vocab: int, audio_token: int, batchsize: int, seqlen: int, seed: int = 2025,
                      audio_tokens: int = 750, prompt_pre: int = 8, prompt_post: int = 6, min_resp: int = 5,
-                     max_resp: int = 40):
+                     max_resp: int = 40, audio_seconds=None):
     """Config C (Qwen2-Audio-7B ASR SFT, packed — beyond what the reference can run):
     per sample a 30 s-padded utterance -> 750 AUDIO placeholder tokens inside a ~14-token prompt, then a
     response of U{5..40} tokens + eos.  Labels follow processing_qwen2_audio.py:96-104: -100 on the prompt
     (pre-shifted), response + eos after it; sentence_lens = len(response) + 1 over the whole sample.
     Samples are packed greedily into [B, T] with document ids and per-sample position ids.
+    ``audio_seconds=(lo, hi)``: utterances of U[lo, hi] seconds instead — the number of AUDIO tokens then follows the
+    valid length like in the reference's processor (a 30 s-padded clip of 8 s gives 200 tokens, not 750) and the
+    result carries ``audio_samples`` (valid samples per clip).
     Returns the int64 batch tensors + the number of audio clips (their waveforms are made by the caller)."""
     rng = np.random.RandomState(seed)
     B, T = batchsize, seqlen
@@ -90,10 +101,17 @@ def qwen2_audio_plan(vocab: int, audio_token: int, batchsize: int, seqlen: int, 
     doc = np.zeros((B, T), dtype=np.int64)
     sentence_lens = np.ones((B, T), dtype=np.int64)
     audio_pos, n_sent, n_lab = [], 0, 0
+    fixed_tokens, lengths, samples = audio_tokens, [], []
     for b in range(B):
         col, d = 0, 1
         while True:
             nresp = int(rng.randint(min_resp, max_resp + 1))
+            n_samp = 480000
+            if audio_seconds is not None:
+                n_samp = int(rng.uniform(*audio_seconds) * 16000)
+                audio_tokens = qwen2_audio_tokens_of(n_samp)
+            else:
+                audio_tokens = fixed_tokens
             plen = prompt_pre + audio_tokens + prompt_post
             tot = plen + nresp
             if col + tot > T:
@@ -109,6 +127,8 @@ def qwen2_audio_plan(vocab: int, audio_token: int, batchsize: int, seqlen: int, 
             doc[b, col:col + tot] = d
             sentence_lens[b, col:col + tot] = nresp + 1
             audio_pos.append(b * T + col + prompt_pre + np.arange(audio_tokens))
+            lengths.append(audio_tokens)
+            samples.append(n_samp)
             col += tot
             d += 1
             n_sent += 1
@@ -117,5 +137,5 @@ def qwen2_audio_plan(vocab: int, audio_token: int, batchsize: int, seqlen: int, 
     return {"input_ids": t(input_ids), "labels": t(labels), "position_ids": t(position_ids),
             "attention_mask": t(doc), "sentence_lens": t(sentence_lens), "num_sentence": n_sent,
             "audio_positions": t(np.concatenate(audio_pos)),
-            "audio_output_lengths": torch.full((n_sent,), audio_tokens, dtype=torch.int64),
-            "labelled_rows_max": n_lab}, n_sent
+            "audio_output_lengths": torch.tensor(lengths, dtype=torch.int64),
+            "audio_samples": samples, "labelled_rows_max": n_lab}, n_sent
