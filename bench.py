@@ -382,6 +382,10 @@ def main():
                        "lm_head_rows": ("labelled only (exact count, host sync)" if args.compact_lm_head else
                                         f"labelled only: static bound {lrm} from the packer, no host sync"
                                         if (lrm is not None and wl.job.training_enable_fused_ce) else "all B*T positions"),
+                       "last_layer_rows": ("labelled only behind the attention core (o_proj, MLP, norms)"
+                                           if (lrm is not None and wl.job.training_enable_fused_ce
+                                               and __import__("touchnet_amd.models.llama.modeling_llama", fromlist=["x"]).LAST_LAYER_LABELLED_ROWS)
+                                           else "all B*T positions"),
                        "gemm_algorithms": "TunableOp replay (touchnet_amd/tuning)" if tuned else "library default",
                        "linear_layer_gemm": ("hand-written MFMA kernel (csrc/gemm.hip) where its shape constraints hold"
                                              if __import__("touchnet_amd.functional", fromlist=["x"]).LINEAR_GEMM == "own"
@@ -421,6 +425,11 @@ def main():
                 if lrm is not None and wl.job.training_enable_fused_ce and not c.tie_word_embeddings:
                     rows = min(wl.B * wl.T, (int(lrm) + 255) // 256 * 256)           # lm_head + CE run on these rows only
                     executed -= 6.0 * c.vocab_size * c.hidden_size * (wl.B * wl.T - rows)
+                    import touchnet_amd.models.llama.modeling_llama as _ml
+                    if _ml.LAST_LAYER_LABELLED_ROWS and 2 * rows <= wl.B * wl.T:
+                        # ... and so does everything behind the LAST layer's attention core (o_proj + MLP)
+                        executed -= 6.0 * (c.hidden_size * c.num_attention_heads * c.head_dim
+                                           + 3 * c.hidden_size * c.intermediate_size) * (wl.B * wl.T - rows)
                 line["step_mfu_executed_flops"] = round(executed / (step_ms * 1e-3) / MFMA_PEAK, 4)
                 line["executed_flops_note"] = ("GEMM terms of the formula (6*N_wo_emb per token; tower on its 1500 frames "
                                                "per clip; an untied lm_head only on the rows it runs on) + attention on "

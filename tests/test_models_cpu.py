@@ -101,6 +101,62 @@ def test_qwen2_audio_tower_on_kept_frames_only_equals_the_padded_schedule(golden
             np.testing.assert_allclose(got.numpy(), want.numpy(), atol=2e-6)
 
 
+@pytest.mark.parametrize("bound,T", [(40, 288), (7, 300)])
+def test_last_layer_on_the_labelled_rows_only_is_the_same_training_step(monkeypatch, bound, T):
+    """With `labelled_rows_max` the rows that carry a label are selected in front of the LAST layer's output projection
+    (o_proj, residual, norm, MLP, final norm and lm_head then see those rows only).  Loss, accuracy and EVERY gradient
+    must equal the full computation (fp32 oracle ops); a bound whose 256-rounding is below the real count (T = 300: 300
+    labelled rows, bound 7 -> 256) must poison the loss with NaN instead of dropping labels."""
+    import touchnet_amd.models.llama.modeling_llama as ml
+    torch.manual_seed(0)
+    cfg = DecoderConfig.from_dict(dict(TINY, num_hidden_layers=3))
+    model = PackedCausalLM(cfg)
+    model.post_init()
+    B = 2
+    g = torch.Generator().manual_seed(1)
+    ids = torch.randint(1, 16, (B, T), generator=g)
+    doc = torch.ones(B, T, dtype=torch.int64)
+    doc[0, 20:] = 2
+    doc[1, 40:] = 0
+    pos = torch.arange(T).expand(B, T).clone()
+    labels = torch.full((B, T), -100)
+    sl = torch.ones(B, T, dtype=torch.int64)
+    spans = ((0, 12, 20), (0, 39, 48), (1, 30, 36)) if T == 288 else ((0, 21, 171), (1, 0, 150))
+    for b, s, e in spans:
+        labels[b, s:e] = torch.randint(1, 16, (e - s,), generator=g)
+        sl[b, s:e] = e - s
+    n_lab = int((labels != -100).sum())
+    assert n_lab == (23 if T == 288 else 300)
+    kw = dict(input_ids=ids, position_ids=pos, attention_mask=doc, labels=labels, sentence_lens=sl, num_sentence=3)
+
+    taken = []
+    inner = PackedCausalLM._forward_labelled_rows
+    monkeypatch.setattr(PackedCausalLM, "_forward_labelled_rows", lambda self, *a, **k: (taken.append(1), inner(self, *a, **k))[1])
+
+    def run(flag):
+        monkeypatch.setattr(ml, "LAST_LAYER_LABELLED_ROWS", flag)
+        model.zero_grad()
+        with use_ops(oops):
+            out = model(**kw, labelled_rows_max=bound)
+            if torch.isfinite(out.loss):
+                out.loss.backward()
+        return out, {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    full, gfull = run(False)
+    assert not taken
+    rows, grows = run(True)
+    assert len(taken) == 1
+    if (bound + 255) // 256 * 256 < n_lab:
+        assert torch.isnan(rows.loss) and torch.isnan(rows.loss_per_token)
+        return                      # (the oracle's fused CE computes every row: no bound, nothing to poison)
+    assert float(rows.loss) == pytest.approx(float(full.loss), rel=1e-6)
+    assert float(rows.loss_per_token) == pytest.approx(float(full.loss_per_token), rel=1e-6)
+    assert float(rows.acc) == float(full.acc)
+    assert gfull.keys() == grows.keys() and len(gfull) > 20
+    for n in gfull:
+        torch.testing.assert_close(grows[n], gfull[n], rtol=1e-5, atol=1e-7, msg=lambda m: f"{n}: {m}")
+
+
 def test_meta_device_construction_and_counts():
     cfg = DecoderConfig.from_dict(TINY)
     with torch.device("meta"):

@@ -243,6 +243,47 @@ def test_qwen2_audio_packed_forward_backward_small(lens):
     _device_vs_oracle(tr, Qwen2AudioPackedForConditionalGeneration, cfg, fwd, batch, cpu_batch)
 
 
+def test_last_layer_on_labelled_rows_only_matches_full_rows_on_device(monkeypatch):
+    """PackedCausalLM with the packers' `labelled_rows_max`: selecting the labelled rows in front of the last layer's
+    output projection (default) vs in front of lm_head only (TN_LAST_LAYER_LABELLED_ROWS=0) — same loss, accuracy and
+    gradients up to bf16 GEMM summation order (the CPU test holds them equal to 1e-6 in fp32)."""
+    import touchnet_amd.models.llama.modeling_llama as ml
+    from touchnet_amd.models.llama import DecoderConfig, PackedCausalLM
+    torch.manual_seed(0)
+    cfg = DecoderConfig.from_dict(dict(TEXT, num_hidden_layers=3, tie_word_embeddings=False))
+    model = PackedCausalLM(cfg)
+    model.post_init()
+    model = model.to(DEV, torch.bfloat16)
+    B, T = 2, 1024
+    g = torch.Generator().manual_seed(1)
+    ids = torch.randint(1, 500, (B, T), generator=g)
+    doc = torch.ones(B, T, dtype=torch.int64)
+    doc[0, 500:] = 2
+    pos = torch.arange(T).expand(B, T).clone()
+    labels = torch.full((B, T), -100)
+    sl = torch.ones(B, T, dtype=torch.int64)
+    for b, s, e in ((0, 470, 500), (0, 990, 1024), (1, 1000, 1024)):
+        labels[b, s:e] = torch.randint(1, 500, (e - s,), generator=g)
+        sl[b, s:e] = e - s
+    kw = {k: v.to(DEV) for k, v in dict(input_ids=ids, position_ids=pos, attention_mask=doc, labels=labels,
+                                        sentence_lens=sl).items()}
+
+    def run(flag):
+        monkeypatch.setattr(ml, "LAST_LAYER_LABELLED_ROWS", flag)
+        model.zero_grad()
+        out = model(**kw, num_sentence=3, labelled_rows_max=int((labels != -100).sum()))
+        out.loss.backward()
+        return out, {n: p.grad.float().clone() for n, p in model.named_parameters()}
+
+    full, gfull = run(False)
+    rows, grows = run(True)
+    assert abs(float(rows.loss) - float(full.loss)) / abs(float(full.loss)) < 2e-3
+    assert float(rows.acc) == pytest.approx(float(full.acc), abs=1e-6)
+    for n in gfull:
+        scale = float(gfull[n].abs().max().clamp_min(1e-6))
+        assert float((grows[n] - gfull[n]).abs().max()) / scale < 4e-2, n
+
+
 def test_fsdp2_single_rank_rccl_matches_unsharded():
     """The FSDP2 path on real hardware: a 1-rank RCCL mesh (TN_FORCE_FSDP=1) must train like the unsharded model —
     fully_shard hooks around the HIP autograd functions, DTensor parameters, the fused AdamW on local shards.

@@ -14,6 +14,7 @@ The arithmetic follows transformers/models/llama/modeling_llama.py:53-67,113-160
 """
 from __future__ import annotations
 
+import os
 from types import SimpleNamespace
 from typing import Optional
 
@@ -60,7 +61,9 @@ class Attention(nn.Module):
         self.o_proj = nn.Linear(self.num_heads * D, H, bias=False)
         self.scaling = D ** -0.5
 
-    def forward(self, x, cos, sin, mask):
+    def forward(self, x, cos, sin, mask, keep_rows=None):
+        """`keep_rows` (flat indices into B*T, last decoder layer only): the output projection runs on those rows only and
+        the result is [1, len(keep_rows), H] — see DecoderModel.forward."""
         B, T, _ = x.shape
         cp = getattr(mask, "cp", None)
         if cp is not None and cp.need is not None:
@@ -78,7 +81,10 @@ class Attention(nn.Module):
                                                self.scaling)
         else:
             a = ops().packed_attention(q, k, v, mask, self.scaling)
-        return ops().linear_group(a.view(B, T, self.num_heads * self.head_dim), [(self.o_proj.weight, None)])[0]
+        a = a.view(B, T, self.num_heads * self.head_dim)
+        if keep_rows is not None:
+            a = a.reshape(B * T, -1).index_select(0, keep_rows)[None]
+        return ops().linear_group(a, [(self.o_proj.weight, None)])[0]
 
 
     def _forward_context_parallel(self, x, cos, sin, mask, cp):
@@ -97,6 +103,11 @@ class Attention(nn.Module):
         k_full, v_full = finish()
         a = ops().packed_attention_sharded(q, k_full, v_full, mask, cp.seq_shard(), self.scaling)
         return ops().linear_group(a.view(B, T, self.num_heads * self.head_dim), [(self.o_proj.weight, None)])[0]
+
+
+# TN_LAST_LAYER_LABELLED_ROWS=0: select the labelled rows in front of lm_head only (the round-2a behaviour), not in front
+# of the last layer's output projection.
+LAST_LAYER_LABELLED_ROWS = os.environ.get("TN_LAST_LAYER_LABELLED_ROWS", "1") != "0"
 
 
 class MLP(nn.Module):
@@ -120,14 +131,17 @@ class DecoderLayer(nn.Module):
         self.input_layernorm = RMSNorm(config.hidden_size, config.rms_norm_eps)
         self.post_attention_layernorm = RMSNorm(config.hidden_size, config.rms_norm_eps)
 
-    def forward(self, delta, residual, cos, sin, mask):
-        """`delta` is the previous sub-layer's output still to be added to the `residual` stream."""
+    def forward(self, delta, residual, cos, sin, mask, keep_rows=None):
+        """`delta` is the previous sub-layer's output still to be added to the `residual` stream.
+        `keep_rows`: everything behind the attention core (o_proj, residual, norm, MLP) runs on those rows only."""
         if residual is None:
             residual = delta
             x = self.input_layernorm(delta)
         else:
             x, residual = self.input_layernorm(delta, residual)
-        a = self.self_attn(x, cos, sin, mask)
+        a = self.self_attn(x, cos, sin, mask, keep_rows)
+        if keep_rows is not None:
+            residual = residual.reshape(-1, residual.shape[-1]).index_select(0, keep_rows)[None]
         x, residual = self.post_attention_layernorm(a, residual)
         return self.mlp(x), residual
 
@@ -142,10 +156,17 @@ class DecoderModel(nn.Module):
         self.rotary_emb = RotaryEmbedding(config)
 
     def forward(self, input_ids=None, inputs_embeds=None, position_ids=None, attention_mask=None,
-                context_parallel=None):
+                context_parallel=None, keep_rows=None):
         """With `context_parallel` (utils.context_parallel.ContextParallel): input_ids / inputs_embeds /
         position_ids are this rank's sequence shard [B, T/cp], `attention_mask` stays the GLOBAL [B, T]
-        document-id tensor (it is tiny and every rank needs the tile metadata of the keys it attends to)."""
+        document-id tensor (it is tiny and every rank needs the tile metadata of the keys it attends to).
+
+        `keep_rows` (int64 [R], flat indices into B*T): return the hidden states of THOSE rows only, [1, R, H].  Positions
+        mix only inside the attention core, so in the LAST layer everything behind it — output projection, residual,
+        norm, MLP, final norm: 3/4 of that layer's GEMM work — is computed for the kept rows alone; all earlier layers and
+        the last layer's q/k/v + attention see every row (they are the keys and values of later positions).  The caller
+        keeps the rows that carry a label (ASR-SFT batches: ~5 % of the positions); results on those rows are what the
+        full computation gives."""
         if inputs_embeds is None:
             inputs_embeds = self.embed_tokens(input_ids)
         B, T, _ = inputs_embeds.shape
@@ -160,8 +181,12 @@ class DecoderModel(nn.Module):
         if context_parallel is not None:
             mask.cp = context_parallel
         delta, residual = inputs_embeds, None
-        for layer in self.layers:
-            delta, residual = layer(delta, residual, cos, sin, mask)
+        last = len(self.layers) - 1
+        for i, layer in enumerate(self.layers):
+            if keep_rows is not None and i == last:
+                delta, residual = layer(delta, residual, cos, sin, mask, keep_rows)
+            else:
+                delta, residual = layer(delta, residual, cos, sin, mask)
         h, _ = self.norm(delta, residual)
         return h
 
@@ -200,6 +225,32 @@ class PackedCausalLM(nn.Module):
             elif isinstance(m, RMSNorm):
                 nn.init.ones_(m.weight)
 
+    def _forward_labelled_rows(self, input_ids, inputs_embeds, position_ids, attention_mask, labels, sentence_lens,
+                               num_sentence, ce_chunk_tokens, rows_max, ignore_index=-100):
+        """Fused lm_head + CE when the packers supply an upper bound of the labelled positions: the rows are selected
+        BEFORE the last layer's output projection instead of in front of lm_head (DecoderModel.forward, `keep_rows`).
+        Static shapes, no host sync: the row list has round_up(rows_max, 256) entries, the filler entries repeat row 0
+        with the label ignore_index (exact zeros in every gradient), and a bound that is too small poisons the loss with
+        NaN on the device — the semantics of functional._FusedLinearCE's static compaction."""
+        from touchnet_amd.loss.cross_entropy import fused_linear_cross_entropy
+        lab = labels.reshape(-1).to(torch.int64)
+        n_max = min((rows_max + 255) // 256 * 256, lab.numel())
+        labelled = lab != ignore_index
+        rows = torch.nonzero_static(labelled, size=max(n_max, 1), fill_value=0).squeeze(1)
+        count = labelled.sum()
+        valid = torch.arange(rows.numel(), device=lab.device) < count
+        h = self.model(input_ids=input_ids, inputs_embeds=inputs_embeds, position_ids=position_ids,
+                       attention_mask=attention_mask, keep_rows=rows)                       # [1, R, H]
+        lab_c = torch.where(valid, lab.index_select(0, rows), torch.full_like(rows, ignore_index))[None]
+        sl_c = sentence_lens.reshape(-1).index_select(0, rows)[None]
+        loss, per_token, acc = fused_linear_cross_entropy(h, self.lm_head.weight, lab_c, sl_c, num_sentence,
+                                                          chunk_tokens=ce_chunk_tokens, compact=False)
+        nan = torch.full((), float("nan"), dtype=loss.dtype, device=loss.device)
+        overflow = count > n_max
+        loss = torch.where(overflow, nan, loss)
+        per_token = torch.where(overflow, nan.to(per_token.dtype), per_token)
+        return SimpleNamespace(logits=None, loss=loss, loss_per_token=per_token, acc=acc)
+
     def forward(self, input_ids=None, inputs_embeds=None, position_ids=None, attention_mask=None,
                 labels=None, sentence_lens=None, num_sentence=None, shift_labels=None,
                 ce_chunk_tokens: int = 4096, ce_compact=False, labelled_rows_max=None, context_parallel=None,
@@ -209,6 +260,11 @@ class PackedCausalLM(nn.Module):
         model — the role liger's fused-linear-CE plays in the reference (`pred.loss`, train.py:443-445), but
         with the per-sentence normalisation kept — and `.loss` / `.loss_per_token` / `.acc` are returned
         with `.logits = None`.  Being inside forward keeps lm_head under FSDP2's unshard/reshard hooks."""
+        if (LAST_LAYER_LABELLED_ROWS and labels is not None and labelled_rows_max is not None and ce_compact is not True
+                and context_parallel is None and len(self.model.layers) > 1
+                and 2 * ((int(labelled_rows_max) + 255) // 256 * 256) <= labels.numel()):    # (pays for sparse labels only)
+            return self._forward_labelled_rows(input_ids, inputs_embeds, position_ids, attention_mask, labels,
+                                               sentence_lens, num_sentence, ce_chunk_tokens, int(labelled_rows_max))
         h = self.model(input_ids=input_ids, inputs_embeds=inputs_embeds, position_ids=position_ids,
                        attention_mask=attention_mask, context_parallel=context_parallel)
         if labelled_rows_max is not None and ce_compact is not True and context_parallel is None:
