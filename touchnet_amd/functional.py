@@ -254,7 +254,10 @@ class _FusedLinearCE(torch.autograd.Function):
     def backward(ctx, g_loss, _g):
         dh, dw = ctx.saved_tensors
         g = g_loss.to(torch.float32)
-        return (dh * g.to(dh.dtype)).view(ctx.hshape), (dw * g).to(ctx.wdtype), None, None, None, None, None, None
+        # (same-dtype operands: a bf16 tensor times an fp32 0-dim DEVICE tensor takes TensorIterator's casting kernel,
+        #  1.4 TB/s on the [V, H] weight gradient — 1.8 ms/step at V = 156 k; the upstream gradient is 1 or a power of two)
+        return ((dh * g.to(dh.dtype)).view(ctx.hshape), (dw * g.to(dw.dtype)).to(ctx.wdtype), None, None, None, None, None,
+                None)
 
 
 def fused_linear_cross_entropy(hidden, weight, labels, sentence_lens, num_sentence, ignore_index=-100,
