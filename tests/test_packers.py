@@ -132,3 +132,25 @@ def test_packers_equal_oracle_on_random_streams(seed):
     got = list(batch_audio_packed(({"audiofeat": torch.from_numpy(f)} for f in feats), cfg, tok))
     want = list(otok.batch_audio_packed(feats, B, T, 6, tok.tokenize, drop_last=drop))
     _eq_batches(got, want, ("labels", "position_ids", "attention_mask", "sentence_lens", "input_features"))
+
+
+def test_synthetic_short_utterance_plan_counts_audio_tokens_like_the_batcher():
+    """bench.py --workload qwen2_audio_7b_short: the plan's AUDIO-token count per utterance must be what the product
+    batcher (pinned against the reference's dynamic_batch in qwen2_audio_data.npz) emits for a clip of that many samples,
+    and the packed batch must be consistent with it."""
+    import numpy as np
+    from touchnet_amd.data import synthetic
+    from touchnet_amd.models.qwen2_audio.processing_qwen2_audio import audio_token_count
+    for n in (1, 159, 160, 161, 16000, 40051, 231999, 479999, 480000):
+        assert synthetic.qwen2_audio_tokens_of(n) == audio_token_count(min(-(-n // 160), 3000))
+    tok, n_clips = synthetic.qwen2_audio_plan(156032, 151646, 2, 8192, 7, audio_seconds=(2.0, 14.5))
+    lens = tok["audio_output_lengths"].numpy()
+    assert len(lens) == n_clips == len(tok["audio_samples"]) and n_clips > 40          # ~32 utterances per 8192-row
+    assert [synthetic.qwen2_audio_tokens_of(s) for s in tok["audio_samples"]] == lens.tolist()
+    assert tok["audio_positions"].numel() == int(lens.sum())
+    ids = tok["input_ids"].reshape(-1).numpy()
+    assert (ids[tok["audio_positions"].numpy()] == 151646).all() and (ids == 151646).sum() == lens.sum()
+    # the default plan (the metric's workload) is untouched by the new option
+    ref, n_ref = synthetic.qwen2_audio_plan(156032, 151646, 2, 8192, 2025)
+    assert n_ref == 20 and ref["audio_positions"].numel() == 15000 and ref["labelled_rows_max"] == 526
+    assert np.unique(ref["audio_output_lengths"].numpy()).tolist() == [750]
