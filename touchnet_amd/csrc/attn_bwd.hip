@@ -19,8 +19,9 @@
 // flex_attention backward has the same two-loop structure (inductor-generated Triton template).
 #include "attn_common.h"
 
-// Timing experiments only (scripts/build_variant.sh <name> -DTN_BWD_ABL=n; results are wrong for n != 0):
-//   1 no in-loop global loads / LDS stores   2 = 1 and no barriers   3 no MFMA / softmax work (staging skeleton only)
+// Timing experiments only (scripts/build_variant.sh <name> -DTN_BWD_ABL=3; results are wrong): no MFMA / softmax work,
+// the staging skeleton alone.  (Values 1 and 2 — no in-loop loads / no barriers — existed for the register-staged kernels
+// this file replaced; their numbers are quoted in the dK/dV kernel's header.)
 #ifndef TN_BWD_ABL
 #define TN_BWD_ABL 0
 #endif

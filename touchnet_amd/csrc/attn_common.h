@@ -192,49 +192,6 @@ __device__ __forceinline__ void wave_id_range(int id, int& minpos, int& mx) {
 // uniform into one s_and_saveexec region PER ELEMENT of the unrolled softmax loops.)
 __device__ __forceinline__ bool uniform(bool c) { return __builtin_amdgcn_readfirstlane((int)c) != 0; }
 
-// Transposed LDS image [D rows][R source rows] of an [R][D] bf16 tile: element (d, s) lives at
-//   d * STRIDE + 4 * ((s >> 2) ^ swz(d)) + (s & 3),  swz(d) = (d >> 3) & (R/4 - 1)
-// Written as 8-byte (4 source rows) groups, read as 8-byte groups by the MFMA operand loads:
-// conflict-free for both on gfx950 with STRIDE = R + 16 (simulated against the LDS bank rules of
-// MI355X_MICROARCH.md).
-template <int R>
-struct TLds {
-  static constexpr int STRIDE = R + 16;
-  static __device__ __forceinline__ int off(int d, int g) { return d * STRIDE + 4 * ((g ^ (d >> 3)) & (R / 4 - 1)); }
-};
-
-// 8-byte LDS accesses of the transposed images.  hipcc's SI load/store optimizer pairs neighbouring ones into
-// ds_read2_b64 / ds_write2_b64 (32-bank rules, contiguous 16-lane groups), under which the TLds swizzle shows
-// SQ_LDS_BANK_CONFLICT = 23-36 % of SQ_LDS_IDX_ACTIVE.  Forcing single ds_read_b64 (volatile LDS pointers) removes
-// the conflicts but serialises the accesses and measured 2-8 % SLOWER end to end (fwd causal 2.01 -> 2.04 ms, bwd
-// 7.27 -> 7.83 ms), so the paired form stays: LDS is not the limiter of these kernels (profiles/r01_*pmc*).
-__device__ __forceinline__ uint64_t lds_load64(const bf16_t* p) { return *reinterpret_cast<const uint64_t*>(p); }
-__device__ __forceinline__ void lds_store64(bf16_t* p, uint64_t v) { *reinterpret_cast<uint64_t*>(p) = v; }
-
-// MFMA-operand reads of a TLds<R> image cost ZERO address VALU inside the tile loops: for lane (l31, hi),
-// row d = 32*db + l31 and group g = ghi + glo (ghi a multiple of 4, glo in {hi, hi + 2}) the swizzle splits as
-//   off(d, g) = [l31*STRIDE + 4*(glo ^ (l31 >> 3))]  +  [32*db*STRIDE + 4*(ghi ^ 4*db)]
-//                 lane part: two VGPRs, set once          compile-time: folded into the ds_read offset field
-template <int R>
-struct TLdsReader {
-  int a0, a2;
-  __device__ __forceinline__ TLdsReader(int l31, int hi) {
-    const int lx = l31 >> 3;
-    a0 = l31 * TLds<R>::STRIDE + 4 * (hi ^ lx);
-    a2 = l31 * TLds<R>::STRIDE + 4 * ((hi + 2) ^ lx);
-  }
-  static __device__ __forceinline__ constexpr int c(int db, int ghi) {
-    return 32 * db * TLds<R>::STRIDE + 4 * (ghi ^ (4 * db));
-  }
-  // 8 contraction slots (groups ghi+hi and ghi+hi+2) of row 32*db + l31
-  __device__ __forceinline__ bf16x8_t operand(const bf16_t* img, int db, int ghi) const {
-    const uint64_t lo = lds_load64(img + a0 + c(db, ghi));
-    const uint64_t hi2 = lds_load64(img + a2 + c(db, ghi));
-    u32x4_t t = {(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi2, (uint32_t)(hi2 >> 32)};
-    return __builtin_bit_cast(bf16x8_t, t);
-  }
-};
-
 // ---- Panel image: ONE LDS copy of an [R rows][D] bf16 tile that serves both MFMA operand shapes ------------------
 // The tile is cut into D/32 column panels of [R][32] (64-byte rows, panel stride R*64 + 64 bytes); inside a row the
 // four 16-byte chunks are permuted by XOR with (row >> 2) & 3:
@@ -316,93 +273,6 @@ __device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t r, uint32_t b
   const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
   return make_uint4(v.x, v.y, v.z, v.w);
 }
-
-// Stage a [R rows][D] bf16 tile, source row stride `ld` elements, rows >= rows_valid zero-filled.
-//  * row-major image  dst_rm[r * (D + 8) + d]          (16-byte writes)
-//  * transposed image dst_t  via TLds<R>               (8-byte writes of 4 consecutive source rows)
-// Split in two phases so the global loads can be issued early and the LDS writes late.
-template <int R, int D, int NT>
-struct RowMajorStage {
-  static constexpr int CPR = D / 8;                       // 16-byte chunks per row
-  static constexpr int N = (R * CPR + NT - 1) / NT;       // chunks per thread
-  static constexpr bool EXACT = (R * CPR) % NT == 0;
-  uint4 v[N];
-  __device__ __forceinline__ void load(const bf16_t* src, size_t ld, int rows_valid, int tid) {
-    const __amdgpu_buffer_rsrc_t rs = tile_rsrc(src, ld, rows_valid < R ? rows_valid : R, D);
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-      const int c = tid + i * NT;
-      const int r = c / CPR, cc = c % CPR;
-      v[i] = buf_load16(rs, (EXACT || c < R * CPR) ? (uint32_t)((r * ld + cc * 8) * 2) : 0xffffffffu);
-    }
-  }
-  __device__ __forceinline__ void store(bf16_t* dst, int tid) const {
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-      const int c = tid + i * NT;
-      const int r = c / CPR, cc = c % CPR;
-      if (EXACT || c < R * CPR) *reinterpret_cast<uint4*>(dst + r * (D + 8) + cc * 8) = v[i];
-    }
-  }
-};
-
-template <int R, int D, int NT>
-struct TransposeStage {
-  static constexpr int CPR = D / 8;
-  static constexpr int UNITS = (R / 4) * CPR;             // one unit = 4 rows x 8 columns
-  static constexpr int N = (UNITS + NT - 1) / NT;
-  static constexpr bool EXACT = UNITS % NT == 0;
-  uint4 v[N][4];
-  __device__ __forceinline__ void load(const bf16_t* src, size_t ld, int rows_valid, int tid) {
-    const __amdgpu_buffer_rsrc_t rs = tile_rsrc(src, ld, rows_valid < R ? rows_valid : R, D);
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-      const int u = tid + i * NT;
-      const int r4 = u / CPR, c8 = u % CPR;
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-        v[i][k] = buf_load16(rs, (EXACT || u < UNITS) ? (uint32_t)(((4 * r4 + k) * ld + c8 * 8) * 2) : 0xffffffffu);
-    }
-  }
-  // row-major image of the same registers (the dK/dV and dQ kernels need both images of one tile)
-  __device__ __forceinline__ void store_rowmajor(bf16_t* dst, int tid) const {
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-      const int u = tid + i * NT;
-      const int r4 = u / CPR, c8 = u % CPR;
-      if (EXACT || u < UNITS) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) *reinterpret_cast<uint4*>(dst + (4 * r4 + k) * (D + 8) + c8 * 8) = v[i][k];
-      }
-    }
-  }
-  __device__ __forceinline__ void store(bf16_t* dst, int tid) const {
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-      const int u = tid + i * NT;
-      const int r4 = u / CPR, c8 = u % CPR;
-      if (EXACT || u < UNITS) {
-        const uint32_t w[4][4] = {{v[i][0].x, v[i][0].y, v[i][0].z, v[i][0].w},
-                                  {v[i][1].x, v[i][1].y, v[i][1].z, v[i][1].w},
-                                  {v[i][2].x, v[i][2].y, v[i][2].z, v[i][2].w},
-                                  {v[i][3].x, v[i][3].y, v[i][3].z, v[i][3].w}};
-#pragma unroll
-        for (int dd = 0; dd < 8; ++dd) {
-          const int wi = dd >> 1;
-          uint2 o;
-          if (dd & 1) {
-            o.x = __builtin_amdgcn_perm(w[1][wi], w[0][wi], 0x07060302u);
-            o.y = __builtin_amdgcn_perm(w[3][wi], w[2][wi], 0x07060302u);
-          } else {
-            o.x = __builtin_amdgcn_perm(w[1][wi], w[0][wi], 0x05040100u);
-            o.y = __builtin_amdgcn_perm(w[3][wi], w[2][wi], 0x05040100u);
-          }
-          lds_store64(dst + TLds<R>::off(c8 * 8 + dd, r4), (uint64_t)o.x | ((uint64_t)o.y << 32));
-        }
-      }
-    }
-  }
-};
 
 // Stage a [R rows][D] bf16 tile (source row stride `ld` elements, rows >= rows_valid zero-filled) into a PTile image:
 // full-row coalesced 16-byte global loads now, 16-byte LDS stores later.
