@@ -346,6 +346,23 @@ def _mm_tn(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = None
     return torch.nn.functional.linear(a, b, bias)
 
 
+def _stacked_view(ts):
+    """[n, M, N] view over `ts` if they are equally shaped contiguous [M, N] matrices lying back to back in one storage
+    (in order), else None."""
+    t0 = ts[0]
+    if t0.dim() != 2 or not all(t.shape == t0.shape and t.dtype == t0.dtype and t.is_contiguous() for t in ts):
+        return None
+    step = t0.numel()
+    try:
+        base = t0.untyped_storage().data_ptr()
+        if not all(t.untyped_storage().data_ptr() == base and t.storage_offset() == t0.storage_offset() + i * step
+                   for i, t in enumerate(ts)):
+            return None
+    except (RuntimeError, NotImplementedError):          # (fake / meta tensors without storage)
+        return None
+    return t0.as_strided((len(ts), t0.shape[0], t0.shape[1]), (step, t0.shape[1], 1))
+
+
 class _LinearGroup(torch.autograd.Function):
     """``y_i = x W_i^T + b_i`` for a group of linear layers that share their input (q/k/v, gate/up, or one layer).
 
@@ -401,7 +418,11 @@ class _LinearGroup(torch.autograd.Function):
         dws = [None] * n
         if any(need_w):
             if ctx.wgrad == "nt_fused" and n > 1:
-                dws = list(torch.split(torch.mm(torch.cat(dys, dim=1).t(), x2), Ns, dim=0))
+                st = _stacked_view(dys)
+                if st is not None:            # the gradients already lie side by side (library.attn_bwd_stacked): no cat
+                    dws = list(torch.bmm(st.transpose(1, 2), x2.unsqueeze(0).expand(n, M, K)).unbind(0))
+                else:
+                    dws = list(torch.split(torch.mm(torch.cat(dys, dim=1).t(), x2), Ns, dim=0))
             elif hip_ok and ctx.wgrad == "tn":
                 xt = transpose_2d(_c(x2))                                          # [K, M]
                 dyt = torch.empty(sum(Ns), M, dtype=x.dtype, device=x.device)      # [sum N, M]

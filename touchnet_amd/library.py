@@ -13,6 +13,7 @@ returns an EMPTY placeholder and the autograd formula keeps the input itself.
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional, Tuple
 
 import torch
@@ -316,6 +317,30 @@ def _(q, k, v, o, do, lse2, doc, meta, scale):
     return e(q), e(k), e(v)
 
 
+_STACKED_BWD = os.environ.get("TN_ATTN_BWD_STACKED", "1") != "0"      # (A/B switch)
+
+
+@custom_op(f"{NS}::attn_bwd_stacked", mutates_args=(), device_types="cuda")
+def attn_bwd_stacked(q: Tensor, k: Tensor, v: Tensor, o: Tensor, do: Tensor, lse2: Tensor, doc: Tensor, meta: Tensor,
+                     scale: float) -> Tensor:
+    """attn_bwd for Nh == Nkv with the three gradients in ONE buffer [3, B, T, Nh, D] (dq, dk, dv = its slices): a
+    consumer that wants them side by side — the fused q/k/v weight gradient of the audio tower — can then run a batched
+    GEMM over the buffer instead of concatenating three tensors first (functional._LinearGroup, wgrad="nt_fused")."""
+    do = _c(do)
+    B, T, Nh, D = q.shape
+    out = q.new_empty(3, B, T, Nh, D)
+    delta = torch.empty_like(lse2)
+    _C.check(_lib().tn_attn_bwd(_p(q), _p(k), _p(v), _p(o), _p(do), _p(lse2), _p(delta), _p(out[0]), _p(out[1]),
+                                _p(out[2]), _p(doc), _p(meta), B, T, Nh, Nh, D, float(scale), _cur()), "tn_attn_bwd")
+    return out
+
+
+@attn_bwd_stacked.register_fake
+def _(q, k, v, o, do, lse2, doc, meta, scale):
+    B, T, Nh, D = q.shape
+    return q.new_empty(3, B, T, Nh, D)
+
+
 def _attn_setup(ctx, inputs, output):
     q, k, v, doc, meta, scale = inputs
     o, lse2 = output
@@ -325,7 +350,10 @@ def _attn_setup(ctx, inputs, output):
 
 def _attn_backward(ctx, do, _dlse):
     q, k, v, o, lse2, doc, meta = ctx.saved_tensors
-    dq, dk, dv = attn_bwd(q, k, v, o, do, lse2, doc, meta, ctx.scale)
+    if q.shape == k.shape and _STACKED_BWD:                  # multi-head attention: one buffer, three slices
+        dq, dk, dv = attn_bwd_stacked(q, k, v, o, do, lse2, doc, meta, ctx.scale).unbind(0)
+    else:
+        dq, dk, dv = attn_bwd(q, k, v, o, do, lse2, doc, meta, ctx.scale)
     return dq, dk, dv, None, None, None
 
 
@@ -700,6 +728,6 @@ def _(feat, quantizer, codebook):
 
 
 OPS = ("rmsnorm_fwd", "rmsnorm_bwd", "layernorm_fwd", "layernorm_bwd", "swiglu_fwd", "swiglu_bwd", "gelu_fwd",
-       "gelu_bwd", "rope_apply", "attn_fwd", "attn_bwd", "attn_build_meta", "attn_fwd_seg", "attn_bwd_seg", "ce_fwd",
+       "gelu_bwd", "rope_apply", "attn_fwd", "attn_bwd", "attn_bwd_stacked", "attn_build_meta", "attn_fwd_seg", "attn_bwd_seg", "ce_fwd",
        "ce_bwd", "ce_bwd_", "gemm_tn", "rope_table", "transpose_bf16_", "colsum_bf16", "swiglu_fwd_t", "swiglu_bwd_t",
        "ce_fwd_rows", "ce_reduce", "kaldi_fbank", "log_mel", "audiofeat_stack", "pcm16_to_f32", "bestrq_tokenize")
