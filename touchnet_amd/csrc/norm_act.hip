@@ -189,27 +189,34 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const T* __restrict__ 
 }
 
 // out[c] = sum_p partial[p][c]  (second stage of every weight/bias gradient).
-// 64 columns per block, 4 row groups (one per wave) summed through LDS: coalesced 256-byte row segments.
+// 16 columns per block (64-byte row segments), 16 row groups summed through LDS.  (The first version gave a block 64
+// columns x 4 row groups: 64 workgroups for a 4096-wide gradient, 16 us per launch x 451 launches per step — most of
+// the chip idle; with cols/16 workgroups the 1-4 MB of partials take a third of that.)
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_partials_kernel(const float* __restrict__ partial, T* __restrict__ out,
                                                               int P, int H) {
-  __shared__ float sm[4][64];
-  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cx;
+  __shared__ float sm[16][16 + 1];
+  const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cx;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (c < H) {
     int p = ry;
-    for (; p + 12 < P; p += 16) {
+    for (; p + 48 < P; p += 64) {
       s0 += partial[(size_t)p * H + c];
-      s1 += partial[(size_t)(p + 4) * H + c];
-      s2 += partial[(size_t)(p + 8) * H + c];
-      s3 += partial[(size_t)(p + 12) * H + c];
+      s1 += partial[(size_t)(p + 16) * H + c];
+      s2 += partial[(size_t)(p + 32) * H + c];
+      s3 += partial[(size_t)(p + 48) * H + c];
     }
-    for (; p < P; p += 4) s0 += partial[(size_t)p * H + c];
+    for (; p < P; p += 16) s0 += partial[(size_t)p * H + c];
   }
   sm[ry][cx] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  if (ry == 0 && c < H) Elem<T>::st(out + c, (sm[0][cx] + sm[1][cx]) + (sm[2][cx] + sm[3][cx]));
+  if (ry == 0 && c < H) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += sm[k][cx];
+    Elem<T>::st(out + c, t);
+  }
 }
 
 // Bias gradient, stage 1:  partial[p][c] = sum over the rows of slab p of x[r][c]   (x bf16 [rows, ld], fp32 sums).
@@ -722,7 +729,7 @@ static int rmsnorm_bwd_t(const void* dy, const void* h, const void* w, const flo
   TN_DISPATCH_MAXV(mv, hipLaunchKernelGGL((rmsnorm_bwd_kernel<T, MAXV>), dim3(nb), dim3(256), 0, st, (const T*)dy,
                                           (const T*)h, (const T*)w, rstd, (const T*)dres, (T*)dh, ws, rows, H));
   TN_LAUNCH_CHECK();
-  hipLaunchKernelGGL((colsum_partials_kernel<T>), dim3((H + 63) / 64), dim3(256), 0, st, ws, (T*)dw, nb, H);
+  hipLaunchKernelGGL((colsum_partials_kernel<T>), dim3((H + 15) / 16), dim3(256), 0, st, ws, (T*)dw, nb, H);
   TN_LAUNCH_CHECK();
   return TN_OK;
 }
@@ -754,8 +761,8 @@ static int layernorm_bwd_t(const void* dy, const void* h, const void* w, const f
                                           (const T*)h, (const T*)w, mean, rstd, (const T*)dres, (T*)dh, ws, ws_b,
                                           rows, H));
   TN_LAUNCH_CHECK();
-  hipLaunchKernelGGL((colsum_partials_kernel<T>), dim3((H + 63) / 64), dim3(256), 0, st, ws, (T*)dw, nb, H);
-  hipLaunchKernelGGL((colsum_partials_kernel<T>), dim3((H + 63) / 64), dim3(256), 0, st, ws_b, (T*)db, nb, H);
+  hipLaunchKernelGGL((colsum_partials_kernel<T>), dim3((H + 15) / 16), dim3(256), 0, st, ws, (T*)dw, nb, H);
+  hipLaunchKernelGGL((colsum_partials_kernel<T>), dim3((H + 15) / 16), dim3(256), 0, st, ws_b, (T*)db, nb, H);
   TN_LAUNCH_CHECK();
   return TN_OK;
 }
@@ -927,7 +934,7 @@ int tn_colsum_bf16(const void* x, void* out, float* ws, int rows, int cols, long
   hipLaunchKernelGGL(colsum_rows_kernel, dim3((cols + 255) / 256, slabs), dim3(256), 0, st, (const bf16_t*)x, ws, rows,
                      cols, ld, rps);
   TN_LAUNCH_CHECK();
-  hipLaunchKernelGGL((colsum_partials_kernel<bf16_t>), dim3((cols + 63) / 64), dim3(256), 0, st, ws, (bf16_t*)out,
+  hipLaunchKernelGGL((colsum_partials_kernel<bf16_t>), dim3((cols + 15) / 16), dim3(256), 0, st, ws, (bf16_t*)out,
                      slabs, cols);
   TN_LAUNCH_CHECK();
   return TN_OK;
