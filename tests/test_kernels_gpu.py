@@ -828,6 +828,34 @@ def test_attention_long_sequence_multi_chunk_tile_list(D, Nh, Nkv):
         ds = p * (dp - delta[..., None])
         dq_ref = torch.einsum("hrt,thd->rhd", ds, kf[0]) * D ** -0.5
         _close(qg.grad[0, rows], dq_ref, 3e-2, 3e-2, f"dQ rows {s}..")
+    # dK / dV of KV rows whose workgroup walks MANY query stages (the dK/dV kernel compacts 256 candidate stages at a time
+    # into its LDS list: the first KV rows of the long document meet 469 q tiles x G heads = several list chunks).
+    # Reference: fp32 softmax statistics of every row of the long document, computed chunk-wise.
+    L = 30000
+    scale = D ** -0.5
+    qf, dof = q[0, :L].float(), do[0, :L].float()
+    lse = torch.empty(Nh, L, device=DEV)
+    dlt = torch.empty(Nh, L, device=DEV)
+    pos = torch.arange(L, device=DEV)
+    for s in range(0, L, 2048):
+        e = min(s + 2048, L)
+        sc = torch.einsum("rhd,thd->hrt", qf[s:e], kf[0, :L]) * scale
+        sc = sc.masked_fill((pos[None, :] > pos[s:e, None])[None], float("-inf"))
+        lse[:, s:e] = torch.logsumexp(sc, dim=-1)
+        o_ref = torch.einsum("hrt,thd->rhd", torch.softmax(sc, dim=-1), vf[0, :L])
+        dlt[:, s:e] = (dof[s:e] * o_ref).sum(-1).transpose(0, 1)
+        del sc, o_ref
+    for ks in (0, 16384 - 32, 29936):
+        kr = torch.arange(ks, ks + 64, device=DEV)
+        sc = torch.einsum("rhd,thd->hrt", qf, kf[0, kr]) * scale                      # [Nh, L, 64]
+        p = torch.exp(sc - lse[..., None]).masked_fill((kr[None, :] > pos[:, None])[None], 0.0)
+        dv_ref = torch.einsum("hrt,rhd->thd", p, dof)                                   # [64, Nh, D]
+        ds = p * (torch.einsum("rhd,thd->hrt", dof, vf[0, kr]) - dlt[..., None])
+        dk_ref = torch.einsum("hrt,rhd->thd", ds, qf) * scale
+        fold = lambda t: t.view(64, Nkv, G, D).sum(2)                                   # GQA: sum over the group's heads
+        _close(vg.grad[0, kr], fold(dv_ref), 3e-2, 3e-2, f"dV rows {ks}..")
+        _close(kg.grad[0, kr], fold(dk_ref), 3e-2, 3e-2, f"dK rows {ks}..")
+        del sc, p, ds
     q1, k1, v1 = [t[:, 30000:31000].clone().requires_grad_() for t in (q, k, v)]
     o1 = F.packed_attention(q1, k1, v1, F.causal_mask(1, 1000, DEV))
     _close(out[:, 30000:31000], o1, 1e-2, 1e-2, "short document after the long one")
