@@ -200,12 +200,21 @@ int tn_pack_fill(const int* row, const int* col, const int* sent, const int* bat
 
 /* ---- hand-written bf16 MFMA GEMM for the linear layers (q/k/v/o/gate/up/down/lm_head of the decoder blocks,
  *      fc1/fc2/out_proj of the audio tower): replaces torch.nn.functional.linear / liger's MLP swap,
- *      touchnet/models/llama/__init__.py:11-15.
- *      C[M,N] = A[M,K] . B[N,K]^T (+ bias[N]) (+ C when accumulate != 0); bf16 in/out, fp32 accumulation, ONE rounding.
- *      Both operands contraction-contiguous (nn.Linear's forward layout).  Ct (optional, may be NULL): transposed copy
- *      [N, M] written by the same epilogue for the weight-gradient GEMM that consumes C^T next.
- *      -22 unless: K % 128 == 0, N % 8 == 0, lda/ldb/ldc % 8 == 0 (>= K, K, N), 16-byte aligned bases,
- *      288 * ld * 2 < 2^31; with Ct: M % 8 == 0, ldct % 8 == 0, accumulate == 0. */
+ *      touchnet/models/llama/__init__.py:11-15 — forward, input-gradient and weight-gradient
+ *      products alike, each reading nn.Linear's own tensors (no transposed copies):
+ *        C[M,N] = sum_{s < nseg} opA_s . opB_s^T (+ bias[N]) (+ C when accumulate != 0)
+ *      bf16 in/out, fp32 accumulation over ALL segments, ONE rounding.
+ *      a_kmaj / b_kmaj = 0: the operand is stored [rows, K] (contraction-contiguous: x and W in y = x W^T, dY in
+ *      dX = dY W); = 1: stored [K, rows] (contraction-major: W in dX = dY W; dY and x in dW = dY^T x).
+ *      (a_kmaj = 1, b_kmaj = 0) has no caller and returns -22.  A, B, lda, ldb, K are arrays of nseg (1..3) entries;
+ *      Ct (optional, may be NULL): transposed copy [N, M] written by the same epilogue.
+ *      -22 unless: every K % 64 == 0, N % 8 == 0, every ld % 8 == 0 and >= the operand's contiguous extent, 16-byte
+ *      aligned bases; row-stored operands 288 * ld * 2 < 2^31, contraction-major operands ((K-1) * ld + rows) * 2 < 2^31;
+ *      a_kmaj: M % 8 == 0; with Ct: M % 8 == 0, ldct % 8 == 0, accumulate == 0. */
+int tn_gemm_bf16(const void* const* A, const void* const* B, const long long* lda, const long long* ldb, const int* K,
+                 int nseg, int a_kmaj, int b_kmaj, void* C, void* Ct, const void* bias, int M, int N, long long ldc,
+                 long long ldct, int accumulate, void* stream);
+/*      Single segment, both operands contraction-contiguous (the round-2 entry point): */
 int tn_gemm_bf16_tn(const void* A, const void* B, void* C, void* Ct, const void* bias, int M, int N, int K,
                     long long lda, long long ldb, long long ldc, long long ldct, int accumulate, void* stream);
 

@@ -64,6 +64,8 @@ PROTOTYPES = {
     "tn_pack_fill": [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _ll, _ll, _ll, _vp, _vp, _vp,
                      _vp, _vp, _vp, _vp, _vp],
     "tn_gemm_bf16_tn": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _ll, _ll, _ll, _ll, _i, _vp],
+    "tn_gemm_bf16": [C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_ll), C.POINTER(_ll), C.POINTER(_i), _i, _i, _i, _vp, _vp,
+                     _vp, _i, _i, _ll, _ll, _i, _vp],
 }
 _RESTYPE = {"tn_version": C.c_char_p, "tn_sumsq_multi_chunk": C.c_longlong, "tn_adamw_multi_chunk": C.c_longlong,
             "tn_colsum_workspace_floats": C.c_longlong}

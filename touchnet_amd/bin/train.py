@@ -133,7 +133,7 @@ class Trainer:
         if optimizer_factory is not None:          # (CPU tests drive the host logic with a torch optimizer)
             self.optimizer = optimizer_factory(model.parameters())
         else:
-            self.optimizer = FusedAdamW(model.parameters(), lr=job.lr_scheduler_lr,
+            self.optimizer = FusedAdamW(model.named_parameters(), lr=job.lr_scheduler_lr,
                                         weight_decay=job.optimizer_weight_decay, max_norm=job.training_max_norm,
                                         process_group=fsdp_mesh.get_group() if sharded else None)
         self.step = 0

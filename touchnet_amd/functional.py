@@ -313,8 +313,63 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = Non
     return out
 
 
+def gemm(segs, a_kmaj: bool = False, b_kmaj: bool = False, bias: Optional[torch.Tensor] = None,
+         out: Optional[torch.Tensor] = None, accumulate: bool = False,
+         out_t: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``out[M, N] = sum_s opA_s @ opB_s^T (+ bias) (+ out)`` on the hand-written MFMA kernel (csrc/gemm.hip), fp32
+    accumulation over all segments, one rounding.  ``segs`` = 1..3 pairs ``(a, b)`` of bf16 device matrices with
+    contiguous rows AS STORED: ``a`` is [M, K] (``a_kmaj=False``) or [K, M] (``a_kmaj=True``: the contraction index is the
+    slow one), ``b`` is [N, K] or [K, N] likewise.  The three products of a linear layer y = x W^T:
+        forward          gemm([(x, W)])                          x [M, K], W [N, K]
+        input gradient   gemm([(dy, W)], b_kmaj=True)            dy [M, N] · W [N, K]      (contraction over N)
+        weight gradient  gemm([(dy, x)], True, True)             dy [M, N]^T · x [M, K]    (contraction over tokens)
+    — none of them needs a transposed copy of an operand."""
+    if not 1 <= len(segs) <= 3:
+        raise _C.KernelError("gemm: 1..3 segments")
+    for a, b in segs:
+        if a.dim() != 2 or b.dim() != 2 or a.dtype != torch.bfloat16 or b.dtype != torch.bfloat16:
+            raise _C.KernelError("gemm: 2-D bf16 operands only")
+        if a.stride(1) != 1 or b.stride(1) != 1:
+            raise _C.KernelError("gemm: operands need contiguous rows")
+    a0, b0 = segs[0]
+    M = a0.shape[1] if a_kmaj else a0.shape[0]
+    N = b0.shape[1] if b_kmaj else b0.shape[0]
+    Ks = []
+    for a, b in segs:
+        Ka, Ma = (a.shape[0], a.shape[1]) if a_kmaj else (a.shape[1], a.shape[0])
+        Kb, Nb = (b.shape[0], b.shape[1]) if b_kmaj else (b.shape[1], b.shape[0])
+        if Ka != Kb or Ma != M or Nb != N:
+            raise _C.KernelError(f"gemm: segment shapes disagree: a {tuple(a.shape)} b {tuple(b.shape)}")
+        Ks.append(Ka)
+    if out is None:
+        if accumulate:
+            raise _C.KernelError("gemm: accumulate needs `out`")
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=a0.device)
+    if out.stride(1) != 1 or tuple(out.shape) != (M, N) or out.dtype != torch.bfloat16:
+        raise _C.KernelError("gemm: bad `out`")
+    if bias is not None:
+        bias = _c(bias).to(torch.bfloat16)
+    n = len(segs)
+    import ctypes as C
+    Ap = (C.c_void_p * n)(*[a.data_ptr() for a, _ in segs])
+    Bp = (C.c_void_p * n)(*[b.data_ptr() for _, b in segs])
+    la = (C.c_longlong * n)(*[a.stride(0) for a, _ in segs])
+    lb = (C.c_longlong * n)(*[b.stride(0) for _, b in segs])
+    Kc = (C.c_int * n)(*Ks)
+    if not a0.is_cuda:
+        raise _C.KernelError("touchnet_amd kernels need device (HIP) tensors; got a CPU tensor")
+    _C.check(_C.lib().tn_gemm_bf16(Ap, Bp, la, lb, Kc, n, int(a_kmaj), int(b_kmaj), _p(out), _p(out_t), _p(bias), M, N,
+                                   out.stride(0), out_t.stride(0) if out_t is not None else 0, int(accumulate),
+                                   _cur()), "tn_gemm_bf16")
+    return out
+
+
+def gemm_supported(M: int, N: int, Ks, a_kmaj: bool = False) -> bool:
+    return all(k % 64 == 0 and k > 0 for k in Ks) and N % 8 == 0 and M > 0 and (not a_kmaj or M % 8 == 0)
+
+
 def gemm_tn_supported(M: int, N: int, K: int) -> bool:
-    return K % 128 == 0 and N % 8 == 0 and M > 0
+    return gemm_supported(M, N, (K,))
 
 
 def _tn_ok(M: int, K: int, Ns) -> bool:

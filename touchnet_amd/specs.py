@@ -18,7 +18,8 @@ from touchnet_amd.utils.train_spec import TrainSpec, _train_specs, get_train_spe
 
 def _build_optimizers(model_parts, job):
     from touchnet_amd.models.tensor_parallel import tp_param_ids
-    params = [p for m in model_parts for p in m.parameters()]
+    many = len(model_parts) > 1
+    params = [(f"{i}.{n}" if many else n, p) for i, m in enumerate(model_parts) for n, p in m.named_parameters()]
     tp_group, tp_ids = tp_param_ids(model_parts)
     return FusedAdamW(params, lr=job.lr_scheduler_lr, weight_decay=job.optimizer_weight_decay,
                       max_norm=job.training_max_norm, tp_group=tp_group, tp_param_ids=tp_ids)

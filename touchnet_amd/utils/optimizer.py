@@ -45,11 +45,22 @@ def _shard_groups(params) -> List[Any]:
 
 
 class FusedAdamW:
-    def __init__(self, params: Iterable[torch.nn.Parameter], lr=8e-4, betas=(0.9, 0.95), eps=1e-8,
+    def __init__(self, params: Iterable, lr=8e-4, betas=(0.9, 0.95), eps=1e-8,
                  weight_decay=0.1, max_norm: float = 1.0, process_group=None, tp_group=None, tp_param_ids=()):
-        """`tp_group` / `tp_param_ids` (models.tensor_parallel.tp_param_ids): parameters sharded over the tensor-parallel
+        """`params`: parameters, or `(name, parameter)` pairs (`model.named_parameters()`): the names key the checkpoint
+        state (`state_dict()`), so pass them whenever the optimizer is checkpointed.
+        `tp_group` / `tp_param_ids` (models.tensor_parallel.tp_param_ids): parameters sharded over the tensor-parallel
         group — their squared gradient norm is summed over it, the replicated parameters' is not."""
-        self.params = [p for p in params if p.requires_grad]
+        items = list(params)
+        if items and isinstance(items[0], (tuple, list)):
+            items = [(n, p) for n, p in items if p.requires_grad]
+            self.names = [n.replace("_checkpoint_wrapped_module.", "") for n, _ in items]
+            self.params = [p for _, p in items]
+        else:
+            self.params = [p for p in items if p.requires_grad]
+            self.names = [f"param.{i}" for i in range(len(self.params))]
+        if len(set(self.names)) != len(self.names):
+            raise ValueError("FusedAdamW: parameter names must be unique")
         self.tp_group = tp_group
         self._tp_index = {i for i, p in enumerate(self.params) if id(p) in set(tp_param_ids)}
         self.lr, self.betas, self.eps, self.weight_decay, self.max_norm = lr, betas, eps, weight_decay, max_norm
@@ -155,24 +166,42 @@ class FusedAdamW:
         """Number of APPLIED updates (host sync: logging / checkpoint use only)."""
         return int(self.step_state[:1].view(torch.int32).item())
 
-    # ------------------------------------------------------------------ checkpoint (touchnet/utils/checkpoint.py keeps the optimizer in its states)
+    # ------------------------------------------------------------------ checkpoint
+    # The reference's CheckpointManager saves the optimizer through torch.distributed.checkpoint
+    # (touchnet/utils/checkpoint.py): DCP flattens nested dicts into string keys and decides per tensor whether it is
+    # sharded (a DTensor: every rank saves / reloads ITS shard) or replicated (a plain tensor: saved once, every rank
+    # reloads the same bytes).  So the state is keyed by parameter NAME, and under FSDP2 the fp32 master / moments —
+    # plain local shards inside this class — are handed out as DTensors with the parameter's mesh and placements.
+    def _as_saved(self, i: int, t: torch.Tensor) -> torch.Tensor:
+        p = self.params[i]
+        mesh = getattr(p, "device_mesh", None)
+        if mesh is None:
+            return t
+        from torch.distributed.tensor import DTensor
+        return DTensor.from_local(t, mesh, p.placements, run_check=False, shape=p.shape, stride=p.stride())
+
     def state_dict(self) -> Dict[str, Any]:
         return {"step_state": self.step_state.clone(),
-                "state": {i: {"master": s["master"], "exp_avg": s["m"], "exp_avg_sq": s["v"]}
-                          for i, s in enumerate(self.state)},
+                "state": {n: {"master": self._as_saved(i, s["master"]), "exp_avg": self._as_saved(i, s["m"]),
+                              "exp_avg_sq": self._as_saved(i, s["v"])}
+                          for i, (n, s) in enumerate(zip(self.names, self.state))},
                 "hyper": {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps,
                           "weight_decay": self.weight_decay, "max_norm": self.max_norm}}
 
     @torch.no_grad()
     def load_state_dict(self, sd: Dict[str, Any]) -> None:
-        if len(sd["state"]) != len(self.state):
-            raise ValueError(f"optimizer state has {len(sd['state'])} tensors, this optimizer {len(self.state)}")
+        st = sd["state"]
+        if len(st) != len(self.state):
+            raise ValueError(f"optimizer state has {len(st)} tensors, this optimizer {len(self.state)}")
         self.step_state.copy_(sd["step_state"])
-        for i, s in enumerate(self.state):
-            src = sd["state"][i]
-            s["master"].copy_(_local(src["master"]))
-            s["m"].copy_(_local(src["exp_avg"]))
-            s["v"].copy_(_local(src["exp_avg_sq"]))
+        for i, (n, s) in enumerate(zip(self.names, self.state)):
+            src = st[n] if n in st else st[i] if i in st else st[str(i)]     # (pre-round-3 checkpoints: integer keys)
+            for key, dst in (("master", s["master"]), ("exp_avg", s["m"]), ("exp_avg_sq", s["v"])):
+                t = _local(src[key])
+                if t.shape != dst.shape:
+                    raise ValueError(f"optimizer state {n}.{key}: shard shape {tuple(t.shape)} != {tuple(dst.shape)}")
+                if t.data_ptr() != dst.data_ptr():
+                    dst.copy_(t)
             lp = _local(self.params[i].data)
             if lp.dtype == torch.bfloat16:
                 lp.copy_(s["master"])
