@@ -1,5 +1,5 @@
-"""GEMM-only workload for rocprofv3 (kernel trace / PMC passes): the hand-written kernel and the library GEMM on the
-decoder-block shapes.   python scripts/gemm_prof.py [iters]"""
+"""GEMM-only workload for rocprofv3 (kernel trace / PMC passes): the hand-written kernel (forward mode and the
+contraction-major weight-gradient mode) and the library GEMM on decoder-block shapes.   python scripts/gemm_prof.py [iters]"""
 import os
 import sys
 
@@ -17,6 +17,13 @@ for M, N, K in [(16384, 4096, 4096), (16384, 4096, 11008)]:
     b = (torch.rand(N, K, device=dev) * 2 - 1).to(torch.bfloat16)
     out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
     for _ in range(iters):
-        F.gemm_tn(a, b, out=out)
+        F.gemm([(a, b)], out=out)
         torch.mm(a, b.t(), out=out)
+# weight gradient: dy [tokens, N]^T x [tokens, K]
+M, N, K = 4096, 4096, 16384
+dy = (torch.rand(K, M, device=dev) * 2 - 1).to(torch.bfloat16)
+x = (torch.rand(K, N, device=dev) * 2 - 1).to(torch.bfloat16)
+out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+for _ in range(iters):
+    F.gemm([(dy, x)], True, True, out=out)
 torch.cuda.synchronize()

@@ -5,7 +5,7 @@ schedule variants against hipBLASLt, on the shapes of the Qwen2-Audio-7B step.  
         [--variants 0,100,110,...] [--rounds 3] [--iters 10] [--out gpurun_out/gemm_sweep.json]
 
 (the `allv` library is built with scripts/build_variant.sh allv -DTN_GEMM_ALL_VARIANTS; the product library only holds
-the default variant).  variant = 100 * PLACE + 10 * PRIO + ILV, see gemm.hip.
+the default variant).  variant = 100 * PLACE + 10 * ASYM + ILV, see gemm.hip; --persist 0,1 also times the one-workgroup-per-tile launch.
 """
 import argparse
 import json
@@ -32,7 +32,7 @@ SHAPES = [
     ("wgrad gate  11008x4096x16384", "wgrad", I, H, T),
     ("wgrad down  4096x11008x16384", "wgrad", H, I, T),
 ]
-ALL_VARIANTS = [0, 10, 20, 1, 11, 100, 110, 101, 111, 200, 210, 201, 211, 300, 310, 301, 311]
+ALL_VARIANTS = [0, 1, 100, 101, 110, 111, 301, 311, 401, 411, 501, 511, 601, 611]
 
 
 def rnd(*shape, seed):
@@ -50,8 +50,9 @@ def timeit(fn, iters):
     return e0.elapsed_time(e1) / iters
 
 
-def set_variant(v):
+def set_variant(v, persist=1):
     os.environ["TN_GEMM_VARIANT"] = str(v)
+    os.environ["TN_GEMM_PERSIST"] = str(persist)
 
 
 def operands(mode, M, N, K, seed):
@@ -81,13 +82,15 @@ def check(name, got, ref):
     return ok
 
 
-def correctness(variants):
+def correctness(variants, persists=(1,)):
     """Every mode on ragged shapes (M, N not multiples of 256, several K depths), bias / accumulate / segments."""
     ok = True
-    for v in variants:
-        set_variant(v)
+    for v, pers in [(v, q) for v in variants for q in persists]:
+        set_variant(v, pers)
+        v = f"{v}p{pers}"
         for mode in ("fwd", "dgrad", "wgrad"):
-            for (M, N, K) in ((256, 256, 64), (520, 264, 192), (1000, 776, 1088), (2048, 1280, 4096)):
+            for (M, N, K) in ((256, 256, 64), (520, 264, 192), (1000, 776, 1088), (2048, 1280, 4096),
+                              (4360, 4104, 128), (8200, 8192, 64)):   # > 256 tiles: several tiles per workgroup
                 if mode == "wgrad":
                     M = (M + 7) // 8 * 8
                 a, b, ak, bk, ref, _ = operands(mode, M, N, K, seed=M + N + K)
@@ -130,13 +133,15 @@ def main():
     ap.add_argument("--out", default="")
     ap.add_argument("--shapes", default="")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--persist", default="1")
     args = ap.parse_args()
     gemm_tuning.enable()
     variants = [int(v) for v in args.variants.split(",")] if args.variants else ALL_VARIANTS
     cvars = [int(v) for v in args.check_variants.split(",")] if args.check_variants else variants
+    persists = [int(v) for v in args.persist.split(",")]
     ok = True
     if not args.no_check:
-        ok = correctness(cvars)
+        ok = correctness(cvars, persists)
         print("CORRECTNESS:", "all ok" if ok else "FAILURES", flush=True)
     res = []
     for name, mode, M, N, K in SHAPES:
@@ -147,7 +152,8 @@ def main():
         fl = 2.0 * M * N * K
         fns = dict(libs)
         for v in variants:
-            fns[f"own_v{v}"] = (lambda v=v: (set_variant(v), F.gemm([(a, b)], ak, bk, out=out)))
+            for q in persists:
+                fns[f"own_v{v}p{q}"] = (lambda v=v, q=q: (set_variant(v, q), F.gemm([(a, b)], ak, bk, out=out)))
         for fn in fns.values():
             fn(), fn()
         times = {k: [] for k in fns}

@@ -91,6 +91,13 @@ __device__ __forceinline__ void tile_of_block(int bid, int nbm, int nbn, int& tm
 
 typedef f32x16_t Acc[4][2];
 
+// Timing experiments (scripts/build_gemm_variant.sh <name> -DTN_GEMM_ABLATE=n; results are garbage for n != 0):
+//   1 no DMA in the loop   2 no fragment reads in the loop   3 no MFMA   4 no epilogue   5 no barrier in the loop
+//   6 every DMA piece reads the tile's first rows (L1 / L2 hits only)
+#ifndef TN_GEMM_ABLATE
+#define TN_GEMM_ABLATE 0
+#endif
+
 // Where the 8 DMA pieces a wave issues per stage go, as positions 0..31 in the stream of MFMAs that follows the barrier
 // which freed their slots (0-7 = last quarter of stage t, 8-31 = quarters 0-2 of stage t+1).  All B positions must be
 // below all A positions (the vmcnt arithmetic above relies on B(t+2) being older than A(t+3)).
@@ -101,6 +108,9 @@ template <> struct Place<0> { static constexpr int B[4] = {0, 1, 2, 3}, A[4] = {
 template <> struct Place<1> { static constexpr int B[4] = {0, 2, 4, 6}, A[4] = {9, 13, 17, 21}; };
 template <> struct Place<2> { static constexpr int B[4] = {0, 4, 8, 12}, A[4] = {16, 20, 24, 28}; };
 template <> struct Place<3> { static constexpr int B[4] = {0, 2, 4, 6}, A[4] = {8, 12, 16, 20}; };
+template <> struct Place<4> { static constexpr int B[4] = {0, 2, 4, 6}, A[4] = {8, 10, 12, 14}; };
+template <> struct Place<5> { static constexpr int B[4] = {0, 1, 2, 3}, A[4] = {9, 13, 17, 21}; };
+template <> struct Place<6> { static constexpr int B[4] = {0, 2, 4, 6}, A[4] = {14, 18, 22, 26}; };
 
 // piece index issued at position `pos` for the given table, or -1
 template <int PLACE, bool IS_A> constexpr int piece_at(int pos) {
@@ -117,35 +127,45 @@ struct Stream {
   int step;      // bytes per stage
   int left;      // stages left in the current segment
   int seg;
+  int ld2;       // row pitch in bytes of the current segment
   int voff[4];   // per-lane byte offsets of this wave's 4 pieces
 
-  // R = rows of the output dimension this operand spans (M or N), origin = first one of this tile
-  __device__ __forceinline__ void open(const bf16_t* X, long long ld, int K, int R, int origin, int wave, int lane) {
-    const long long ld2 = ld * 2;
+  // (re)derive the per-lane piece offsets from the lane id (also used to re-materialise them behind a tile's epilogue,
+  // so that they are not kept alive — i.e. spilled — across it)
+  __device__ __forceinline__ void set_voff(int wave, int lane) {
     if constexpr (!KMAJ) {
       // piece q = rows 32 wave + 8 q + (lane >> 3), the lane's 16-byte slot holds chunk (lane & 7) ^ ((row >> 1) & 7)
-      const long long bytes = (long long)(R - origin) * ld2;
-      rs = __builtin_amdgcn_make_buffer_rsrc((void*)(X + (long long)origin * ld), 0, (int)min(bytes, 0x7fffffffLL),
-                                             0x00020000);
-      step = 128;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int row = wave * 32 + q * 8 + (lane >> 3);
-        voff[q] = (int)(row * ld2) + (((lane & 7) ^ ((row >> 1) & 7)) << 4);
+        voff[q] = (TN_GEMM_ABLATE == 6 ? (row & 7) : row) * ld2 + (((lane & 7) ^ ((row >> 1) & 7)) << 4);
       }
     } else {
       // piece q = k-rows 8 wave + 2 q + (lane >> 5) of the stage; the lane's 16-byte slot u = lane & 31 of the 512-byte
       // row holds 64-byte group (u >> 2) ^ (k & 3), chunk u & 3
-      const long long bytes = ((long long)(K - 1) * ld + (R - origin)) * 2;
-      rs = __builtin_amdgcn_make_buffer_rsrc((void*)(X + origin), 0, (int)min(bytes, 0x7fffffffLL), 0x00020000);
-      step = (int)(64 * ld2);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int k = wave * 8 + q * 2 + (lane >> 5);
         const int u = lane & 31;
-        voff[q] = (int)(k * ld2) + ((((u >> 2) ^ (k & 3)) << 6) | ((u & 3) << 4));
+        voff[q] = (TN_GEMM_ABLATE == 6 ? (k & 1) : k) * ld2 + ((((u >> 2) ^ (k & 3)) << 6) | ((u & 3) << 4));
       }
     }
+  }
+
+  // R = rows of the output dimension this operand spans (M or N), origin = first one of this tile
+  __device__ __forceinline__ void open(const bf16_t* X, long long ld, int K, int R, int origin, int wave, int lane) {
+    ld2 = (int)(ld * 2);
+    if constexpr (!KMAJ) {
+      const long long bytes = (long long)(R - origin) * ld2;
+      rs = __builtin_amdgcn_make_buffer_rsrc((void*)(X + (long long)origin * ld), 0, (int)min(bytes, 0x7fffffffLL),
+                                             0x00020000);
+      step = 128;
+    } else {
+      const long long bytes = ((long long)(K - 1) * ld + (R - origin)) * 2;
+      rs = __builtin_amdgcn_make_buffer_rsrc((void*)(X + origin), 0, (int)min(bytes, 0x7fffffffLL), 0x00020000);
+      step = 64 * ld2;
+    }
+    set_voff(wave, lane);
     soff = 0;
     left = K >> 6;
   }
@@ -173,7 +193,7 @@ __device__ __forceinline__ u32x2_t ds_tr16(uint32_t addr) {
   return r;
 }
 
-template <bool AK, bool BK, int PLACE, int PRIO, int ILV, bool HAS_CT>
+template <bool AK, bool BK, int PLACE, int ASYM, int ILV, bool HAS_CT>
 struct Kernel {
   // ---- per-lane LDS read offsets ------------------------------------------------------------------------------------------
   //  ROW : xr[q] = (row0 + l31) * 128 + (((2 q + hi) ^ ((l31 >> 1) & 7)) << 4); block b at + b * 4096
@@ -236,25 +256,47 @@ struct Kernel {
     }
   }
 
-  // ---- the kernel body ----------------------------------------------------------------------------------------------------
-  static __device__ __forceinline__ void run(const Params& p, char* smem) {
+  // ---- the kernel body; HALF = 0 for waves 0-3, 1 for waves 4-7 (ASYM shifts the younger half's DMA positions by one
+  //      MFMA so that the two waves of a SIMD, which leave every barrier together, do not issue their pieces in the same gap)
+  template <int HALF>
+  static __device__ __forceinline__ void body(const Params& p, char* smem) {
+    constexpr int SH = ASYM ? HALF : 0;
     const int tid = threadIdx.x;
-    const int lane = tid & 63;
+    int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;   // 2 x 4 waves
 
-    int tm, tn;
-    tile_of_block(blockIdx.x, p.nbm, p.nbn, tm, tn);
-    const int m0 = tm * BM, n0 = tn * BN;
+    // persistent: workgroup b of G owns tiles b, b + G, b + 2 G, ... of the XCD-aware order (G is a multiple of 8 or
+    // the grid covers every tile at once, so a workgroup's tiles stay on its XCD)
+    const int bid = blockIdx.x, G = gridDim.x;
+    const int mine = (p.nbm * p.nbn - bid + G - 1) / G;
+    auto origin = [&](int k, int& m0, int& n0) {
+      int tm, tn;
+      tile_of_block(bid + k * G, p.nbm, p.nbn, tm, tn);
+      m0 = tm * BM;
+      n0 = tn * BN;
+    };
 
     Stream<AK> sA;
     Stream<BK> sB;
-    auto open_a = [&](int s) { sA.open(p.seg[s].A, p.seg[s].lda, p.seg[s].K, p.M, m0, wave, lane); sA.seg = s; };
-    auto open_b = [&](int s) { sB.open(p.seg[s].B, p.seg[s].ldb, p.seg[s].K, p.N, n0, wave, lane); sB.seg = s; };
+    int ka = 0, kb = 0;                        // tile cursors of the two operand streams (they run 2-3 stages ahead)
+    auto open_a = [&](int s) {
+      int m0, n0;
+      origin(ka, m0, n0);
+      sA.open(p.seg[s].A, p.seg[s].lda, p.seg[s].K, p.M, m0, wave, lane);
+      sA.seg = s;
+    };
+    auto open_b = [&](int s) {
+      int m0, n0;
+      origin(kb, m0, n0);
+      sB.open(p.seg[s].B, p.seg[s].ldb, p.seg[s].K, p.N, n0, wave, lane);
+      sB.seg = s;
+    };
     auto adv_a = [&]() {
       sA.soff += sA.step;
       if (--sA.left == 0) {
         if (sA.seg + 1 < p.nseg) open_a(sA.seg + 1);
+        else if (++ka < mine) open_a(0);
         else sA.kill(p.C);
       }
     };
@@ -262,6 +304,7 @@ struct Kernel {
       sB.soff += sB.step;
       if (--sB.left == 0) {
         if (sB.seg + 1 < p.nseg) open_b(sB.seg + 1);
+        else if (++kb < mine) open_b(0);
         else sB.kill(p.C);
       }
     };
@@ -276,16 +319,19 @@ struct Kernel {
     open_a(0);
     open_b(0);
 
-    const Reader<AK, 4> ra(lane, wr * 128);
-    const Reader<BK, 2> rb(lane, wc * 64);
+    Reader<AK, 4> ra(lane, wr * 128);
+    Reader<BK, 2> rb(lane, wc * 64);
 
     Acc acc;
+    auto zero_acc = [&]() {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    };
+    zero_acc();
 
     Frags<AK, 4> ae, ao;
     Frags<BK, 2> be, bo;
@@ -306,16 +352,20 @@ struct Kernel {
       read_frag(QC, std::integral_constant<int, 5>{}, sa, sb, a, b);
     };
     auto mma = [&](const Frags<AK, 4>& a, const Frags<BK, 2>& b, int i, int j) {
+#if TN_GEMM_ABLATE == 3
+      asm volatile("" ::"v"(a.v[i]), "v"(b.v[j]));
+#else
       acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b.v[j], a.v[i], acc[i][j], 0, 0, 0);
+#endif
     };
 
     // One quarter: the 8 MFMAs of (ca, cb); the fragments of quarter NQ of slots (nsa, nsb) are read into (na, nb) either
     // all in front (ILV = 0) or one behind each of the first six MFMAs (ILV = 1); the DMA pieces the placement table
-    // puts at positions P0 .. P0 + 7 go behind their MFMA.  dst_b / dst_a = slots the open piece set fills.
+    // puts at positions P0 .. P0 + 7 go behind their MFMA (P0 < 0: none).  dst_b / dst_a = slots the open piece set fills.
     auto quarter = [&](auto NQC, auto P0C, const Frags<AK, 4>& ca, const Frags<BK, 2>& cb, Frags<AK, 4>& na,
                        Frags<BK, 2>& nb, int nsa, int nsb, int dst_b, int dst_a) {
       constexpr int P0 = decltype(P0C)::value;
-      if constexpr (ILV == 0) {
+      if constexpr (ILV == 0 && TN_GEMM_ABLATE != 2) {
         read_all(NQC, nsa, nsb, na, nb);
         TN_PIN();
       }
@@ -323,18 +373,19 @@ struct Kernel {
         constexpr int m = decltype(MC)::value;
         mma(ca, cb, m >> 1, m & 1);
         TN_PIN();
-        if constexpr (ILV == 1 && m < 6) {
+        if constexpr (ILV == 1 && m < 6 && TN_GEMM_ABLATE != 2) {
           read_frag(NQC, std::integral_constant<int, m>{}, nsa, nsb, na, nb);
           TN_PIN();
         }
-        constexpr int pb = piece_at<PLACE, false>(P0 + m), pa = piece_at<PLACE, true>(P0 + m);
+        constexpr int pb = P0 < 0 ? -1 : piece_at<PLACE, false>(P0 + m - SH);
+        constexpr int pa = P0 < 0 ? -1 : piece_at<PLACE, true>(P0 + m - SH);
         if constexpr (pb >= 0) {
-          piece_b(dst_b, pb);
+          if constexpr (TN_GEMM_ABLATE != 1) piece_b(dst_b, pb);
           if constexpr (pb == 3) adv_b();
           TN_PIN();
         }
         if constexpr (pa >= 0) {
-          piece_a(dst_a, pa);
+          if constexpr (TN_GEMM_ABLATE != 1) piece_a(dst_a, pa);
           if constexpr (pa == 3) adv_a();
           TN_PIN();
         }
@@ -348,14 +399,38 @@ struct Kernel {
       step(std::integral_constant<int, 6>{});
       step(std::integral_constant<int, 7>{});
     };
+    // the pieces of positions 0..7 in one burst (prologue; behind a tile's epilogue)
+    auto early_pieces = [&](int dst_b, int dst_a) {
+      auto one = [&](auto MC) {
+        constexpr int m = decltype(MC)::value;
+        constexpr int pb = piece_at<PLACE, false>(m - SH), pa = piece_at<PLACE, true>(m - SH);
+        if constexpr (pb >= 0) {
+          piece_b(dst_b, pb);
+          if constexpr (pb == 3) adv_b();
+        }
+        if constexpr (pa >= 0) {
+          piece_a(dst_a, pa);
+          if constexpr (pa == 3) adv_a();
+        }
+      };
+      one(std::integral_constant<int, 0>{});
+      one(std::integral_constant<int, 1>{});
+      one(std::integral_constant<int, 2>{});
+      one(std::integral_constant<int, 3>{});
+      one(std::integral_constant<int, 4>{});
+      one(std::integral_constant<int, 5>{});
+      one(std::integral_constant<int, 6>{});
+      one(std::integral_constant<int, 7>{});
+    };
     auto next = [](int s, int d) { s += d; return s >= 5 ? s - 5 : s; };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
     using I2 = std::integral_constant<int, 2>;
     using I3 = std::integral_constant<int, 3>;
+    using NONE = std::integral_constant<int, -1>;
 
-    // prologue: A0 B0 A1 B1 -> slots 0..3, then the piece set "opened at the barrier of stage -1" = {B(1) [already
-    // issued], A(2) -> slot 4}: its pieces with positions < 8 are issued here, the later ones by the first trip
+    // prologue: A0 B0 A1 -> slots 0..2, then the piece set "opened at the barrier of stage -1" = {B(1) -> slot 3,
+    // A(2) -> slot 4}: its pieces with positions < 8 are issued here, the later ones by the first trip
 #pragma unroll
     for (int q = 0; q < 4; ++q) piece_a(0, q);
     adv_a();
@@ -365,32 +440,23 @@ struct Kernel {
 #pragma unroll
     for (int q = 0; q < 4; ++q) piece_a(2, q);
     adv_a();
-    constexpr int kEarlyB = (Place<PLACE>::B[0] < 8) + (Place<PLACE>::B[1] < 8) + (Place<PLACE>::B[2] < 8) +
-                            (Place<PLACE>::B[3] < 8);
-    constexpr int kEarlyA = (Place<PLACE>::A[0] < 8) + (Place<PLACE>::A[1] < 8) + (Place<PLACE>::A[2] < 8) +
-                            (Place<PLACE>::A[3] < 8);
-    static_assert(kEarlyA == 0 || kEarlyB == 4, "every B position lies below every A position");
-#pragma unroll
-    for (int q = 0; q < kEarlyB; ++q) piece_b(3, q);
-    if constexpr (kEarlyB == 4) adv_b();
-#pragma unroll
-    for (int q = 0; q < kEarlyA; ++q) piece_a(4, q);
-    if constexpr (kEarlyA == 4) adv_a();
+    early_pieces(3, 4);
+    constexpr int kEarly = (Place<PLACE>::B[0] + SH < 8) + (Place<PLACE>::B[1] + SH < 8) + (Place<PLACE>::B[2] + SH < 8) +
+                           (Place<PLACE>::B[3] + SH < 8) + (Place<PLACE>::A[0] + SH < 8) + (Place<PLACE>::A[1] + SH < 8) +
+                           (Place<PLACE>::A[2] + SH < 8) + (Place<PLACE>::A[3] + SH < 8);
     // A(0), B(0) must have landed; everything issued behind them may stay in flight
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + kEarlyB + kEarlyA) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + kEarly) : "memory");
     __builtin_amdgcn_s_barrier();
-    if constexpr (PRIO == 1) {
-      if (wave >= 4) __builtin_amdgcn_s_setprio(1);          // static priority for the younger half (arbitration loser)
-    }
     int sa = 0, sb = 1;                         // slots of A(t), B(t)
     int pa = 4, pb = 3;                         // slots the piece set opened at the previous barrier fills (A part, B part)
-    read_all(I0{}, sa, sb, ae, be);
-    wait_frags(ae, be);
 
-    const int np = p.stages;
-    for (int t = 0; t < np; ++t) {
+    // One stage.  LAST = last stage of a tile: its final quarter neither opens the next piece set (the two slots it
+    // frees first serve as the epilogue's park) nor reads the next stage's first fragments (nothing but the accumulators
+    // is to stay alive across the epilogue).
+    auto trip = [&](auto LASTC) {
+      constexpr bool LAST = decltype(LASTC)::value;
       const int sa1 = next(sa, 2), sb1 = next(sb, 2);       // slots of stage t+1
-      if constexpr (PRIO == 0) __builtin_amdgcn_s_setprio(1);
+      __builtin_amdgcn_s_setprio(1);
       // quarters 0..2 of stage t (positions 8..31 of the piece set opened at the previous barrier)
       quarter(I1{}, std::integral_constant<int, 8>{}, ae, be, ao, bo, sa, sb, pb, pa);
       wait_frags(ao, bo);
@@ -399,33 +465,69 @@ struct Kernel {
       wait_frags(ae, be);
       TN_PIN();
       quarter(I3{}, std::integral_constant<int, 24>{}, ae, be, ao, bo, sa, sb, pb, pa);
-      if constexpr (PRIO == 0) __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_s_setprio(0);
       wait_frags(ao, bo);                                 // (asm reads retired here; ROW reads by the next line)
       __builtin_amdgcn_s_waitcnt(0xc07f);                 // my reads of stage t are complete (quarter 3 is in registers)
       asm volatile("s_waitcnt vmcnt(4)" ::: "memory");    // A(t+1), B(t+1) landed; A(t+2) may still be in flight
-      __builtin_amdgcn_s_barrier();                       // stage t+1 visible; slots sa, sb free
-      if constexpr (PRIO == 0) __builtin_amdgcn_s_setprio(1);
-      // last quarter of stage t: the new piece set {B(t+2) -> slot sa, A(t+3) -> slot sb} opens (positions 0..7)
-      quarter(I0{}, I0{}, ao, bo, ae, be, sa1, sb1, sa, sb);
-      if constexpr (PRIO == 0) __builtin_amdgcn_s_setprio(0);
-      wait_frags(ae, be);
-      TN_PIN();
+      if constexpr (TN_GEMM_ABLATE != 5) __builtin_amdgcn_s_barrier();   // stage t+1 visible; slots sa, sb free
+      __builtin_amdgcn_s_setprio(1);
+      if constexpr (!LAST) {
+        // last quarter of stage t: the new piece set {B(t+2) -> slot sa, A(t+3) -> slot sb} opens (positions 0..7)
+        quarter(I0{}, I0{}, ao, bo, ae, be, sa1, sb1, sa, sb);
+        __builtin_amdgcn_s_setprio(0);
+        wait_frags(ae, be);
+        TN_PIN();
+      } else {
+#pragma unroll
+        for (int m = 0; m < 8; ++m) mma(ao, bo, m >> 1, m & 1);
+        __builtin_amdgcn_s_setprio(0);
+      }
       pb = sa;
       pa = sb;
       sa = sa1;
       sb = sb1;
-    }
-    if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(0);
+    };
 
-    epilogue(p, acc, smem + wave * 16384, m0 + wr * 128, n0 + wc * 64, lane);
+    const int np = p.stages;
+    for (int kc = 0; kc < mine; ++kc) {
+      read_all(I0{}, sa, sb, ae, be);
+      wait_frags(ae, be);
+      TN_PIN();
+      for (int t = 1; t < np; ++t) trip(std::false_type{});
+      trip(std::true_type{});
+      // Epilogue.  The streams are already inside the next tile (its stage 0 and A(1) are in the other three slots);
+      // the two slots the last barrier freed (now pb / pa) are the park, then they take their deferred pieces.
+      int m0, n0;
+      origin(kc, m0, n0);
+      if constexpr (TN_GEMM_ABLATE != 4)
+        epilogue(p, acc, smem + (wave < 4 ? pb : pa) * SLOT + (wave & 3) * 8192, m0 + wr * 128, n0 + wc * 64, lane);
+      zero_acc();
+      __builtin_amdgcn_s_waitcnt(0xc07f);               // my park reads are done ...
+      __builtin_amdgcn_s_barrier();                     // ... and everybody's: the slots may be refilled
+      // lane constants are re-derived from an opaque copy of the lane id: the compiler must not carry (spill) the old
+      // ones across the epilogue
+      asm volatile("" : "+v"(lane));
+      ra = Reader<AK, 4>(lane, wr * 128);
+      rb = Reader<BK, 2>(lane, wc * 64);
+      sA.set_voff(wave, lane);
+      sB.set_voff(wave, lane);
+      early_pieces(pb, pa);
+    }
   }
 
-  // Epilogue through LDS: the wave parks its 128 x 64 tile in its own XOR-swizzled LDS region ([128 rows][64 cols]
-  // bf16, 128-byte rows, chunk ^= row & 7) and writes full 128-byte lines.
+  static __device__ __forceinline__ void run(const Params& p, char* smem) {
+    if constexpr (ASYM) {
+      if (__builtin_amdgcn_readfirstlane(threadIdx.x) < 256) body<0>(p, smem);
+      else body<1>(p, smem);
+    } else {
+      body<0>(p, smem);
+    }
+  }
+
+  // Epilogue through LDS: the wave parks its 128 x 64 tile, 64 rows at a time, in its own XOR-swizzled 8 KB
+  // ([64 rows][64 cols] bf16, 128-byte rows, chunk ^= row & 7) and writes full 128-byte lines.
   static __device__ __forceinline__ void epilogue(const Params& p, Acc& acc, char* park, int wm0, int wn0, int lane) {
     const int l31 = lane & 31, hi = lane >> 5;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the dead tail DMAs must not land on the parked tile
-    __builtin_amdgcn_s_barrier();
     float bias_v[2][4][4];
     if (p.bias != nullptr) {
 #pragma unroll
@@ -440,108 +542,118 @@ struct Kernel {
           bias_v[j][g][3] = __uint_as_float(w.y & 0xffff0000u);
         }
     }
-    // result rows (registers) = n, result column (lane) = m: 4 consecutive n per register quad -> 8-byte packs
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = i * 32 + l31;
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          float v[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] + (p.bias != nullptr ? bias_v[j][g][e] : 0.f);
-          const int chunk = (j * 4 + g) ^ (row & 7);
-          *reinterpret_cast<uint2*>(park + row * 128 + chunk * 16 + hi * 8) =
-              make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
-        }
-    }
-    // (only this wave touches its park region: a wave-level wait is enough)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const bool acc_c = p.accumulate != 0;
-#pragma unroll 4
-    for (int it = 0; it < 16; ++it) {
-      const int row = it * 8 + (lane >> 3), c = lane & 7;
-      uint4 v = *reinterpret_cast<const uint4*>(park + row * 128 + ((c ^ (row & 7)) << 4));
-      const int m = wm0 + row, n = wn0 + c * 8;
-      if (m < p.M && n < p.N) {                            // N is a multiple of 8 (checked by the host)
-        bf16_t* dst = p.C + (long long)m * p.ldc + n;
-        if (acc_c) {
-          Vec16<bf16_t> o, nw;
-          o.load(dst);
-          nw.raw = v;
-          float fo[8], fn[8];
-          o.unpack(fo);
-          nw.unpack(fn);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) fn[e] += fo[e];
-          nw.pack(fn);
-          v = nw.raw;
-        }
-        *reinterpret_cast<uint4*>(dst) = v;
+    for (int half = 0; half < 2; ++half) {
+      // result rows (registers) = n, result column (lane) = m: 4 consecutive n per register quad -> 8-byte packs
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii) {
+        const int i = half * 2 + ii;
+        const int row = ii * 32 + l31;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] + (p.bias != nullptr ? bias_v[j][g][e] : 0.f);
+            const int chunk = (j * 4 + g) ^ (row & 7);
+            // (vector-typed LDS accesses: hipcc puts `s_waitcnt vmcnt(0)` in front of an LDS access without alias
+            //  metadata while an LDS-DMA is pending — here the next tile's prefetched stages)
+            const u32x2_t pk = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+            *reinterpret_cast<u32x2_t*>(park + row * 128 + chunk * 16 + hi * 8) = pk;
+          }
       }
-    }
-    if constexpr (HAS_CT) {
-      // transposed copy: Ct[n, m]; a lane gathers 8 consecutive m of one n from the parked tile (2-byte LDS reads:
-      // this path trades LDS instructions for the HBM round trip of a separate transpose pass)
-#pragma unroll 2
-      for (int it = 0; it < 16; ++it) {
-        const int n_l = it * 4 + (lane >> 4), mg = lane & 15;       // 64 n x 16 groups of 8 m
-        uint32_t w[4];
+      // (only this wave touches its park region: a wave-level wait is enough; LDS operations of one wave execute in
+      //  order, so the next half's stores cannot overtake this half's reads)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll 4
+      for (int it = 0; it < 8; ++it) {
+        const int row = it * 8 + (lane >> 3), c = lane & 7;
+        const u32x4_t pv = *reinterpret_cast<const u32x4_t*>(park + row * 128 + ((c ^ (row & 7)) << 4));
+        uint4 v = make_uint4(pv.x, pv.y, pv.z, pv.w);
+        const int m = wm0 + half * 64 + row, n = wn0 + c * 8;
+        if (m < p.M && n < p.N) {                            // N is a multiple of 8 (checked by the host)
+          bf16_t* dst = p.C + (long long)m * p.ldc + n;
+          if (acc_c) {
+            Vec16<bf16_t> o, nw;
+            o.load(dst);
+            nw.raw = v;
+            float fo[8], fn[8];
+            o.unpack(fo);
+            nw.unpack(fn);
 #pragma unroll
-        for (int e2 = 0; e2 < 4; ++e2) {
-          uint32_t lo, hi16;
-          {
-            const int row = mg * 8 + 2 * e2;
-            lo = *reinterpret_cast<const uint16_t*>(park + row * 128 + ((((n_l >> 3) ^ (row & 7))) << 4) + (n_l & 7) * 2);
+            for (int e = 0; e < 8; ++e) fn[e] += fo[e];
+            nw.pack(fn);
+            v = nw.raw;
           }
-          {
-            const int row = mg * 8 + 2 * e2 + 1;
-            hi16 = *reinterpret_cast<const uint16_t*>(park + row * 128 + ((((n_l >> 3) ^ (row & 7))) << 4) + (n_l & 7) * 2);
-          }
-          w[e2] = lo | (hi16 << 16);
+          *reinterpret_cast<uint4*>(dst) = v;
         }
-        const int n = wn0 + n_l, m = wm0 + mg * 8;
-        if (n < p.N && m < p.M)     // M is a multiple of 8 when a transposed copy is requested (host check)
-          *reinterpret_cast<uint4*>(p.Ct + (long long)n * p.ldct + m) = make_uint4(w[0], w[1], w[2], w[3]);
+      }
+      if constexpr (HAS_CT) {
+        // transposed copy: Ct[n, m]; a lane gathers 8 consecutive m of one n from the parked half tile (2-byte LDS
+        // reads: this path trades LDS instructions for the HBM round trip of a separate transpose pass)
+#pragma unroll 2
+        for (int it = 0; it < 8; ++it) {
+          const int n_l = it * 8 + (lane >> 3), mg = lane & 7;       // 64 n x 8 groups of 8 m
+          uint32_t w[4];
+#pragma unroll
+          for (int e2 = 0; e2 < 4; ++e2) {
+            uint32_t lo, hi16;
+            {
+              const int row = mg * 8 + 2 * e2;
+              lo = *reinterpret_cast<const uint16_t*>(park + row * 128 + ((((n_l >> 3) ^ (row & 7))) << 4) + (n_l & 7) * 2);
+            }
+            {
+              const int row = mg * 8 + 2 * e2 + 1;
+              hi16 = *reinterpret_cast<const uint16_t*>(park + row * 128 + ((((n_l >> 3) ^ (row & 7))) << 4) + (n_l & 7) * 2);
+            }
+            w[e2] = lo | (hi16 << 16);
+          }
+          const int n = wn0 + n_l, m = wm0 + half * 64 + mg * 8;
+          if (n < p.N && m < p.M)     // M is a multiple of 8 when a transposed copy is requested (host check)
+            *reinterpret_cast<uint4*>(p.Ct + (long long)n * p.ldct + m) = make_uint4(w[0], w[1], w[2], w[3]);
+        }
       }
     }
   }
 };
 
-template <bool AK, bool BK, int PLACE, int PRIO, int ILV, bool HAS_CT>
+template <bool AK, bool BK, int PLACE, int ASYM, int ILV, bool HAS_CT>
 __global__ __launch_bounds__(NT, 2) void gemm_kernel(const Params p) {
   __shared__ __attribute__((aligned(1024))) char smem[LDS_BYTES];
-  Kernel<AK, BK, PLACE, PRIO, ILV, HAS_CT>::run(p, smem);
+  Kernel<AK, BK, PLACE, ASYM, ILV, HAS_CT>::run(p, smem);
 }
 
-// kernel-development switch: TN_GEMM_VARIANT = 100 * PLACE + 10 * PRIO + ILV (scripts/gemm_bench.py sweeps it)
+// kernel-development switch: TN_GEMM_VARIANT = 100 * PLACE + 10 * ASYM + ILV (scripts/gemm_sweep.py sweeps it)
 #ifndef TN_GEMM_DEFAULT_VARIANT
-#define TN_GEMM_DEFAULT_VARIANT 0
+#define TN_GEMM_DEFAULT_VARIANT 101
 #endif
 
 template <bool AK, bool BK, bool HAS_CT>
 static int launch_variant(int variant, dim3 grid, hipStream_t st, const Params& p) {
-#define TN_V(PL, PR, IL)                                                                             \
-  case 100 * PL + 10 * PR + IL:                                                                      \
-    hipLaunchKernelGGL((gemm_kernel<AK, BK, PL, PR, IL, HAS_CT>), grid, dim3(NT), 0, st, p);         \
+#define TN_V(PL, AS, IL)                                                                             \
+  case 100 * PL + 10 * AS + IL:                                                                      \
+    hipLaunchKernelGGL((gemm_kernel<AK, BK, PL, AS, IL, HAS_CT>), grid, dim3(NT), 0, st, p);         \
     return 0;
-  constexpr int DPL = TN_GEMM_DEFAULT_VARIANT / 100, DPR = (TN_GEMM_DEFAULT_VARIANT / 10) % 10,
+  constexpr int DPL = TN_GEMM_DEFAULT_VARIANT / 100, DAS = (TN_GEMM_DEFAULT_VARIANT / 10) % 10,
                 DIL = TN_GEMM_DEFAULT_VARIANT % 10;
 #ifdef TN_GEMM_ALL_VARIANTS
   if constexpr (!HAS_CT) {
     switch (variant) {
-      TN_V(0, 0, 0) TN_V(0, 1, 0) TN_V(0, 2, 0) TN_V(0, 0, 1) TN_V(0, 1, 1)
-      TN_V(1, 0, 0) TN_V(1, 1, 0) TN_V(1, 0, 1) TN_V(1, 1, 1)
-      TN_V(2, 0, 0) TN_V(2, 1, 0) TN_V(2, 0, 1) TN_V(2, 1, 1)
-      TN_V(3, 0, 0) TN_V(3, 1, 0) TN_V(3, 0, 1) TN_V(3, 1, 1)
+      TN_V(0, 0, 0) TN_V(0, 0, 1)
+      TN_V(1, 0, 0) TN_V(1, 0, 1) TN_V(1, 1, 0) TN_V(1, 1, 1)
+      TN_V(3, 0, 1) TN_V(3, 1, 1)
+      TN_V(4, 0, 1) TN_V(4, 1, 1)
+      TN_V(5, 0, 1) TN_V(5, 1, 1)
+      TN_V(6, 0, 1) TN_V(6, 1, 1)
       default:
         return -1;
     }
   }
 #endif
   (void)variant;
-  hipLaunchKernelGGL((gemm_kernel<AK, BK, DPL, DPR, DIL, HAS_CT>), grid, dim3(NT), 0, st, p);
+  hipLaunchKernelGGL((gemm_kernel<AK, BK, DPL, DAS, DIL, HAS_CT>), grid, dim3(NT), 0, st, p);
   return 0;
 #undef TN_V
 }
@@ -602,7 +714,16 @@ int tn_gemm_bf16(const void* const* A, const void* const* B, const long long* ld
   p.accumulate = accumulate;
   p.nbm = (M + BM - 1) / BM;
   p.nbn = (N + BN - 1) / BN;
-  const dim3 grid(p.nbm * p.nbn);
+  // persistent: one workgroup per CU walks its tiles (TN_GEMM_PERSIST=0: one workgroup per tile, kernel-development A/B)
+  static const int ncu = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n >= 8 ? n / 8 * 8 : 8;
+  }();
+  const char* pe = getenv("TN_GEMM_PERSIST");
+  const bool persist = pe ? atoi(pe) != 0 : true;
+  const int tiles = p.nbm * p.nbn;
+  const dim3 grid(persist && tiles > ncu ? ncu : tiles);
   hipStream_t st = (hipStream_t)stream;
   const char* e = getenv("TN_GEMM_VARIANT");     // kernel-development A/B switch (read per call: the sweep changes it)
   const int variant = e ? atoi(e) : TN_GEMM_DEFAULT_VARIANT;
