@@ -625,22 +625,440 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const Params p) {
   Kernel<AK, BK, PLACE, ASYM, ILV, HAS_CT>::run(p, smem);
 }
 
+// =====================================================================================================================
+// Half-stage ring (variants 1000 + PLACE32): the same tile, operands and fragment maths, but K is consumed in 32-deep
+// HALF stages and the 160 KB of LDS are a ring of FIVE (A, B) pairs of 16 KB half-slots.  The barrier of half-stage h
+// frees pair h, which takes pair h + 5; pairs h+2 .. h+4 are under way meanwhile: every operand is issued 4 half-stages
+// = TWO full stages before it is due (the 64-deep ring gives B(t+2) one stage), and a wave issues one piece every 4
+// MFMAs without pause instead of 8 pieces per 32 MFMAs behind one barrier.
+//      wait at the barrier of half-stage h, in flight oldest first: pair h+1 | h+2, h+3, h+4 -> vmcnt(12)
+//   ROW   half image [256 r][64 B] : 16-byte chunk c of row r in slot c ^ ((r >> 2) & 3) (a 256-byte bank row holds 4
+//         tile rows; the 16 lanes of a ds_read_b128 service group see 16 different (row & 3, slot) pairs); a DMA piece is
+//         16 rows x 64 B (half lines: the L2 request granule is 64 B, TCC_REQ counts say so)
+//   KMAJ  half image [32 k][512 B] : as the 64-deep image
+// =====================================================================================================================
+constexpr int HSLOT = 16384;
+
+template <int PLACE32> struct Place32;     // positions 0..15 behind the barrier: two B pieces, then two A pieces
+template <> struct Place32<0> { static constexpr int B[2] = {0, 4}, A[2] = {8, 12}; };
+template <> struct Place32<1> { static constexpr int B[2] = {0, 2}, A[2] = {4, 6}; };
+template <> struct Place32<2> { static constexpr int B[2] = {1, 5}, A[2] = {9, 13}; };
+template <> struct Place32<3> { static constexpr int B[2] = {2, 6}, A[2] = {10, 14}; };
+
+template <int PLACE32, bool IS_A> constexpr int piece32_at(int pos) {
+  for (int i = 0; i < 2; ++i)
+    if ((IS_A ? Place32<PLACE32>::A[i] : Place32<PLACE32>::B[i]) == pos) return i;
+  return -1;
+}
+
+template <bool KMAJ>
+struct Stream32 {
+  __amdgpu_buffer_rsrc_t rs;
+  int soff, step, left, seg, ld2;
+  int voff[2];   // per-lane byte offsets of this wave's 2 pieces
+
+  __device__ __forceinline__ void set_voff(int wave, int lane) {
+    if constexpr (!KMAJ) {
+      // piece q = rows 32 wave + 16 q + (lane >> 2); the lane's slot lane & 3 holds chunk (lane & 3) ^ ((row >> 2) & 3)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int row = wave * 32 + q * 16 + (lane >> 2);
+        voff[q] = (TN_GEMM_ABLATE == 6 ? (row & 7) : row) * ld2 + (((lane & 3) ^ ((row >> 2) & 3)) << 4);
+      }
+    } else {
+      // piece q = k-rows 4 wave + 2 q + (lane >> 5) of the half stage
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int k = wave * 4 + q * 2 + (lane >> 5);
+        const int u = lane & 31;
+        voff[q] = (TN_GEMM_ABLATE == 6 ? (k & 1) : k) * ld2 + ((((u >> 2) ^ (k & 3)) << 6) | ((u & 3) << 4));
+      }
+    }
+  }
+  __device__ __forceinline__ void open(const bf16_t* X, long long ld, int K, int R, int origin, int wave, int lane) {
+    ld2 = (int)(ld * 2);
+    if constexpr (!KMAJ) {
+      const long long bytes = (long long)(R - origin) * ld2;
+      rs = __builtin_amdgcn_make_buffer_rsrc((void*)(X + (long long)origin * ld), 0, (int)min(bytes, 0x7fffffffLL),
+                                             0x00020000);
+      step = 64;
+    } else {
+      const long long bytes = ((long long)(K - 1) * ld + (R - origin)) * 2;
+      rs = __builtin_amdgcn_make_buffer_rsrc((void*)(X + origin), 0, (int)min(bytes, 0x7fffffffLL), 0x00020000);
+      step = 32 * ld2;
+    }
+    set_voff(wave, lane);
+    soff = 0;
+    left = K >> 5;
+  }
+  __device__ __forceinline__ void kill(const void* any) {
+    rs = __builtin_amdgcn_make_buffer_rsrc((void*)any, 0, 0, 0x00020000);
+    soff = 0;
+    step = 0;
+    left = 0x7fffffff;
+  }
+};
+
+template <bool AK, bool BK, int PLACE32, bool HAS_CT>
+struct Kernel32 {
+  template <bool KMAJ, int NB>
+  struct Reader {
+    int x[4];
+    __device__ __forceinline__ Reader(int lane, int row0) {
+      const int l31 = lane & 31, hi = lane >> 5;
+      if constexpr (!KMAJ) {
+        const int f = (l31 >> 2) & 3;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) x[q] = (row0 + l31) * 64 + (((2 * q + hi) ^ f) << 4);
+        x[2] = x[3] = 0;
+      } else {
+        const int s4 = lane & 15, j = s4 >> 2, w = s4 & 3, half = (lane >> 4) & 1;
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          x[b] = (8 * hi + j) * 512 + half * 32 + w * 8 + ((((row0 >> 5) + (b < NB ? b : 0)) ^ j) << 6);
+      }
+    }
+    template <int Q, int B>
+    __device__ __forceinline__ void read(const char* smem, int sbase, Frags<KMAJ, NB>& f) const {
+      if constexpr (!KMAJ) {
+        f.v[B] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(smem + sbase + x[Q] + B * 2048));
+      } else {
+        const uint32_t a = (uint32_t)(size_t)(lds_ptr_t)smem + (uint32_t)(sbase + x[B]);
+        f.h[B][0] = ds_tr16<(16 * Q) * 512>(a);
+        f.h[B][1] = ds_tr16<(16 * Q + 4) * 512>(a);
+      }
+    }
+  };
+
+  using K64 = Kernel<AK, BK, 0, 0, 1, HAS_CT>;       // (wait_frags is shared)
+
+  static __device__ __forceinline__ void run(const Params& p, char* smem) {
+    const int tid = threadIdx.x;
+    int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    const int bid = blockIdx.x, G = gridDim.x;
+    const int mine = (p.nbm * p.nbn - bid + G - 1) / G;
+    auto origin = [&](int k, int& m0, int& n0) {
+      int tm, tn;
+      tile_of_block(bid + k * G, p.nbm, p.nbn, tm, tn);
+      m0 = tm * BM;
+      n0 = tn * BN;
+    };
+
+    Stream32<AK> sA;
+    Stream32<BK> sB;
+    int ka = 0, kb = 0;
+    auto open_a = [&](int s) {
+      int m0, n0;
+      origin(ka, m0, n0);
+      sA.open(p.seg[s].A, p.seg[s].lda, p.seg[s].K, p.M, m0, wave, lane);
+      sA.seg = s;
+    };
+    auto open_b = [&](int s) {
+      int m0, n0;
+      origin(kb, m0, n0);
+      sB.open(p.seg[s].B, p.seg[s].ldb, p.seg[s].K, p.N, n0, wave, lane);
+      sB.seg = s;
+    };
+    auto adv_a = [&]() {
+      sA.soff += sA.step;
+      if (--sA.left == 0) {
+        if (sA.seg + 1 < p.nseg) open_a(sA.seg + 1);
+        else if (++ka < mine) open_a(0);
+        else sA.kill(p.C);
+      }
+    };
+    auto adv_b = [&]() {
+      sB.soff += sB.step;
+      if (--sB.left == 0) {
+        if (sB.seg + 1 < p.nseg) open_b(sB.seg + 1);
+        else if (++kb < mine) open_b(0);
+        else sB.kill(p.C);
+      }
+    };
+    // pair slot `pr`: A half at pr * 32 KB, B half 16 KB behind it; this wave's pieces 2 wave, 2 wave + 1
+    auto piece_a = [&](int pr, int q) {
+      if constexpr (TN_GEMM_ABLATE != 1)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(sA.rs, (lds_ptr_t)(smem + pr * SLOT + wave * 2048 + q * 1024), 16,
+                                                 sA.voff[q], sA.soff, 0, 0);
+      if (q == 1) adv_a();
+    };
+    auto piece_b = [&](int pr, int q) {
+      if constexpr (TN_GEMM_ABLATE != 1)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(sB.rs, (lds_ptr_t)(smem + pr * SLOT + HSLOT + wave * 2048 + q * 1024),
+                                                 16, sB.voff[q], sB.soff, 0, 0);
+      if (q == 1) adv_b();
+    };
+    open_a(0);
+    open_b(0);
+
+    Reader<AK, 4> ra(lane, wr * 128);
+    Reader<BK, 2> rb(lane, wc * 64);
+
+    Acc acc;
+    auto zero_acc = [&]() {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    };
+    zero_acc();
+
+    Frags<AK, 4> ae, ao;
+    Frags<BK, 2> be, bo;
+
+    auto read_frag = [&](auto QC, auto FC, int pr, Frags<AK, 4>& a, Frags<BK, 2>& b) {
+      constexpr int Q = decltype(QC)::value, F = decltype(FC)::value;
+      if constexpr (F < 2) rb.template read<Q, F>(smem, pr * SLOT + HSLOT, b);
+      else ra.template read<Q, F - 2>(smem, pr * SLOT, a);
+    };
+    auto read_all = [&](auto QC, int pr, Frags<AK, 4>& a, Frags<BK, 2>& b) {
+      read_frag(QC, std::integral_constant<int, 0>{}, pr, a, b);
+      read_frag(QC, std::integral_constant<int, 1>{}, pr, a, b);
+      read_frag(QC, std::integral_constant<int, 2>{}, pr, a, b);
+      read_frag(QC, std::integral_constant<int, 3>{}, pr, a, b);
+      read_frag(QC, std::integral_constant<int, 4>{}, pr, a, b);
+      read_frag(QC, std::integral_constant<int, 5>{}, pr, a, b);
+    };
+    auto mma = [&](const Frags<AK, 4>& a, const Frags<BK, 2>& b, int i, int j) {
+#if TN_GEMM_ABLATE == 3
+      asm volatile("" ::"v"(a.v[i]), "v"(b.v[j]));
+#else
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b.v[j], a.v[i], acc[i][j], 0, 0, 0);
+#endif
+    };
+    // 8 MFMAs of (ca, cb); the fragments of 16-deep step NQ of pair `npr` are read one behind each of the first six
+    // MFMAs; the pieces the table puts at positions P0 .. P0 + 7 go behind their MFMA into pair `dst` (P0 < 0: none;
+    // NQ < 0: no reads)
+    auto quarter = [&](auto NQC, auto P0C, const Frags<AK, 4>& ca, const Frags<BK, 2>& cb, Frags<AK, 4>& na,
+                       Frags<BK, 2>& nb, int npr, int dst) {
+      constexpr int P0 = decltype(P0C)::value, NQ = decltype(NQC)::value;
+      auto step = [&](auto MC) {
+        constexpr int m = decltype(MC)::value;
+        mma(ca, cb, m >> 1, m & 1);
+        TN_PIN();
+        if constexpr (NQ >= 0 && m < 6 && TN_GEMM_ABLATE != 2) {
+          read_frag(std::integral_constant<int, (NQ < 0 ? 0 : NQ)>{}, std::integral_constant<int, m>{}, npr, na, nb);
+          TN_PIN();
+        }
+        constexpr int pb = P0 < 0 ? -1 : piece32_at<PLACE32, false>(P0 + m);
+        constexpr int pa = P0 < 0 ? -1 : piece32_at<PLACE32, true>(P0 + m);
+        if constexpr (pb >= 0) {
+          piece_b(dst, pb);
+          TN_PIN();
+        }
+        if constexpr (pa >= 0) {
+          piece_a(dst, pa);
+          TN_PIN();
+        }
+      };
+      step(std::integral_constant<int, 0>{});
+      step(std::integral_constant<int, 1>{});
+      step(std::integral_constant<int, 2>{});
+      step(std::integral_constant<int, 3>{});
+      step(std::integral_constant<int, 4>{});
+      step(std::integral_constant<int, 5>{});
+      step(std::integral_constant<int, 6>{});
+      step(std::integral_constant<int, 7>{});
+    };
+    auto early_pieces = [&](int dst) {
+      auto one = [&](auto MC) {
+        constexpr int m = decltype(MC)::value;
+        constexpr int pb = piece32_at<PLACE32, false>(m), pa = piece32_at<PLACE32, true>(m);
+        if constexpr (pb >= 0) piece_b(dst, pb);
+        if constexpr (pa >= 0) piece_a(dst, pa);
+      };
+      one(std::integral_constant<int, 0>{});
+      one(std::integral_constant<int, 1>{});
+      one(std::integral_constant<int, 2>{});
+      one(std::integral_constant<int, 3>{});
+      one(std::integral_constant<int, 4>{});
+      one(std::integral_constant<int, 5>{});
+      one(std::integral_constant<int, 6>{});
+      one(std::integral_constant<int, 7>{});
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using NONE = std::integral_constant<int, -1>;
+
+    // prologue: pairs 0..3 whole, then the positions < 8 of the set "opened at the barrier of half-stage -1" = pair 4
+#pragma unroll
+    for (int pr = 0; pr < 4; ++pr) {
+      piece_a(pr, 0);
+      piece_a(pr, 1);
+      piece_b(pr, 0);
+      piece_b(pr, 1);
+    }
+    early_pieces(4);
+    constexpr int kEarly = (Place32<PLACE32>::B[0] < 8) + (Place32<PLACE32>::B[1] < 8) + (Place32<PLACE32>::A[0] < 8) +
+                           (Place32<PLACE32>::A[1] < 8);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(12 + kEarly) : "memory");     // pair 0 landed
+    __builtin_amdgcn_s_barrier();
+    int pr = 0;          // pair slot of the current half-stage
+    int pf = 4;          // pair slot the set opened at the previous barrier fills
+
+    auto trip = [&](auto LASTC) {
+      constexpr bool LAST = decltype(LASTC)::value;
+      const int pn = pr == 4 ? 0 : pr + 1;
+      __builtin_amdgcn_s_setprio(1);
+      quarter(I1{}, std::integral_constant<int, 8>{}, ae, be, ao, bo, pr, pf);       // 16-deep step 0
+      __builtin_amdgcn_s_setprio(0);
+      K64::wait_frags(ao, bo);
+      __builtin_amdgcn_s_waitcnt(0xc07f);                 // my reads of this half-stage are complete
+      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // pair h+1 landed; h+2 .. h+4 may be in flight
+      if constexpr (TN_GEMM_ABLATE != 5) __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_setprio(1);
+      if constexpr (!LAST) {
+        quarter(I0{}, I0{}, ao, bo, ae, be, pn, pr);      // 16-deep step 1; the freed pair takes pair h+5
+        __builtin_amdgcn_s_setprio(0);
+        K64::wait_frags(ae, be);
+        TN_PIN();
+      } else {
+        quarter(NONE{}, NONE{}, ao, bo, ae, be, pn, pr);
+        __builtin_amdgcn_s_setprio(0);
+      }
+      pf = pr;
+      pr = pn;
+    };
+
+    const int np = p.stages;                              // HALF stages here
+    for (int kc = 0; kc < mine; ++kc) {
+      read_all(I0{}, pr, ae, be);
+      K64::wait_frags(ae, be);
+      TN_PIN();
+      for (int t = 1; t < np; ++t) trip(std::false_type{});
+      trip(std::true_type{});
+      int m0, n0;
+      origin(kc, m0, n0);
+      if constexpr (TN_GEMM_ABLATE != 4)
+        epilogue32(p, acc, smem + pf * SLOT + wave * 4096, m0 + wr * 128, n0 + wc * 64, lane);
+      zero_acc();
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" : "+v"(lane));
+      ra = Reader<AK, 4>(lane, wr * 128);
+      rb = Reader<BK, 2>(lane, wc * 64);
+      sA.set_voff(wave, lane);
+      sB.set_voff(wave, lane);
+      early_pieces(pf);
+    }
+  }
+
+  // Epilogue through LDS, 32 rows at a time: the wave parks [32 rows][64 cols] bf16 (4 KB, chunk ^= row & 7) in its
+  // share of the pair the last barrier freed and writes full 128-byte lines.
+  static __device__ __forceinline__ void epilogue32(const Params& p, Acc& acc, char* park, int wm0, int wn0, int lane) {
+    const int l31 = lane & 31, hi = lane >> 5;
+    float bias_v[2][4][4];
+    if (p.bias != nullptr) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n = min(wn0 + j * 32 + 8 * g + 4 * hi, p.N - 4);
+          const uint2 w = *reinterpret_cast<const uint2*>(p.bias + n);
+          bias_v[j][g][0] = __uint_as_float(w.x << 16);
+          bias_v[j][g][1] = __uint_as_float(w.x & 0xffff0000u);
+          bias_v[j][g][2] = __uint_as_float(w.y << 16);
+          bias_v[j][g][3] = __uint_as_float(w.y & 0xffff0000u);
+        }
+    }
+    const bool acc_c = p.accumulate != 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = l31;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] + (p.bias != nullptr ? bias_v[j][g][e] : 0.f);
+          const int chunk = (j * 4 + g) ^ (row & 7);
+          const u32x2_t pk = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+          *reinterpret_cast<u32x2_t*>(park + row * 128 + chunk * 16 + hi * 8) = pk;
+        }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int r = it * 8 + (lane >> 3), c = lane & 7;
+        const u32x4_t pv = *reinterpret_cast<const u32x4_t*>(park + r * 128 + ((c ^ (r & 7)) << 4));
+        uint4 v = make_uint4(pv.x, pv.y, pv.z, pv.w);
+        const int m = wm0 + i * 32 + r, n = wn0 + c * 8;
+        if (m < p.M && n < p.N) {
+          bf16_t* dst = p.C + (long long)m * p.ldc + n;
+          if (acc_c) {
+            Vec16<bf16_t> o, nw;
+            o.load(dst);
+            nw.raw = v;
+            float fo[8], fn[8];
+            o.unpack(fo);
+            nw.unpack(fn);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) fn[e] += fo[e];
+            nw.pack(fn);
+            v = nw.raw;
+          }
+          *reinterpret_cast<uint4*>(dst) = v;
+        }
+      }
+      if constexpr (HAS_CT) {
+        // transposed copy: Ct[n, m]: a lane gathers 8 consecutive m of one n (64 n x 4 groups of 8 m per pass)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int n_l = it * 16 + (lane >> 2), mg = lane & 3;
+          uint32_t w[4];
+#pragma unroll
+          for (int e2 = 0; e2 < 4; ++e2) {
+            const int r0 = mg * 8 + 2 * e2, r1 = r0 + 1;
+            const uint32_t lo =
+                *reinterpret_cast<const uint16_t*>(park + r0 * 128 + ((((n_l >> 3) ^ (r0 & 7))) << 4) + (n_l & 7) * 2);
+            const uint32_t hi16 =
+                *reinterpret_cast<const uint16_t*>(park + r1 * 128 + ((((n_l >> 3) ^ (r1 & 7))) << 4) + (n_l & 7) * 2);
+            w[e2] = lo | (hi16 << 16);
+          }
+          const int n = wn0 + n_l, m = wm0 + i * 32 + mg * 8;
+          if (n < p.N && m < p.M)
+            *reinterpret_cast<uint4*>(p.Ct + (long long)n * p.ldct + m) = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+      }
+    }
+  }
+};
+
+template <bool AK, bool BK, int PLACE32, bool HAS_CT>
+__global__ __launch_bounds__(NT, 2) void gemm32_kernel(const Params p) {
+  __shared__ __attribute__((aligned(1024))) char smem[LDS_BYTES];
+  Kernel32<AK, BK, PLACE32, HAS_CT>::run(p, smem);
+}
+
 // kernel-development switch: TN_GEMM_VARIANT = 100 * PLACE + 10 * ASYM + ILV (scripts/gemm_sweep.py sweeps it)
 #ifndef TN_GEMM_DEFAULT_VARIANT
 #define TN_GEMM_DEFAULT_VARIANT 101
 #endif
 
 template <bool AK, bool BK, bool HAS_CT>
-static int launch_variant(int variant, dim3 grid, hipStream_t st, const Params& p) {
+static int launch_variant(int variant, dim3 grid, hipStream_t st, Params p) {
+  const int stages64 = p.stages;
+  p.stages = 2 * stages64;                     // (the half-stage ring counts 32-deep stages; reset below for the others)
 #define TN_V(PL, AS, IL)                                                                             \
   case 100 * PL + 10 * AS + IL:                                                                      \
+    p.stages = stages64;                                                                             \
     hipLaunchKernelGGL((gemm_kernel<AK, BK, PL, AS, IL, HAS_CT>), grid, dim3(NT), 0, st, p);         \
     return 0;
-  constexpr int DPL = TN_GEMM_DEFAULT_VARIANT / 100, DAS = (TN_GEMM_DEFAULT_VARIANT / 10) % 10,
+  constexpr int DPL = (TN_GEMM_DEFAULT_VARIANT % 1000) / 100, DAS = (TN_GEMM_DEFAULT_VARIANT / 10) % 10,
                 DIL = TN_GEMM_DEFAULT_VARIANT % 10;
+#define TN_V32(PL)                                                                                   \
+  case 1000 + PL:                                                                                    \
+    hipLaunchKernelGGL((gemm32_kernel<AK, BK, PL, HAS_CT>), grid, dim3(NT), 0, st, p);               \
+    return 0;
 #ifdef TN_GEMM_ALL_VARIANTS
   if constexpr (!HAS_CT) {
     switch (variant) {
+      TN_V32(0) TN_V32(1) TN_V32(2) TN_V32(3)
       TN_V(0, 0, 0) TN_V(0, 0, 1)
       TN_V(1, 0, 0) TN_V(1, 0, 1) TN_V(1, 1, 0) TN_V(1, 1, 1)
       TN_V(3, 0, 1) TN_V(3, 1, 1)
@@ -653,9 +1071,15 @@ static int launch_variant(int variant, dim3 grid, hipStream_t st, const Params& 
   }
 #endif
   (void)variant;
-  hipLaunchKernelGGL((gemm_kernel<AK, BK, DPL, DAS, DIL, HAS_CT>), grid, dim3(NT), 0, st, p);
+  if constexpr (TN_GEMM_DEFAULT_VARIANT >= 1000)
+    hipLaunchKernelGGL((gemm32_kernel<AK, BK, TN_GEMM_DEFAULT_VARIANT - 1000, HAS_CT>), grid, dim3(NT), 0, st, p);
+  else {
+    p.stages = stages64;
+    hipLaunchKernelGGL((gemm_kernel<AK, BK, DPL, DAS, DIL, HAS_CT>), grid, dim3(NT), 0, st, p);
+  }
   return 0;
 #undef TN_V
+#undef TN_V32
 }
 
 }  // namespace gemm
