@@ -679,9 +679,10 @@ def test_linear_group_matches_autograd(M, K, Ns, bias, wtn):
 
 
 def test_linear_layers_on_the_hand_written_gemm_match_the_library(monkeypatch):
-    """TN_LINEAR_GEMM=own (`bench.py --linear-gemm own`): every forward-layout product of linear_group and of the fused
-    SwiGLU MLP node runs on csrc/gemm.hip instead of hipBLASLt.  Same bf16 inputs, fp32 accumulation in both: outputs
-    and all gradients agree to bf16 rounding of differently ordered sums, and the kernel really is the one that ran."""
+    """TN_LINEAR_GEMM=own (`bench.py --linear-gemm own`): every product of linear_group and of the fused SwiGLU MLP node —
+    forward, input gradient, weight gradient — runs on csrc/gemm.hip in its native operand mode instead of hipBLASLt on
+    transposed copies.  Same bf16 inputs, fp32 accumulation in both: outputs and all gradients agree to bf16 rounding of
+    differently ordered sums, the kernel really is the one that ran, and no transpose pass is left."""
     F = _f()
     from touchnet_amd import _C
     g = torch.Generator(device="cpu").manual_seed(5)
@@ -695,10 +696,11 @@ def test_linear_layers_on_the_hand_written_gemm_match_the_library(monkeypatch):
 
     def run(mode):
         monkeypatch.setattr(F, "LINEAR_GEMM", mode)
+        monkeypatch.setattr(F, "_OWN_MIN_TILES", 1)        # (test sizes have a handful of tiles)
         calls = []
-        real = _C.lib().tn_gemm_bf16_tn
-        if mode == "own":
-            monkeypatch.setattr(F, "gemm_tn", lambda *a, **k: (calls.append(1), _orig(*a, **k))[1])
+        monkeypatch.setattr(F, "gemm", lambda *a, **k: (calls.append((len(a[0]), a[1:], tuple(k))), _orig(*a, **k))[1])
+        tr = []
+        monkeypatch.setattr(F, "transpose_2d", lambda *a, **k: (tr.append(1), _orig_t(*a, **k))[1])
         xx = x.clone().requires_grad_()
         ww = [w.clone().requires_grad_() for w in ws]
         y = F.swiglu_mlp(xx, *ww)
@@ -708,13 +710,16 @@ def test_linear_layers_on_the_hand_written_gemm_match_the_library(monkeypatch):
         outs = F.linear_group(x2, lw)
         torch.autograd.backward(outs, dq)
         res = [y, xx.grad] + [w.grad for w in ww] + list(outs) + [x2.grad] + [w.grad for w, _ in lw] + [b.grad for _, b in lw]
-        del real
-        return [r.float() for r in res], len(calls)
+        return [r.float() for r in res], calls, len(tr)
 
-    _orig = F.gemm_tn
-    lib, n_lib = run("lib")
-    own, n_own = run("own")
-    assert n_lib == 0 and n_own == 3 + 1 + 1 + 2 + 1 + 3 + 3 + 1, n_own      # MLP: 3 fwd, dWd, dact, dx(2), dWgu; group: 3 fwd, 3 dx, dW
+    _orig, _orig_t = F.gemm, F.transpose_2d
+    lib, c_lib, t_lib = run("lib")
+    own, c_own, t_own = run("own")
+    # MLP: 3 forward, dW_down, d(act), dX (one launch over the gate / up pair), dW_gate, dW_up; group: 3 forward, dX (ONE
+    # launch with three segments), 3 dW.  And not a single transposed copy.
+    assert len(c_lib) == 0 and t_lib > 0
+    assert len(c_own) == 8 + 7 and t_own == 0, (len(c_own), t_own)
+    assert sorted(n for n, _, _ in c_own) == [1] * 13 + [2, 3]
     for i, (a, b) in enumerate(zip(own, lib)):
         scale = float(b.abs().max())
         assert float((a - b).abs().max()) <= 1.6e-2 * scale + 1e-6, (i, float((a - b).abs().max()), scale)
@@ -864,7 +869,7 @@ def test_attention_long_sequence_multi_chunk_tile_list(D, Nh, Nkv):
 
 # ---------------------------------------------------------------------------------------- hand-written MFMA GEMM
 @pytest.mark.parametrize("M,N,K,bias,acc,ct", [
-    (256, 256, 128, False, False, False),      # one tile, one trip of the 4-slot ring
+    (256, 256, 128, False, False, False),      # one tile, two stages
     (512, 768, 256, True, False, False),       # bias, several tiles
     (300, 264, 384, False, False, False),      # ragged M and N (zero-filled DMA rows, guarded stores)
     (1000, 1288, 512, True, True, False),      # accumulate into C (group input gradients), ragged
@@ -898,6 +903,69 @@ def test_gemm_tn_matches_fp32_reference(M, N, K, bias, acc, ct):
         assert torch.equal(out_t.cpu(), got.cpu().t()), "transposed copy differs from C^T"
 
 
+@pytest.mark.parametrize("mode", ["fwd", "dgrad", "wgrad"])
+@pytest.mark.parametrize("M,N,K", [
+    (256, 256, 64),          # one tile, one stage: prologue / epilogue only
+    (520, 264, 192),         # ragged rows and columns
+    (1000, 776, 1088),       # 17 stages: the ring wraps more than three times
+    (4360, 4104, 128),       # 306 tiles > 256 CUs: persistent workgroups walk two tiles (park in the freed slots)
+])
+def test_gemm_operand_modes_match_fp64_reference(mode, M, N, K):
+    """The three products of a linear layer in their native layouts (functional.gemm): forward x W^T, input gradient
+    dY W (W contraction-major, read with ds_read_b64_tr_b16), weight gradient dY^T x (both contraction-major).
+    Asymmetric random data: a swapped operand, a transposed tile or a wrong contraction slot cannot pass."""
+    F = _f()
+    g = torch.Generator().manual_seed(M + 3 * N + 7 * K)
+    r = lambda *sh: (torch.rand(*sh, generator=g) * 2 - 1).to(torch.bfloat16)
+    if mode == "fwd":
+        a, b = r(M, K), r(N, K)
+        ref, ak, bk = a.double() @ b.double().t(), False, False
+    elif mode == "dgrad":
+        a, b = r(M, K), r(K, N)
+        ref, ak, bk = a.double() @ b.double(), False, True
+    else:
+        a, b = r(K, M), r(K, N)
+        ref, ak, bk = a.double().t() @ b.double(), True, True
+    got = F.gemm([(a.to(DEV), b.to(DEV))], ak, bk)
+    _close(got, ref, atol=float(ref.abs().max()) * 2 ** -8, rtol=2 ** -7, what=f"gemm {mode} {M}x{N}x{K}")
+
+
+def test_gemm_segments_accumulate_in_fp32_and_reject_bad_shapes():
+    """dX = dQ Wq + dK Wk + dV Wv as ONE launch (three segments of different depth and row pitch) and dW over two token
+    ranges: equal to the fp64 sum rounded once — better than three bf16 round trips through C."""
+    F = _f()
+    from touchnet_amd import _C
+    g = torch.Generator().manual_seed(77)
+    r = lambda *sh: (torch.rand(*sh, generator=g) * 2 - 1).to(torch.bfloat16).to(DEV)
+    M, N = 1032, 520
+    segs, ref = [], 0
+    for K in (256, 64, 128):
+        a, b = r(M, K + 64)[:, :K], r(K, N)                  # (row pitch K + 64)
+        segs.append((a, b))
+        ref = ref + a.double().cpu() @ b.double().cpu()
+    got = F.gemm(segs, False, True)
+    _close(got, ref, atol=float(ref.abs().max()) * 2 ** -8, rtol=2 ** -7, what="3-segment input gradient")
+    chained = None
+    for a, b in segs:                                        # the same sum with a bf16 rounding behind every term
+        chained = F.gemm([(a, b)], False, True, out=chained, accumulate=chained is not None)
+    e1 = float((got.double().cpu() - ref).abs().mean()), float((chained.double().cpu() - ref).abs().mean())
+    assert e1[0] <= e1[1], e1
+    segs, ref = [], 0
+    for K in (128, 192):
+        a, b = r(K, M), r(K, N)
+        segs.append((a, b))
+        ref = ref + a.double().cpu().t() @ b.double().cpu()
+    _close(F.gemm(segs, True, True), ref, atol=float(ref.abs().max()) * 2 ** -8, rtol=2 ** -7, what="2-segment wgrad")
+    with pytest.raises(_C.KernelError):
+        F.gemm([(r(64, 100), r(64, 128))], True, True)       # contraction-major A: M % 8
+    with pytest.raises(_C.KernelError):
+        F.gemm([(r(128, 96), r(128, 96))])                   # K % 64
+    with pytest.raises(_C.KernelError):
+        F.gemm([(r(128, 64), r(64, 128))], True, False)      # (A contraction-major, B not): no such product
+    with pytest.raises(_C.KernelError):
+        F.gemm([(r(128, 64), r(128, 64))] * 4)               # more than three segments
+
+
 def test_gemm_tn_strided_operands_and_rejects():
     F = _f()
     from touchnet_amd import _C
@@ -912,7 +980,7 @@ def test_gemm_tn_strided_operands_and_rejects():
     _close(out, ref, atol=float(ref.abs().max()) * 2 ** -8, rtol=2 ** -7, what="gemm_tn strided")
     assert float(out_full[:, :64].abs().max()) == 0 and float(out_full[:, 448:].abs().max()) == 0
     with pytest.raises(_C.KernelError):
-        F.gemm_tn(big_a[:, :100], big_b[:, :100])                 # K % 128 != 0
+        F.gemm_tn(big_a[:, :100], big_b[:, :100])                 # K % 64 != 0
     with pytest.raises(_C.KernelError):
         F.gemm_tn(big_a.float(), big_b.float())
 

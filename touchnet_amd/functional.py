@@ -376,12 +376,28 @@ def _tn_ok(M: int, K: int, Ns) -> bool:
     return M % 8 == 0 and K % 8 == 0 and all(n % 8 == 0 for n in Ns)
 
 
-# Which GEMM runs the forward-layout products of the linear layers below: "lib" (default) = hipBLASLt through torch,
-# "own" = the hand-written MFMA kernel of csrc/gemm.hip wherever its shape constraints hold (TN_LINEAR_GEMM=own or
-# `bench.py --linear-gemm own`).  The library stays the default because it is 10-20 % faster on the step's shapes
-# (profiles/r02_gemm_own_vs_hipblaslt.md); the switch exists so that the WHOLE step can be measured on hand-written
-# GEMMs and so that parity of the two is tested at model level (tests/test_models_gpu.py).
+# Which GEMM runs the products of the linear layers below:
+#   "own"  the hand-written MFMA kernel of csrc/gemm.hip in its three operand modes — forward x W^T, input gradient
+#          dY W (W contraction-major) and weight gradient dY^T x (both contraction-major): every product reads nn.Linear's
+#          own tensors, no transposed copy of W, dY or x is made, and the input gradient of a group (q/k/v, gate/up) is ONE
+#          multi-segment launch.  Shapes the kernel does not take (K % 64, fewer output tiles than half the CUs) go to the
+#          library.
+#   "lib"  hipBLASLt through torch, every product brought into the forward layout by transposed copies
+#          (tn_transpose_bf16; round 2's default).
+# TN_LINEAR_GEMM / `bench.py --linear-gemm` select; tests/test_kernels_gpu.py holds the two to each other.
 LINEAR_GEMM = os.environ.get("TN_LINEAR_GEMM", "lib")
+_OWN_MIN_TILES = 96          # below this many 256 x 256 output tiles most CUs would idle: the library's split-K wins
+
+
+def _own(M: int, N: int, Ks, a_kmaj: bool = False) -> bool:
+    """The hand-written kernel takes this product (and is the configured choice)."""
+    return (LINEAR_GEMM == "own" and gemm_supported(M, N, Ks, a_kmaj)
+            and ((M + 255) // 256) * ((N + 255) // 256) >= _OWN_MIN_TILES)
+
+
+def _bf16_rows(*ts) -> bool:
+    return all(t.is_cuda and t.dtype == torch.bfloat16 and t.dim() == 2 and t.stride(1) == 1 and t.stride(0) % 8 == 0
+               and t.data_ptr() % 16 == 0 for t in ts)
 
 
 def _mm_tn(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
@@ -389,16 +405,35 @@ def _mm_tn(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = None
     """``a @ b.T (+ bias)`` (``out += ...`` if accumulate) for contraction-contiguous a [M, K], b [N, K]."""
     M, K = a.shape
     N = b.shape[0]
-    own = (LINEAR_GEMM == "own" and a.is_cuda and a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16
-           and a.stride(1) == 1 and b.stride(1) == 1 and gemm_tn_supported(M, N, K)
-           and (bias is None or bias.dtype == torch.bfloat16))
-    if own:
-        return gemm_tn(a, b, bias=bias, out=out, accumulate=accumulate)
+    if (_own(M, N, (K,)) and _bf16_rows(a, b) and (bias is None or bias.dtype == torch.bfloat16)):
+        return gemm([(a, b)], bias=bias, out=out, accumulate=accumulate)
     if accumulate:
         return out.addmm_(a, b.t())
     if out is not None:
         return torch.mm(a, b.t(), out=out) if bias is None else torch.addmm(bias, a, b.t(), out=out)
     return torch.nn.functional.linear(a, b, bias)
+
+
+def _dgrad(dys, ws) -> Optional[torch.Tensor]:
+    """sum_i dY_i W_i on the hand-written kernel (W_i [N_i, K] read contraction-major; one launch for up to three
+    layers), or None when it does not take the shapes."""
+    M, K = dys[0].shape[0], ws[0].shape[1]
+    if not (_own(M, K, [w.shape[0] for w in ws]) and _bf16_rows(*dys, *ws)):
+        return None
+    dx = None
+    for i in range(0, len(ws), 3):
+        segs = list(zip(dys[i:i + 3], ws[i:i + 3]))
+        dx = gemm(segs, b_kmaj=True, out=dx, accumulate=dx is not None)
+    return dx
+
+
+def _wgrad(dy, x2) -> Optional[torch.Tensor]:
+    """dY^T x [N, K] on the hand-written kernel (both operands contraction-major: the contraction runs over tokens),
+    or None."""
+    M, N = dy.shape
+    if not (_own(N, x2.shape[1], (M,), a_kmaj=True) and _bf16_rows(dy, x2)):
+        return None
+    return gemm([(dy, x2)], True, True)
 
 
 def _stacked_view(ts):
@@ -421,18 +456,15 @@ def _stacked_view(ts):
 class _LinearGroup(torch.autograd.Function):
     """``y_i = x W_i^T + b_i`` for a group of linear layers that share their input (q/k/v, gate/up, or one layer).
 
-    Forward is what nn.Linear does.  Backward differs from autograd's in the WEIGHT gradient: dW_i = dY_i^T x
-    contracts over tokens, the slow dimension of both operands, which hipBLASLt runs at ~1.0 PFLOP/s on MI355X;
-    here dY_i and x are transposed by a HIP kernel (tn_transpose_bf16, ~5 TB/s) and ONE GEMM over the whole group
-    ``[sum N_i, M] x [M, K]`` runs in the forward GEMM's layout at 1.4-1.55 PFLOP/s
-    (scripts/wgrad_layout_bench.py: q/k/v of a 7B block 1.67 -> 1.27 ms, gate/up 3.14 -> 2.46 ms incl. transposes).
-    The INPUT gradient dX = sum_i dY_i W_i contracts over W_i's slow dimension; with W_i transposed first (33-90 MB,
-    ~0.01-0.04 ms) the same hipBLASLt GEMM runs 8-19 % faster (scripts/gemm_layout_bench.py: 4096^2 0.50 -> 0.43 ms,
-    11008 -> 4096 1.11 -> 0.93 ms); it accumulates over the group inside the GEMM epilogue (addmm, beta = 1).
-    ``wgrad``: "tn" (above) | "nt" autograd's layout per layer |
-    "nt_fused" one NT GEMM over the column-concatenated dY (the 1280-wide audio tower: three 1280 x 1280 outputs
-    are 25 tiles each, 351 TFLOP/s; fused 781 TFLOP/s, while TN brings nothing at that width).
-    ``dgrad_tn=False`` keeps W as stored for the input gradient (no gain at 1280 x 1280)."""
+    Forward is what nn.Linear does.  LINEAR_GEMM == "own": all three products run on the hand-written kernel in their
+    native layouts (see above).  Otherwise the library path of round 2: its WEIGHT gradient dW_i = dY_i^T x contracts
+    over tokens, the slow dimension of both operands, which hipBLASLt runs at ~1.0 PFLOP/s on MI355X; there dY_i and x are
+    transposed by a HIP kernel (tn_transpose_bf16) and ONE GEMM over the whole group ``[sum N_i, M] x [M, K]`` runs in
+    the forward GEMM's layout; the INPUT gradient dX = sum_i dY_i W_i uses W_i transposed first and accumulates over the
+    group inside the GEMM epilogue (addmm, beta = 1).
+    ``wgrad`` (library path): "tn" (above) | "nt" autograd's layout per layer | "nt_fused" one NT GEMM over the
+    column-concatenated dY (the 1280-wide audio tower: three 1280 x 1280 outputs are 25 tiles each).
+    ``dgrad_tn=False`` keeps W as stored for the library's input gradient (no gain at 1280 x 1280)."""
 
     @staticmethod
     def forward(ctx, x, n, wgrad, dgrad_tn, *wb):
@@ -457,9 +489,14 @@ class _LinearGroup(torch.autograd.Function):
         need_x, need_w = ctx.needs_input_grad[0], [ctx.needs_input_grad[4 + i] for i in range(n)]
         Ns = [w.shape[0] for w in ws]
         hip_ok = x.dtype == torch.bfloat16 and (x.is_cuda or x.is_meta) and _tn_ok(M, K, Ns)
+        own = LINEAR_GEMM == "own" and x.is_cuda and x.dtype == torch.bfloat16
         dx = None
         if need_x:
-            if hip_ok and ctx.dgrad_tn:
+            if own:
+                dx = _dgrad(dys, [_c(w) for w in ws])
+            if dx is not None:
+                pass
+            elif hip_ok and ctx.dgrad_tn:
                 wts = [transpose_2d(_c(w)) for w in ws]                                # W^T [K, N]: forward layout
                 dx = _mm_tn(dys[0], wts[0])
                 for d, wt in zip(dys[1:], wts[1:]):
@@ -472,7 +509,16 @@ class _LinearGroup(torch.autograd.Function):
             dx = dx.view(x.shape)
         dws = [None] * n
         if any(need_w):
-            if ctx.wgrad == "nt_fused" and n > 1:
+            if own:
+                x2c = _c(x2)
+                dws = [_wgrad(d, x2c) if nw else None for d, nw in zip(dys, need_w)]
+            todo = [i for i in range(n) if need_w[i] and dws[i] is None]
+            if not todo:
+                pass
+            elif len(todo) < n:                           # (some layers of the group went to the hand-written kernel)
+                for i in todo:
+                    dws[i] = torch.mm(dys[i].t(), x2)
+            elif ctx.wgrad == "nt_fused" and n > 1:
                 st = _stacked_view(dys)
                 if st is not None:            # the gradients already lie side by side (library.attn_bwd_stacked): no cat
                     dws = list(torch.bmm(st.transpose(1, 2), x2.unsqueeze(0).expand(n, M, K)).unbind(0))
@@ -509,31 +555,46 @@ def linear_group(x, layers, wgrad: str = "tn", dgrad_tn: bool = True):
 class _SwiGLUMLP(torch.autograd.Function):
     """``down(silu(gate(x)) * up(x))`` as ONE autograd node (modeling_llama.py:174-176, three bias-free nn.Linear).
 
-    Same GEMMs and layouts as three linear_group calls + swiglu (forward-layout weight- and input-gradient GEMMs,
-    _LinearGroup), but the transposed operands those GEMMs need — act^T for dW_down, [d_gate^T; d_up^T] for the
-    grouped dW_gate/up — are written by the SwiGLU kernels themselves (tn_swiglu_fwd_t / tn_swiglu_bwd_t: one extra
-    store each) instead of by separate transpose passes (a load and a store each): 0.44 -> 0.22 ms per layer at
-    [16384, 11008].  act itself is not kept for backward (act^T is)."""
+    LINEAR_GEMM == "own": seven launches of the hand-written kernel (gate, up, down; dW_down, d(act), dX over the
+    (gate, up) pair as one two-segment launch, dW_gate, dW_up) + the two SwiGLU kernels; nothing is transposed.
+    Library path: same GEMMs in the forward layout, the transposed operands they need — act^T for dW_down,
+    [d_gate^T; d_up^T] for the grouped dW_gate/up — written by the SwiGLU kernels themselves (tn_swiglu_fwd_t /
+    tn_swiglu_bwd_t: one extra store each) instead of by separate transpose passes."""
 
     @staticmethod
     def forward(ctx, x, wg, wu, wd):
         K, I = x.shape[-1], wg.shape[0]
         x2 = _c(x.reshape(-1, K))
         M = x2.shape[0]
+        own = _own(M, I, (K,)) and _own(M, K, (I,)) and _own(I, K, (M,), True) and _own(K, I, (M,), True)
         gate, up = _mm_tn(x2, _c(wg)), _mm_tn(x2, _c(wu))
-        act, act_t = L.swiglu_fwd_t(gate, up)
+        if own:
+            act = L.swiglu_fwd(gate, up)
+            kept = act
+        else:
+            act, kept = L.swiglu_fwd_t(gate, up)                       # kept = act^T
         y = _mm_tn(act, _c(wd))
-        ctx.save_for_backward(x2, gate, up, act_t, wg, wu, wd)
-        ctx.xshape = x.shape
+        ctx.save_for_backward(x2, gate, up, kept, wg, wu, wd)
+        ctx.xshape, ctx.own = x.shape, own
         return y.view(*x.shape[:-1], wd.shape[0])
 
     @staticmethod
     def backward(ctx, dy):
-        x2, gate, up, act_t, wg, wu, wd = ctx.saved_tensors
+        x2, gate, up, kept, wg, wu, wd = ctx.saved_tensors
         M, K = x2.shape
         I, H = wg.shape[0], wd.shape[0]
         dy2 = _c(dy).reshape(M, H)
         nx, ng, nu, nd = ctx.needs_input_grad
+        if ctx.own and LINEAR_GEMM == "own":
+            dwd = gemm([(dy2, kept)], True, True) if nd else None                      # dY^T act  [H, I]
+            dact = gemm([(dy2, _c(wd))], b_kmaj=True)                                  # dY W_down [M, I]
+            dgate, dup = L.swiglu_bwd(dact, gate, up)
+            del dact
+            dx = gemm([(dgate, _c(wg)), (dup, _c(wu))], b_kmaj=True).view(ctx.xshape) if nx else None
+            dwg = gemm([(dgate, x2)], True, True) if ng else None
+            dwu = gemm([(dup, x2)], True, True) if nu else None
+            return dx, dwg, dwu, dwd
+        act_t = kept if not ctx.own else transpose_2d(kept)
         dwd = _mm_tn(transpose_2d(dy2), act_t) if nd else None                      # [H, I], forward layout
         dact = _mm_tn(dy2, transpose_2d(_c(wd)))                                    # [M, I]
         dgate, dup, dgu_t = L.swiglu_bwd_t(dact, gate, up)
