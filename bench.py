@@ -263,25 +263,35 @@ def kernel_rooflines(workload: "Workload"):
     add("packed attention bwd (true masked flops)",
         t_ms(lambda: torch.autograd.grad(o, [qg, kg, vg], do, retain_graph=True)), flops=2.5 * fl, per_step=L_)
     del q, k, v, qg, kg, vg, o, do
-    # the step's dominant kernels are the library GEMMs (72 % of its time): one of each kind at the MLP shapes, in the
-    # operand layouts functional._LinearGroup gives them, plus the transpose that feeds them
+    # the step's dominant kernels are the linear layers' GEMMs (~70 % of its time): one of each kind at the MLP shapes, on
+    # the path that is configured (hand-written kernel in its native operand modes, or the library on transposed copies),
+    # the other path beside it for comparison (launches_per_step = 0)
+    own = F.LINEAR_GEMM == "own"
     wg = torch.randn(I, H, dtype=bf, device=dev)
-    add(f"hipBLASLt GEMM fwd gate_proj [{N}x{H}]x[{I}x{H}]^T", t_ms(lambda: torch.nn.functional.linear(x, wg)),
-        flops=2.0 * N * H * I, per_step=3 * L_)        # gate, up, down forward: same flops each
-    add(f"hand-written MFMA GEMM (csrc/gemm.hip), same shape", t_ms(lambda: F.gemm_tn(x, wg)), flops=2.0 * N * H * I)
+    wu = torch.randn(I, H, dtype=bf, device=dev)
     dy = torch.randn(N, I, dtype=bf, device=dev)
+    du = torch.randn(N, I, dtype=bf, device=dev)
+    fl1 = 2.0 * N * H * I
+    add(f"tn::gemm fwd gate_proj [{N}x{H}]x[{I}x{H}]^T (hand-written, csrc/gemm.hip)", t_ms(lambda: F.gemm([(x, wg)])),
+        flops=fl1, per_step=3 * L_ if own else 0)     # gate, up, down forward: same flops each
+    add("tn::gemm dgrad gate+up: dX = dG Wg + dU Wu, ONE two-segment launch, W read contraction-major",
+        t_ms(lambda: F.gemm([(dy, wg), (du, wu)], b_kmaj=True)), flops=2 * fl1, per_step=L_ if own else 0)
+    add("tn::gemm wgrad gate_proj: dW = dG^T X, both operands contraction-major (no transposed copies)",
+        t_ms(lambda: F.gemm([(dy, x)], True, True)), flops=fl1, per_step=3 * L_ if own else 0)
+    add(f"hipBLASLt GEMM fwd gate_proj, same shape", t_ms(lambda: torch.nn.functional.linear(x, wg)),
+        flops=fl1, per_step=0 if own else 3 * L_)
     wgt = F.transpose_2d(wg)
-    add("hipBLASLt GEMM dgrad gate_proj (W pre-transposed)", t_ms(lambda: torch.mm(dy, wgt.t())), flops=2.0 * N * H * I,
-        per_step=3 * L_)
+    add("hipBLASLt GEMM dgrad gate_proj (W pre-transposed)", t_ms(lambda: torch.mm(dy, wgt.t())), flops=fl1,
+        per_step=0 if own else 3 * L_)
     dyt = torch.empty(2 * I, N, dtype=bf, device=dev)
     F.transpose_2d(dy, out=dyt[:I])
     F.transpose_2d(dy, out=dyt[I:])
     xt = F.transpose_2d(x)
     add("hipBLASLt GEMM wgrad gate+up fused (both operands pre-transposed)", t_ms(lambda: torch.mm(dyt, xt.t())),
-        flops=2.0 * N * H * 2 * I, per_step=L_)
-    add("autograd-layout wgrad gate_proj (dY^T X, for comparison)", t_ms(lambda: torch.mm(dy.t(), x)),
-        flops=2.0 * N * H * I)
-    add("bf16 transpose (tn_transpose_bf16) [N, I]", t_ms(lambda: F.transpose_2d(dy, out=dyt[:I])), bytes_=4 * N * I)
+        flops=2 * fl1, per_step=0 if own else L_)
+    add("autograd-layout wgrad gate_proj (dY^T X, for comparison)", t_ms(lambda: torch.mm(dy.t(), x)), flops=fl1)
+    add("bf16 transpose (tn_transpose_bf16) [N, I] (library path only)", t_ms(lambda: F.transpose_2d(dy, out=dyt[:I])),
+        bytes_=4 * N * I)
     return out, allowed
 
 
@@ -303,8 +313,8 @@ def main():
                     help="A/B switch: ignore the loader's labelled-row bound and run lm_head + CE on all B*T positions")
     ap.add_argument("--no-gemm-tuning", action="store_true", help="library-default GEMM algorithm selection")
     ap.add_argument("--linear-gemm", choices=("lib", "own"), default=None,
-                    help="own = the linear layers' forward-layout GEMMs on the hand-written MFMA kernel (csrc/gemm.hip) "
-                         "instead of hipBLASLt (default: TN_LINEAR_GEMM or lib)")
+                    help="own (default) = the linear layers' GEMMs on the hand-written MFMA kernel (csrc/gemm.hip) in its "
+                         "native operand modes; lib = hipBLASLt on transposed copies (A/B runs; TN_LINEAR_GEMM)")
     args = ap.parse_args()
     if args.linear_gemm:
         import touchnet_amd.functional as _F
@@ -387,9 +397,11 @@ def main():
                                                and __import__("touchnet_amd.models.llama.modeling_llama", fromlist=["x"]).LAST_LAYER_LABELLED_ROWS)
                                            else "all B*T positions"),
                        "gemm_algorithms": "TunableOp replay (touchnet_amd/tuning)" if tuned else "library default",
-                       "linear_layer_gemm": ("hand-written MFMA kernel (csrc/gemm.hip) where its shape constraints hold"
+                       "linear_layer_gemm": ("hand-written MFMA kernel (csrc/gemm.hip): forward, input-gradient and "
+                                             "weight-gradient products in native operand modes; hipBLASLt only for "
+                                             "outputs below 96 tiles (1280 x 1280 tower weight gradients, lm_head)"
                                              if __import__("touchnet_amd.functional", fromlist=["x"]).LINEAR_GEMM == "own"
-                                             else "hipBLASLt")},
+                                             else "hipBLASLt (A/B mode)")},
             "step_mfu": round(mfu, 4),
             "mfu_convention": "6*N_wo_emb + 12*L*H*Dh*T per token (touchnet/models/*/__init__.py), no causal/packing "
                               "discount, no recompute credit, tokens = all B*T slots incl. pad",
@@ -430,17 +442,36 @@ def main():
                         # ... and so does everything behind the LAST layer's attention core (o_proj + MLP)
                         executed -= 6.0 * (c.hidden_size * c.num_attention_heads * c.head_dim
                                            + 3 * c.hidden_size * c.intermediate_size) * (wl.B * wl.T - rows)
-                line["step_mfu_executed_flops"] = round(executed / (step_ms * 1e-3) / MFMA_PEAK, 4)
+                ex_frac = executed / (step_ms * 1e-3) / MFMA_PEAK
+                line["step_mfu_executed_flops"] = round(ex_frac, 4)
+                # the roofline's primary number is the utilisation on EXECUTED flops; the reference-formula value (which
+                # credits attention pairs the document mask never computes) stays beside it and in `step_mfu`
+                line["roofline"].update({"achieved": round(ex_frac * MFMA_PEAK / 1e12, 1), "frac": round(ex_frac, 4),
+                                         "formula_achieved": round(fpt * (tps / world) / 1e12, 1),
+                                         "formula_frac": round(mfu, 4),
+                                         "note": "whole training step per GPU against the dense bf16 MFMA peak: `frac` on the "
+                                                 "FLOPs the step executes, `formula_frac` by the reference MFU formula; "
+                                                 "per-kernel rooflines of the hand-written HIP kernels in `kernels`"})
                 line["executed_flops_note"] = ("GEMM terms of the formula (6*N_wo_emb per token; tower on its 1500 frames "
                                                "per clip; an untied lm_head only on the rows it runs on) + attention on "
                                                "the allowed (query, key) pairs only, fwd + 2.5x bwd")
             except Exception as e:  # never lose the headline number to a diagnostics failure
                 line["kernels_error"] = repr(e)
-        tfile = os.path.join(ROOT, "profiles", f"r02_step_hbm_traffic_{wl.name}.json")
-        if os.path.exists(tfile):          # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this same command (scripts/step_traffic.sh)
+        # HBM traffic: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this same command (scripts/step_traffic.sh), kept only
+        # while it describes the code that is running: the file carries the digest of the kernel sources and the GEMM
+        # mode it was taken with, and a stale one is reported as such instead of as a number
+        tfile = os.path.join(ROOT, "profiles", f"r03_step_hbm_traffic_{wl.name}.json")
+        if os.path.exists(tfile):
             t = json.load(open(tfile))
-            line["roofline"]["traffic"] = t["hbm_bytes_per_step"]
-            line["roofline"]["traffic_source"] = t["source"]
+            stamp = os.path.join(ROOT, "touchnet_amd", "_lib", "build.stamp")
+            digest = open(stamp).read().strip() if os.path.exists(stamp) else None
+            mode = __import__("touchnet_amd.functional", fromlist=["x"]).LINEAR_GEMM
+            if t.get("kernel_sources_digest") == digest and t.get("linear_gemm") == mode:
+                line["roofline"]["traffic"] = t["hbm_bytes_per_step"]
+                line["roofline"]["traffic_source"] = t["source"]
+            else:
+                line["roofline"]["traffic_source"] = ("stale: profiles/" + os.path.basename(tfile) + " was taken with other "
+                                                      "kernel sources / GEMM mode; re-run scripts/step_traffic.sh")
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(wl)
         print(json.dumps(line), flush=True)

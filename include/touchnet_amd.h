@@ -208,7 +208,7 @@ int tn_pack_fill(const int* row, const int* col, const int* sent, const int* bat
  *      dX = dY W); = 1: stored [K, rows] (contraction-major: W in dX = dY W; dY and x in dW = dY^T x).
  *      (a_kmaj = 1, b_kmaj = 0) has no caller and returns -22.  A, B, lda, ldb, K are arrays of nseg (1..3) entries;
  *      Ct (optional, may be NULL): transposed copy [N, M] written by the same epilogue.
- *      -22 unless: every K % 64 == 0, N % 8 == 0, every ld % 8 == 0 and >= the operand's contiguous extent, 16-byte
+ *      -22 unless: every K % 64 == 0 (any K > 0 when both operands are contraction-major), N % 8 == 0, every ld % 8 == 0 and >= the operand's contiguous extent, 16-byte
  *      aligned bases; row-stored operands 288 * ld * 2 < 2^31, contraction-major operands ((K-1) * ld + rows) * 2 < 2^31;
  *      a_kmaj: M % 8 == 0; with Ct: M % 8 == 0, ldct % 8 == 0, accumulate == 0. */
 int tn_gemm_bf16(const void* const* A, const void* const* B, const long long* lda, const long long* ldb, const int* K,

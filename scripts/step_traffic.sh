@@ -2,7 +2,8 @@
 # HBM traffic of one training step from the PMC counters (MI355X_MICROARCH.md, HBM section: FETCH_SIZE and WRITE_SIZE
 # in separate passes, kernel trace only; FETCH_SIZE x 2 on gfx950 for wide coalesced streams; both in KiB).
 #   usage (on the GPU box, from the repo root): bash scripts/step_traffic.sh [workload]
-# writes gpurun_out/step_traffic/{fetch,write}/... and gpurun_out/r02_step_hbm_traffic_<workload>.json
+# writes gpurun_out/step_traffic/{fetch,write}/... and gpurun_out/r03_step_hbm_traffic_<workload>.json (copy it to
+# profiles/: bench.py reports it as roofline.traffic while its kernel-source digest and GEMM mode match the running code)
 set -e
 wl=${1:-qwen2_audio_7b}
 R=$(pwd)
@@ -14,7 +15,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 cd $R
 python - "$wl" $STEPS $WARM <<'PY'
-import csv, glob, json, sys
+import csv, glob, json, os, sys
 wl, steps, warm = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 res, per_kernel = {}, {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -35,12 +36,16 @@ fetch = res["FETCH_SIZE"] * 1024 * 2            # KiB -> bytes, gfx950 doubling
 write = res["WRITE_SIZE"] * 1024
 byt = lambda v: (v.get("FETCH_SIZE", 0) * 2 + v.get("WRITE_SIZE", 0)) * 1024
 top = sorted(per_kernel.items(), key=lambda kv: -byt(kv[1]))[:12]
-out = {"workload": wl, "hbm_bytes_per_step": int(fetch + write), "fetch_bytes_per_step": int(fetch),
+sys.path.insert(0, os.getcwd())
+import touchnet_amd.functional as F
+stamp = "touchnet_amd/_lib/build.stamp"
+out = {"workload": wl, "kernel_sources_digest": open(stamp).read().strip() if os.path.exists(stamp) else None,
+       "linear_gemm": F.LINEAR_GEMM, "hbm_bytes_per_step": int(fetch + write), "fetch_bytes_per_step": int(fetch),
        "write_bytes_per_step": int(write),
        "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over bench.py --workload {wl} --steps {steps} "
                  f"--warmup {warm}: kernels between consecutive optimizer steps ({n} whole steps averaged; model init and "
                  f"the first step excluded); FETCH_SIZE doubled per the gfx950 correction",
        "top_kernels_GB_per_step": {k: round(byt(v) / 1e9, 2) for k, v in top}}
-json.dump(out, open(f"gpurun_out/r02_step_hbm_traffic_{wl}.json", "w"), indent=1)
+json.dump(out, open(f"gpurun_out/r03_step_hbm_traffic_{wl}.json", "w"), indent=1)
 print(json.dumps(out)[:900])
 PY

@@ -8,6 +8,8 @@ from collections import defaultdict
 def category(name):
     if name.startswith("Cijk") or name.startswith("Custom_Cijk"):
         return "GEMM (hipBLASLt, via F.linear)"
+    if "tn::gemm::" in name:
+        return "tn::gemm hand-written MFMA GEMM (HIP)"
     if "attn_" in name:
         return "tn:: packed attention (HIP)"
     if "adamw" in name or "sumsq" in name:

@@ -909,12 +909,20 @@ def test_gemm_tn_matches_fp32_reference(M, N, K, bias, acc, ct):
     (520, 264, 192),         # ragged rows and columns
     (1000, 776, 1088),       # 17 stages: the ring wraps more than three times
     (4360, 4104, 128),       # 306 tiles > 256 CUs: persistent workgroups walk two tiles (park in the freed slots)
+    (1280, 520, 3000),       # depth not a multiple of 64: weight-gradient mode only (zero-filled tail stage)
 ])
 def test_gemm_operand_modes_match_fp64_reference(mode, M, N, K):
     """The three products of a linear layer in their native layouts (functional.gemm): forward x W^T, input gradient
     dY W (W contraction-major, read with ds_read_b64_tr_b16), weight gradient dY^T x (both contraction-major).
     Asymmetric random data: a swapped operand, a transposed tile or a wrong contraction slot cannot pass."""
     F = _f()
+    if K % 64 and mode != "wgrad":
+        from touchnet_amd import _C
+        with pytest.raises(_C.KernelError):
+            F.gemm([(torch.zeros(M, K, dtype=torch.bfloat16, device=DEV),
+                     torch.zeros(*((N, K) if mode == "fwd" else (K, N)), dtype=torch.bfloat16, device=DEV))],
+                   False, mode == "dgrad")
+        return
     g = torch.Generator().manual_seed(M + 3 * N + 7 * K)
     r = lambda *sh: (torch.rand(*sh, generator=g) * 2 - 1).to(torch.bfloat16)
     if mode == "fwd":

@@ -364,8 +364,10 @@ def gemm(segs, a_kmaj: bool = False, b_kmaj: bool = False, bias: Optional[torch.
     return out
 
 
-def gemm_supported(M: int, N: int, Ks, a_kmaj: bool = False) -> bool:
-    return all(k % 64 == 0 and k > 0 for k in Ks) and N % 8 == 0 and M > 0 and (not a_kmaj or M % 8 == 0)
+def gemm_supported(M: int, N: int, Ks, a_kmaj: bool = False, b_kmaj: bool = False) -> bool:
+    """Shapes tn_gemm_bf16 takes (two contraction-major operands: any depth, the tail is zero-filled)."""
+    k_ok = all(k > 0 and (k % 64 == 0 or (a_kmaj and b_kmaj)) for k in Ks)
+    return k_ok and N % 8 == 0 and M > 0 and (not a_kmaj or M % 8 == 0)
 
 
 def gemm_tn_supported(M: int, N: int, K: int) -> bool:
@@ -383,15 +385,17 @@ def _tn_ok(M: int, K: int, Ns) -> bool:
 #          multi-segment launch.  Shapes the kernel does not take (K % 64, fewer output tiles than half the CUs) go to the
 #          library.
 #   "lib"  hipBLASLt through torch, every product brought into the forward layout by transposed copies
-#          (tn_transpose_bf16; round 2's default).
+#          (tn_transpose_bf16; round 2's default).  Kept for A/B runs: on one box the Qwen2-Audio-7B step takes 742 ms
+#          on "own" and 717 ms on "lib" (profiles/r03f_*): the library's kernel runs 12 % faster (same cycles within
+#          4 %, higher clock: 2/3 of our LDS read traffic), "own" saves the transposes and their extra stores.
 # TN_LINEAR_GEMM / `bench.py --linear-gemm` select; tests/test_kernels_gpu.py holds the two to each other.
-LINEAR_GEMM = os.environ.get("TN_LINEAR_GEMM", "lib")
+LINEAR_GEMM = os.environ.get("TN_LINEAR_GEMM", "own")
 _OWN_MIN_TILES = 96          # below this many 256 x 256 output tiles most CUs would idle: the library's split-K wins
 
 
-def _own(M: int, N: int, Ks, a_kmaj: bool = False) -> bool:
+def _own(M: int, N: int, Ks, a_kmaj: bool = False, b_kmaj: bool = False) -> bool:
     """The hand-written kernel takes this product (and is the configured choice)."""
-    return (LINEAR_GEMM == "own" and gemm_supported(M, N, Ks, a_kmaj)
+    return (LINEAR_GEMM == "own" and gemm_supported(M, N, Ks, a_kmaj, b_kmaj)
             and ((M + 255) // 256) * ((N + 255) // 256) >= _OWN_MIN_TILES)
 
 
@@ -431,7 +435,7 @@ def _wgrad(dy, x2) -> Optional[torch.Tensor]:
     """dY^T x [N, K] on the hand-written kernel (both operands contraction-major: the contraction runs over tokens),
     or None."""
     M, N = dy.shape
-    if not (_own(N, x2.shape[1], (M,), a_kmaj=True) and _bf16_rows(dy, x2)):
+    if not (_own(N, x2.shape[1], (M,), True, True) and _bf16_rows(dy, x2)):
         return None
     return gemm([(dy, x2)], True, True)
 
@@ -566,7 +570,7 @@ class _SwiGLUMLP(torch.autograd.Function):
         K, I = x.shape[-1], wg.shape[0]
         x2 = _c(x.reshape(-1, K))
         M = x2.shape[0]
-        own = _own(M, I, (K,)) and _own(M, K, (I,)) and _own(I, K, (M,), True) and _own(K, I, (M,), True)
+        own = _own(M, I, (K,)) and _own(M, K, (I,)) and _own(I, K, (M,), True, True) and _own(K, I, (M,), True, True)
         gate, up = _mm_tn(x2, _c(wg)), _mm_tn(x2, _c(wu))
         if own:
             act = L.swiglu_fwd(gate, up)
