@@ -1568,7 +1568,7 @@ __global__ __launch_bounds__(256, 1) void gemm4_kernel(const Params p) {
 
 // kernel-development switch: TN_GEMM_VARIANT = 100 * PLACE + 10 * ASYM + ILV (scripts/gemm_sweep.py sweeps it)
 #ifndef TN_GEMM_DEFAULT_VARIANT
-#define TN_GEMM_DEFAULT_VARIANT 101
+#define TN_GEMM_DEFAULT_VARIANT 601
 #endif
 
 template <bool AK, bool BK, bool HAS_CT>
