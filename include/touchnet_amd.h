@@ -105,6 +105,19 @@ int tn_attn_bwd(const void* q, const void* k, const void* v, const void* o, cons
 int tn_attn_fwd_seg(const void* q, const void* k, const void* v, void* o, float* lse2, const int* doc,
                     const int* meta, int B, int T, int Nh, int Nkv, int D, float scale, int nseg,
                     const int* host_segs, int rows_per_batch, void* stream);
+/*      Key side restricted to the sequence chunks whose bit is set in `chunk_mask` (chunk c = positions
+ *      [c*chunk_len, (c+1)*chunk_len), chunk_len % 64 == 0, at most 64 chunks): rows that see no key there get
+ *      O = 0, LSE2 = +inf.  With tn_attn_merge this is the local / remote split of context-parallel attention: the
+ *      own-chunk part runs while the halo travels (replaces the per-step (out, lse) merge of torch's ring attention,
+ *      torch/distributed/tensor/experimental/_context_parallel/_attention.py:182-183 entered from
+ *      touchnet/utils/distributed.py:292-315). */
+int tn_attn_fwd_seg_chunks(const void* q, const void* k, const void* v, void* o, float* lse2, const int* doc,
+                           const int* meta, int B, int T, int Nh, int Nkv, int D, float scale, int nseg, const int* segs,
+                           int rows_per_batch, int chunk_len, unsigned long long chunk_mask, void* stream);
+/*      lse = log2(2^lse_a + 2^lse_b), O = (2^lse_a O_a + 2^lse_b O_b) / 2^lse for two partial results over DISJOINT key
+ *      sets; o may alias o_a, lse2 may alias lse2_a.  o_* [B, rows, Nh, D] bf16, lse2_* [B, Nh, rows] fp32. */
+int tn_attn_merge(const void* o_a, const float* lse2_a, const void* o_b, const float* lse2_b, void* o, float* lse2,
+                  int B, int rows, int Nh, int D, void* stream);
 int tn_attn_bwd_seg(const void* q, const void* k, const void* v, const void* o, const void* dout,
                     const float* lse2, float* delta, void* dq, void* dk, void* dv, const int* doc, const int* meta,
                     int B, int T, int Nh, int Nkv, int D, float scale, int nseg, const int* host_segs,

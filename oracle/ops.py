@@ -117,6 +117,48 @@ def packed_attention_sharded(q_local, k_full, v_full, mask, shard, scale=None):
     return torch.matmul(p, v).transpose(1, 2).contiguous()
 
 
+def packed_attention_sharded_split(q_local, k_full, v_full, mask, shard, chunk_len, own_chunks, remote_chunks, wait=None,
+                                   scale=None):
+    """mirror of touchnet_amd.functional.packed_attention_sharded_split: the softmax over the rank's OWN chunks, then
+    (behind `wait()`) over the received chunks, merged by their log-sum-exp — the formula of torch's ring attention
+    (torch/distributed/tensor/experimental/_context_parallel/_attention.py:182-183, entered from
+    touchnet/utils/distributed.py:292-315).  Only the chunks a part covers are ever indexed, so a test may leave the
+    remote chunks poisoned until `wait()`."""
+    scale = q_local.shape[-1] ** -0.5 if scale is None else scale
+    pos = torch.cat([torch.arange(off, off + rows) for (_, rows, off) in shard.segs]).to(q_local.device)
+    B, R, Nh, D = q_local.shape
+    g = Nh // k_full.shape[2]
+    qh = q_local.transpose(1, 2).float()                                           # [B, Nh, R, D]
+
+    def part(chunks):
+        if not chunks:
+            return None
+        cols = torch.cat([torch.arange(c * chunk_len, (c + 1) * chunk_len) for c in chunks]).to(q_local.device)
+        allow = mask.allow[:, pos][:, :, cols]                                     # [B, R, n]
+        k = k_full[:, cols].transpose(1, 2).repeat_interleave(g, dim=1).float()
+        v = v_full[:, cols].transpose(1, 2).repeat_interleave(g, dim=1).float()
+        s = torch.matmul(qh, k.transpose(2, 3)) * scale
+        s = s.masked_fill(~allow[:, None], float("-inf"))
+        lse = torch.logsumexp(s, dim=-1)                                           # -inf where the part is empty
+        p = torch.exp(s - torch.where(torch.isfinite(lse), lse, torch.zeros_like(lse))[..., None])
+        p = torch.where(allow[:, None], p, torch.zeros_like(p))
+        return torch.matmul(p, v), lse                                             # [B, Nh, R, D], [B, Nh, R]
+
+    a = part(list(own_chunks))
+    if wait is not None:
+        wait()
+    b = part(list(remote_chunks))
+    if b is None:
+        o = a[0]
+    else:
+        lse = torch.logaddexp(a[1], b[1])
+        wa = torch.where(torch.isfinite(a[1]), torch.exp(a[1] - lse), torch.zeros_like(lse))
+        wb = torch.where(torch.isfinite(b[1]), torch.exp(b[1] - lse), torch.zeros_like(lse))
+        o = wa[..., None] * a[0] + wb[..., None] * b[0]
+        o = torch.where(torch.isfinite(lse)[..., None], o, torch.zeros_like(o))
+    return o.to(q_local.dtype).transpose(1, 2).contiguous()
+
+
 # ---- frontend (same call signatures as touchnet_amd.functional; numpy restatements of oracle/frontend.py) ----------
 def kaldi_fbank(wav, num_mel_bins=80):
     from . import frontend as _fe

@@ -368,7 +368,7 @@ def _order_worker(rank, world, port, ret):
         doc = torch.ones(1, T, dtype=torch.int64)
         cp.set_documents(doc)
         order = []
-        for name, cls in (("issue_return", CP._HaloFinish), ("finish_return", CP._HaloStart)):
+        for name, cls in (("issue_return", CP._HaloReturn), ("finish_return", CP._HaloStart)):
             orig = cls.backward
 
             def wrap(ctx, *a, _o=orig, _n=name):
@@ -393,6 +393,79 @@ def _order_worker(rank, world, port, ret):
         if dist.is_initialized():
             dist.barrier()
             dist.destroy_process_group()
+
+
+def _split_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    try:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import oracle.ops as oops
+        from touchnet_amd.models.backend import use_ops
+        from touchnet_amd.utils import context_parallel as CP
+        T, B, Nh, Nkv, D = 2 * world * 128, 2, 4, 2, 16
+        cp = CP.ContextParallel(dist.group.WORLD, T)
+        g = torch.Generator().manual_seed(11)
+        # two documents per row, the second one starts in the middle of a chunk; a pad tail
+        doc = torch.ones(B, T, dtype=torch.int64)
+        doc[:, 200:] = 2
+        doc[1, T - 40:] = 0
+        cp.set_documents(doc)
+        q, k, v = [torch.randn(B, T, h, D, generator=g) for h in (Nh, Nkv, Nkv)]
+        mask = oops.build_packed_mask(doc)
+        ql, kl, vl = [cp.shard(t).clone().requires_grad_() for t in (q, k, v)]
+        events = []
+        real_start = CP._start_forward
+
+        def poisoned_start(cpar, locals_):
+            fulls, tr = real_start(cpar, locals_)
+            tr.wait()                                   # (gloo: land the data, then hide it again until `wait()`)
+            stash = []
+            mine = cpar.my_chunks()
+            for f in fulls:
+                for c in range(2 * cpar.cp):
+                    if c not in mine:
+                        view = f.narrow(1, c * cpar.Tc, cpar.Tc)
+                        stash.append((view, view.clone()))
+                        view.fill_(float("nan"))
+
+            class Later:
+                def wait(self_inner):
+                    events.append("wait")
+                    with torch.no_grad():
+                        for view, data in stash:
+                            view.copy_(data)
+            return fulls, Later()
+        CP._start_forward = poisoned_start
+        with use_ops(oops):
+            ex = CP.exchange_kv(cp, kl, vl)
+            out = ex.attend(ql, mask, D ** -0.5)
+            ref = oops.packed_attention_sharded(cp.shard(q), k, v, mask, cp.seq_shard(), D ** -0.5)
+        ok_val = bool(torch.isfinite(out).all()) and float((out - ref).abs().max()) < 2e-5
+        w = torch.randn(out.shape, generator=g)
+        (out * w).sum().backward()
+        ret[rank] = ("ok", ok_val, events, bool(torch.isfinite(ql.grad).all() and torch.isfinite(kl.grad).all()))
+    except Exception as e:
+        import traceback
+        ret[rank] = ("fail", traceback.format_exc(), repr(e))
+    finally:
+        if dist.is_initialized():
+            dist.barrier()
+            dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_split_attention_reads_remote_chunks_only_behind_the_wait(world):
+    """KVExchange.attend: the attention over the rank's OWN chunks must not touch a remote chunk (they are NaN until
+    `wait()` here), the part over the received chunks runs behind the wait, and the LSE merge of the two equals the
+    single attention over the global K/V (rows without any key in one part — e.g. a document that lives entirely in
+    remote chunks — included)."""
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_split_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+        results = dict(ret)
+    for r in range(world):
+        assert results[r][0] == "ok", results[r][1]
+        assert results[r][1] and results[r][2] == ["wait"] and results[r][3], results[r]
 
 
 def test_halo_return_travels_under_the_query_path_backward():

@@ -569,6 +569,57 @@ def test_config_d_long_audio_context_parallel_segments():
     assert float(of[0][pad].float().abs().max()) == 0.0 and float(kf.grad[0][pad].float().abs().max()) == 0.0
 
 
+def test_config_d_local_remote_split_with_lse_merge_equals_the_single_kernel():
+    """Context parallel at config-D size (T = 65536, cp = 4, two 30 000-token recordings): the attention of a rank's
+    16384 rows over its OWN two chunks + over the six other chunks, merged by tn_attn_merge, against the single
+    tn_attn_fwd_seg over the global K/V — equal to bf16 rounding of the merge (the partial results are rounded to bf16
+    before they are combined) — and the gradients of the split node (ONE tn_attn_bwd_seg with the merged O / LSE)
+    against the unsplit node.  Also: a rank whose rows see NO key in their own chunks for one document part, pad rows,
+    and the `wait` callback sitting exactly between the two parts."""
+    F = _f()
+    from touchnet_amd import library as Lb
+    B, T, Nh, Nkv, D, cp = 1, 65536, 4, 4, 128, 4
+    lens = [30000, 30000, 700, 1200, 900, 2000]
+    doc = torch.zeros(B, T, dtype=torch.int64)
+    t = 0
+    for i, n in enumerate(lens):
+        doc[0, t:t + n] = i + 1
+        t += n
+    g = torch.Generator().manual_seed(4 * 65536)
+    q, k, v, do = [torch.randn(B, T, n, D, generator=g).bfloat16().to(DEV) for n in (Nh, Nkv, Nkv, Nh)]
+    mask = F.build_packed_mask(doc.to(DEV))
+    Tc = T // (2 * cp)
+    for r in range(cp):
+        mine = [r, 2 * cp - 1 - r]
+        remote = [c for c in range(2 * cp) if c not in mine and c < max(mine)]      # (causal: later chunks see nothing)
+        offs = (mine[0] * Tc, mine[1] * Tc)
+        pos = torch.cat([torch.arange(o, o + Tc) for o in offs])
+        shard = F.SeqShard(((0, Tc, offs[0]), (Tc, Tc, offs[1])), 2 * Tc)
+        dol = do[:, pos].contiguous()
+        ql, kl, vl = q[:, pos].clone().requires_grad_(), k.clone().requires_grad_(), v.clone().requires_grad_()
+        ref = F.packed_attention_sharded(ql, kl, vl, mask, shard)
+        ref.backward(dol)
+        qs, ks, vs = q[:, pos].clone().requires_grad_(), k.clone().requires_grad_(), v.clone().requires_grad_()
+        calls = []
+        out = F.packed_attention_sharded_split(qs, ks, vs, mask, shard, Tc, mine, remote, wait=lambda: calls.append(1))
+        out.backward(dol)
+        assert calls == [1]
+        _close(out, ref, 2 ** -7, 2 ** -7, f"rank {r}: merged forward vs single kernel")
+        _close(qs.grad, ql.grad, 3e-2, 3e-2, f"rank {r}: dQ")
+        _close(ks.grad, kl.grad, 6e-2, 3e-2, f"rank {r}: dK partial")
+        _close(vs.grad, vl.grad, 6e-2, 3e-2, f"rank {r}: dV partial")
+        # the two parts on their own: rows whose document lies entirely in remote chunks have an EMPTY local part
+        segs = shard.flat()
+        bits = lambda cs: sum(1 << c for c in cs)
+        o_a, l_a = Lb.attn_fwd_seg_chunks(qs.detach(), k, v, mask.doc, mask.meta, D ** -0.5, segs, 2 * Tc, Tc, bits(mine))
+        o_b, l_b = Lb.attn_fwd_seg_chunks(qs.detach(), k, v, mask.doc, mask.meta, D ** -0.5, segs, 2 * Tc, Tc, bits(remote))
+        assert bool(torch.isinf(l_b[0, :, :Tc]).all()) == (r == 0)                  # chunk 0 has nothing before it
+        empty_a = torch.isinf(l_a)
+        assert float(o_a.transpose(1, 2)[empty_a].float().abs().max() if empty_a.any() else 0.0) == 0.0
+        pad = (doc[0, pos] == 0).to(DEV)
+        assert float(out[0][pad].float().abs().max() if pad.any() else 0.0) == 0.0
+
+
 # ------------------------------------------------------------------------------------ linear layers
 @pytest.mark.parametrize("R,C", [(8, 8), (256, 64), (264, 72), (1000 * 8, 1280), (16384, 4096)])
 def test_transpose_bf16_bit_exact(R, C):

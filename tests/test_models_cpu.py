@@ -106,7 +106,7 @@ def test_last_layer_on_the_labelled_rows_only_is_the_same_training_step(monkeypa
     """With `labelled_rows_max` the rows that carry a label are selected in front of the LAST layer's output projection
     (o_proj, residual, norm, MLP, final norm and lm_head then see those rows only).  Loss, accuracy and EVERY gradient
     must equal the full computation (fp32 oracle ops); a bound whose 256-rounding is below the real count (T = 300: 300
-    labelled rows, bound 7 -> 256) must poison the loss with NaN instead of dropping labels."""
+    labelled rows, bound 7 -> 256) must poison the loss AND all gradients with NaN instead of dropping labels."""
     import touchnet_amd.models.llama.modeling_llama as ml
     torch.manual_seed(0)
     cfg = DecoderConfig.from_dict(dict(TINY, num_hidden_layers=3))
@@ -138,8 +138,7 @@ def test_last_layer_on_the_labelled_rows_only_is_the_same_training_step(monkeypa
         model.zero_grad()
         with use_ops(oops):
             out = model(**kw, labelled_rows_max=bound)
-            if torch.isfinite(out.loss):
-                out.loss.backward()
+            out.loss.backward()
         return out, {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
 
     full, gfull = run(False)
@@ -147,7 +146,10 @@ def test_last_layer_on_the_labelled_rows_only_is_the_same_training_step(monkeypa
     rows, grows = run(True)
     assert len(taken) == 1
     if (bound + 255) // 256 * 256 < n_lab:
-        assert torch.isnan(rows.loss) and torch.isnan(rows.loss_per_token)
+        assert torch.isnan(rows.loss) and torch.isnan(rows.loss_per_token) and torch.isnan(rows.acc)
+        # ... and the poison reaches EVERY gradient, so that the optimizer's non-finite check skips the step (a NaN
+        # loss with zero / truncated gradients would still apply weight decay and stale momentum)
+        assert len(grows) > 20 and all(bool(torch.isnan(g).any()) for g in grows.values())
         return                      # (the oracle's fused CE computes every row: no bound, nothing to poison)
     assert float(rows.loss) == pytest.approx(float(full.loss), rel=1e-6)
     assert float(rows.loss_per_token) == pytest.approx(float(full.loss_per_token), rel=1e-6)

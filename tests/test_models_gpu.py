@@ -475,3 +475,48 @@ def test_fused_adamw_tensor_parallel_norm_counts_replicated_parameters_once():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_dataloader_thread_uses_the_callers_device_and_orders_batches_by_event(monkeypatch):
+    """PackedDataLoader runs the datapipe (device frontend, device packers) in a background thread.  The current HIP
+    device is per thread and defaults to 0, so the thread must adopt the CALLER's device; and a batch produced on the
+    thread's stream is handed to the consumer's stream through an event (no host sync, no reliance on the default stream)."""
+    import threading
+    from touchnet_amd.data.dataloader import PackedDataLoader
+    seen = {}
+
+    class Pipe:
+        def __init__(self):
+            self.i = 0
+
+        def state_dict(self):
+            return {"epoch": 0, "i": self.i}
+
+        def load_state_dict(self, s):
+            self.i = s["i"]
+
+        def __iter__(self):
+            while self.i < 4:
+                seen.setdefault("thread", threading.current_thread().name)
+                seen.setdefault("stream", torch.cuda.current_stream().cuda_stream)
+                x = torch.full((1 << 20,), float(self.i), device="cuda")
+                for _ in range(20):                      # (enough queued work that an unordered consumer would race)
+                    x = x * 1.0 + 0.0
+                self.i += 1
+                yield {"x": x, "n": self.i}
+
+    calls = []
+    real = torch.cuda.set_device
+    monkeypatch.setattr(torch.cuda, "set_device", lambda d: (calls.append((threading.current_thread().name, d)), real(d))[1])
+    side = torch.cuda.Stream()
+    out = []
+    with torch.cuda.stream(side):
+        for b in PackedDataLoader(Pipe(), 0, 1):
+            assert "_ready" not in b
+            out.append((b["n"], b["x"].sum()))           # consumed on `side`, ordered behind the producer by the event
+    torch.cuda.synchronize()
+    assert [n for n, _ in out] == [1, 2, 3, 4]
+    assert [float(s) for _, s in out] == [0.0, float(1 << 20), float(2 << 20), float(3 << 20)]
+    assert seen["thread"] != threading.current_thread().name
+    assert (seen["thread"], torch.cuda.current_device()) in calls          # the producer thread adopted our device
+    assert seen["stream"] not in (side.cuda_stream, torch.cuda.default_stream().cuda_stream)

@@ -677,7 +677,7 @@ static int attn_bwd_launch(const void* q, const void* k, const void* v, const vo
 int tn_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse2,
                 float* delta, void* dq, void* dk, void* dv, const int* doc, const int* meta, int B, int T, int Nh,
                 int Nkv, int D, float scale, void* stream) {
-  const QView qv = {1, {0, 0}, {T, 0}, {0, 0}, T};
+  const QView qv = {1, {0, 0}, {T, 0}, {0, 0}, T, 0, ~0ull};
   return attn_bwd_launch(q, k, v, o, dout, lse2, delta, dq, dk, dv, doc, meta, B, T, Nh, Nkv, D, scale, qv, stream);
 }
 
@@ -691,7 +691,7 @@ int tn_attn_bwd_seg(const void* q, const void* k, const void* v, const void* o, 
                     void* stream) {
   if (nseg < 1 || nseg > 2) return TN_EINVAL;
   const QView qv = {nseg, {segs[0], nseg > 1 ? segs[3] : 0}, {segs[1], nseg > 1 ? segs[4] : 0},
-                    {segs[2], nseg > 1 ? segs[5] : 0}, rows_per_batch};
+                    {segs[2], nseg > 1 ? segs[5] : 0}, rows_per_batch, 0, ~0ull};
   return attn_bwd_launch(q, k, v, o, dout, lse2, delta, dq, dk, dv, doc, meta, B, T, Nh, Nkv, D, scale, qv, stream);
 }
 

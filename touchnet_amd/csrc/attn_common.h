@@ -75,6 +75,12 @@ struct QView {
   int nseg;
   int row0[2], rows[2], off[2];
   int rpb;
+  // optional restriction of the KEY side to a set of sequence chunks (context parallel: the forward runs once on the
+  // rank's own chunks while the remote ones travel, once on the remote ones, and the two are merged by their LSE):
+  // kv_tpc = 64-position tiles per chunk (0 = no restriction), bit c of kv_mask = chunk c takes part
+  int kv_tpc;
+  unsigned long long kv_mask;
+  __device__ __forceinline__ bool kv_tile_on(int j) const { return kv_tpc == 0 || ((kv_mask >> (j / kv_tpc)) & 1ull); }
   __host__ __device__ int tiles(int s, int bm) const { return s < nseg ? (rows[s] + bm - 1) / bm : 0; }
   // tile `idx` of size bm over all segments -> local first row, global first position, rows left in segment
   __device__ __forceinline__ void tile(int idx, int bm, int& l0, int& g0, int& left) const {
@@ -118,7 +124,7 @@ constexpr int kListCap = 1024;
 template <int NT>
 __device__ __forceinline__ int build_kv_list(int4* list, int* wcount, int lo, int hi, int sentinel, int bminpos,
                                              int bmax, const int* m_min, const int* m_max, const int* m_minpos,
-                                             int tid) {
+                                             int tid, int kv_tpc = 0, unsigned long long kv_mask = ~0ull) {
   constexpr int NW = NT / 64;
   const int lane = tid & 63, wave = tid >> 6;
   int n = 0;
@@ -130,7 +136,7 @@ __device__ __forceinline__ int build_kv_list(int4* list, int* wcount, int lo, in
       mn = m_min[j];
       mx = m_max[j];
       mp = m_minpos[j];
-      ok = tile_may_interact(bminpos, bmax, mp, mx);
+      ok = tile_may_interact(bminpos, bmax, mp, mx) && (kv_tpc == 0 || ((kv_mask >> (j / kv_tpc)) & 1ull));
     }
     const unsigned long long bal = __ballot(ok);
     if (lane == 0) wcount[wave] = __popcll(bal);

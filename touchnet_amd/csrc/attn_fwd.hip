@@ -161,7 +161,7 @@ __global__ __launch_bounds__(64 * NW, D == 64 ? 3 : 2) void attn_fwd_kernel(cons
   int cur = 0;
   for (int c_lo = j_lo; c_lo <= j_hi; c_lo += CAP) {
     const int n = build_kv_list<NT>(tlist, wcount, c_lo, min(c_lo + CAP - 1, j_hi), j_hi + 1, bminpos, bmax, m_min,
-                                    m_max, m_minpos, tid);
+                                    m_max, m_minpos, tid, qv.kv_tpc, qv.kv_mask);
     if (n == 0) continue;
     issue(list_entry(tlist, 0).x);
     stage_store(cur);
@@ -302,6 +302,44 @@ __global__ __launch_bounds__(64 * NW, D == 64 ? 3 : 2) void attn_fwd_kernel(cons
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Merge of two partial attention results over DISJOINT key sets (context parallel: own chunks / received chunks):
+//   lse = log2(2^lse_a + 2^lse_b),  O = (2^lse_a O_a + 2^lse_b O_b) / 2^lse      (LSE2 convention of the forward kernels:
+// log2 domain, +inf = the row saw no key in that part).  HBM-bound: 3 x rows x Nh x D x 2 B + the statistics.
+// The reference's ring attention merges its per-step (out, lse) the same way
+// (torch/distributed/tensor/experimental/_context_parallel/_attention.py:182-183 via touchnet/utils/distributed.py:292-315).
+// ------------------------------------------------------------------------------------------------
+__global__ void attn_merge_kernel(const bf16_t* __restrict__ oa, const float* __restrict__ la,
+                                  const bf16_t* __restrict__ ob, const float* __restrict__ lb, bf16_t* __restrict__ o,
+                                  float* __restrict__ l, int B, int R, int Nh, int D) {
+  const int dv = D / 8;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)B * R * Nh * dv;
+  if (idx >= total) return;
+  const int d8 = (int)(idx % dv);
+  const int h = (int)((idx / dv) % Nh);
+  const size_t br = idx / ((size_t)dv * Nh);                 // b * R + r
+  const int b = (int)(br / R), r = (int)(br % R);
+  const size_t li = ((size_t)b * Nh + h) * R + r;
+  const float a = la[li], c = lb[li];
+  const bool ea = a == INFINITY, ec = c == INFINITY;          // empty parts
+  const float m = ea ? c : (ec ? a : fmaxf(a, c));
+  const float wa = ea ? 0.f : fast_exp2(a - m), wc = ec ? 0.f : fast_exp2(c - m);
+  const float tot = wa + wc;
+  const float inv = tot > 0.f ? 1.f / tot : 0.f;
+  Vec16<bf16_t> va, vc, vo;
+  va.load(oa + idx * 8);
+  vc.load(ob + idx * 8);
+  float fa[8], fc[8], fo[8];
+  va.unpack(fa);
+  vc.unpack(fc);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) fo[e] = (wa * fa[e] + wc * fc[e]) * inv;
+  vo.pack(fo);
+  vo.store(o + idx * 8);
+  if (d8 == 0) l[li] = tot > 0.f ? m + log2f(tot) : INFINITY;
+}
+
 }  // namespace tn
 
 using namespace tn;
@@ -358,7 +396,7 @@ static int attn_fwd_launch(const void* q, const void* k, const void* v, void* o,
   AttnMeta m = {meta, meta + n, meta + 2 * n, meta + 3 * n, meta + 4 * n, nt};
   const float sl2 = scale * 1.4426950408889634f;
   hipStream_t st = (hipStream_t)stream;
-  if (fwd_schedule() == 1 && (D == 64 || D == 128) && nt <= 1024)   // (the ping-pong kernel's LDS tile list)
+  if (fwd_schedule() == 1 && (D == 64 || D == 128) && nt <= 1024 && qv.kv_tpc == 0)   // (the ping-pong kernel's LDS tile list)
     return tn_attn_fwd_pp_launch(q, k, v, o, lse2, doc, m, qv, B, T, Nh, Nkv, D, sl2, st);
   dim3 grid(Nh, qv.tiles(0, 128) + qv.tiles(1, 128), B), block(256);
   if (D == 128)
@@ -375,7 +413,7 @@ static int attn_fwd_launch(const void* q, const void* k, const void* v, void* o,
 
 int tn_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse2, const int* doc, const int* meta,
                 int B, int T, int Nh, int Nkv, int D, float scale, void* stream) {
-  const QView qv = {1, {0, 0}, {T, 0}, {0, 0}, T};
+  const QView qv = {1, {0, 0}, {T, 0}, {0, 0}, T, 0, ~0ull};
   return attn_fwd_launch(q, k, v, o, lse2, doc, meta, B, T, Nh, Nkv, D, scale, qv, stream);
 }
 
@@ -385,7 +423,7 @@ int tn_attn_fwd_ablate(const void* q, const void* k, const void* v, void* o, flo
                        const int* meta, int B, int T, int Nh, int Nkv, float scale, int ablation, void* stream) {
   const int nt = (T + kTile - 1) / kTile, n = B * nt;
   AttnMeta m = {meta, meta + n, meta + 2 * n, meta + 3 * n, meta + 4 * n, nt};
-  const QView qv = {1, {0, 0}, {T, 0}, {0, 0}, T};
+  const QView qv = {1, {0, 0}, {T, 0}, {0, 0}, T, 0, ~0ull};
   const float sl2 = scale * 1.4426950408889634f;
   hipStream_t st = (hipStream_t)stream;
   switch (ablation) {
@@ -407,8 +445,32 @@ int tn_attn_fwd_seg(const void* q, const void* k, const void* v, void* o, float*
                     int rows_per_batch, void* stream) {
   if (nseg < 1 || nseg > 2) return TN_EINVAL;
   const QView qv = {nseg, {segs[0], nseg > 1 ? segs[3] : 0}, {segs[1], nseg > 1 ? segs[4] : 0},
-                    {segs[2], nseg > 1 ? segs[5] : 0}, rows_per_batch};
+                    {segs[2], nseg > 1 ? segs[5] : 0}, rows_per_batch, 0, ~0ull};
   return attn_fwd_launch(q, k, v, o, lse2, doc, meta, B, T, Nh, Nkv, D, scale, qv, stream);
+}
+
+// The same, restricted on the KEY side to the sequence chunks whose bit is set in `chunk_mask` (chunk c = positions
+// [c * chunk_len, (c + 1) * chunk_len); chunk_len a multiple of 64, at most 64 chunks).  Rows that see no key in those
+// chunks get O = 0 and LSE2 = +inf, which tn_attn_merge treats as "no contribution".
+int tn_attn_fwd_seg_chunks(const void* q, const void* k, const void* v, void* o, float* lse2, const int* doc,
+                           const int* meta, int B, int T, int Nh, int Nkv, int D, float scale, int nseg, const int* segs,
+                           int rows_per_batch, int chunk_len, unsigned long long chunk_mask, void* stream) {
+  if (nseg < 1 || nseg > 2 || chunk_len <= 0 || chunk_len % kTile || (T + chunk_len - 1) / chunk_len > 64) return TN_EINVAL;
+  const QView qv = {nseg, {segs[0], nseg > 1 ? segs[3] : 0}, {segs[1], nseg > 1 ? segs[4] : 0},
+                    {segs[2], nseg > 1 ? segs[5] : 0}, rows_per_batch, chunk_len / kTile, chunk_mask};
+  return attn_fwd_launch(q, k, v, o, lse2, doc, meta, B, T, Nh, Nkv, D, scale, qv, stream);
+}
+
+// O / LSE2 of two partial attentions over disjoint key sets -> merged (o may alias o_a, lse2 may alias lse2_a).
+// o_* [B, rows, Nh, D] bf16, lse2_* [B, Nh, rows] fp32 (log2 domain, +inf = no key seen).
+int tn_attn_merge(const void* o_a, const float* lse2_a, const void* o_b, const float* lse2_b, void* o, float* lse2,
+                  int B, int rows, int Nh, int D, void* stream) {
+  if (B <= 0 || rows <= 0 || Nh <= 0 || D <= 0 || D % 8) return TN_EINVAL;
+  const size_t total = (size_t)B * rows * Nh * (D / 8);
+  hipLaunchKernelGGL(attn_merge_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)o_a, lse2_a, (const bf16_t*)o_b, lse2_b, (bf16_t*)o, lse2, B, rows, Nh, D);
+  TN_LAUNCH_CHECK();
+  return TN_OK;
 }
 
 }  // extern "C"

@@ -48,9 +48,18 @@ class PackedDataLoader(BaseDataLoader):
         self._stop = threading.Event()
 
     # ---- iteration --------------------------------------------------------------------------------------------
-    def _produce(self, q: "queue.Queue", stop: threading.Event):
+    def _produce(self, q: "queue.Queue", stop: threading.Event, device: Optional[int]):
         try:
-            for batch in self.datapipe:
+            stream = None
+            if device is not None:
+                # The current HIP device is per THREAD and defaults to 0: without this every rank's frontend kernels and
+                # batch buffers would land on GPU 0 (extra contexts, memory and a cross-device copy per batch).  The
+                # producer also gets its own stream, and every batch carries an event recorded on it: the consumer's
+                # stream waits for that event instead of relying on both sides using the default stream.
+                import torch
+                torch.cuda.set_device(device)
+                stream = torch.cuda.Stream(device=device)
+            for batch in self._iterate(stream):
                 item = (batch, copy.deepcopy(self.datapipe.state_dict()))
                 while not stop.is_set():
                     try:
@@ -64,12 +73,38 @@ class PackedDataLoader(BaseDataLoader):
         except BaseException as e:                   # surface producer errors in the consumer (train.py has no recovery)
             q.put((e, None))
 
+    def _iterate(self, stream):
+        """The datapipe's batches, produced on `stream` (when there is a device) and tagged with a `_ready` event."""
+        if stream is None:
+            yield from self.datapipe
+            return
+        import torch
+        it = iter(self.datapipe)
+        while True:
+            with torch.cuda.stream(stream):
+                try:
+                    batch = next(it)
+                except StopIteration:
+                    return
+                if isinstance(batch, dict):
+                    ev = torch.cuda.Event()
+                    ev.record(stream)
+                    batch["_ready"] = ev
+            yield batch
+
     def __iter__(self):
         self.shutdown()
         self.datapipe.load_state_dict(copy.deepcopy(self._state))
         q: "queue.Queue" = queue.Queue(maxsize=max(1, self.prefetch))
         self._stop = threading.Event()
-        self._thread = threading.Thread(target=self._produce, args=(q, self._stop), daemon=True)
+        device = None
+        try:
+            import torch
+            if torch.cuda.is_available():
+                device = torch.cuda.current_device()       # the CALLER's device (its rank's GPU)
+        except ImportError:
+            pass
+        self._thread = threading.Thread(target=self._produce, args=(q, self._stop, device), daemon=True)
         self._thread.start()
         while True:
             batch, state = q.get()
@@ -77,6 +112,13 @@ class PackedDataLoader(BaseDataLoader):
                 return
             if isinstance(batch, BaseException):
                 raise batch
+            if isinstance(batch, dict) and "_ready" in batch:
+                import torch
+                ev = batch.pop("_ready")
+                torch.cuda.current_stream().wait_event(ev)  # device-side ordering with the consumer's stream, no host sync
+                for v in batch.values():
+                    if isinstance(v, torch.Tensor) and v.is_cuda:
+                        v.record_stream(torch.cuda.current_stream())
             self._state = state
             yield batch
 

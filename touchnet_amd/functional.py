@@ -139,6 +139,44 @@ def packed_attention_sharded(q_local, k_full, v_full, mask: PackedMask, shard: S
                           int(shard.rows_per_batch))[0]
 
 
+class _SplitAttention(torch.autograd.Function):
+    """Context-parallel attention with the exchange hidden under the LOCAL part: the rank's query rows first attend to
+    the keys of its OWN chunks (in the global K/V buffers from the start), then the compute stream waits for the halo
+    (`wait`), the rows attend to the RECEIVED chunks, and the two partial results are merged by their log-sum-exp
+    (tn_attn_merge).  The backward is ONE tn_attn_bwd_seg over all chunks with the merged O / LSE — the gradient of a
+    softmax over the union of the key sets does not care how the forward was split."""
+
+    @staticmethod
+    def forward(ctx, q, k_full, v_full, doc, meta, scale, segs, rpb, chunk_len, own_mask, remote_mask, wait):
+        o, lse = L.attn_fwd_seg_chunks(q, k_full, v_full, doc, meta, scale, segs, rpb, chunk_len, own_mask)
+        if wait is not None:
+            wait()
+        if remote_mask:
+            o_b, lse_b = L.attn_fwd_seg_chunks(q, k_full, v_full, doc, meta, scale, segs, rpb, chunk_len, remote_mask)
+            o, lse = L.attn_merge(o, lse, o_b, lse_b)
+        ctx.save_for_backward(_c(q), _c(k_full), _c(v_full), o, lse, doc, meta)
+        ctx.scale, ctx.segs, ctx.rpb = scale, list(segs), rpb
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, o, lse, doc, meta = ctx.saved_tensors
+        dq, dk, dv = L.attn_bwd_seg(q, k, v, o, do, lse, doc, meta, ctx.scale, ctx.segs, ctx.rpb)
+        return dq, dk, dv, None, None, None, None, None, None, None, None, None
+
+
+def packed_attention_sharded_split(q_local, k_full, v_full, mask: PackedMask, shard: SeqShard, chunk_len: int,
+                                   own_chunks, remote_chunks, wait=None, scale: Optional[float] = None):
+    """`packed_attention_sharded` as two key-side parts + an LSE merge: `own_chunks` / `remote_chunks` = indices of the
+    sequence chunks (of `chunk_len` positions) the first / second part covers; `wait()` is called between the two (the
+    halo exchange's completion: the remote chunks of k_full / v_full may still be in flight before it)."""
+    if scale is None:
+        scale = q_local.shape[-1] ** -0.5
+    bits = lambda cs: sum(1 << int(c) for c in cs)
+    return _SplitAttention.apply(q_local, k_full, v_full, mask.doc, mask.meta, float(scale), shard.flat(),
+                                 int(shard.rows_per_batch), int(chunk_len), bits(own_chunks), bits(remote_chunks), wait)
+
+
 # ------------------------------------------------------------------------------------ loss
 def _num_sentence_dev(num_sentence, device):
     if isinstance(num_sentence, torch.Tensor):
@@ -244,7 +282,12 @@ class _FusedLinearCE(torch.autograd.Function):
             # (index_add: the filler rows of the static form repeat index 0 and carry exact zeros)
             dh = torch.zeros(n_all, H, dtype=dh.dtype, device=dh.device).index_add_(0, rows, dh)
         if overflow is not None:
-            out = torch.where(overflow, torch.full_like(out, float("nan")), out)
+            # a bound that is too small poisons the statistics AND both gradients (they were computed from the truncated
+            # label set): the optimizer's non-finite check then skips the step instead of applying it
+            poison = torch.where(overflow, float("nan"), 1.0)
+            out = out * poison.to(out.dtype)
+            dh = dh * poison.to(dh.dtype)
+            dw = dw * poison.to(dw.dtype) if dw is not None else dw
         ctx.save_for_backward(dh, dw)
         ctx.hshape, ctx.wdtype = hidden.shape, weight.dtype
         ctx.mark_non_differentiable(out)

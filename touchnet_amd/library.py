@@ -406,6 +406,51 @@ def _(q, k, v, doc, meta, scale, segs, rows_per_batch):
     return torch.empty_like(q, memory_format=torch.contiguous_format), q.new_empty(B, Nh, R, dtype=torch.float32)
 
 
+@custom_op(f"{NS}::attn_fwd_seg_chunks", mutates_args=(), device_types="cuda")
+def attn_fwd_seg_chunks(q: Tensor, k: Tensor, v: Tensor, doc: Tensor, meta: Tensor, scale: float, segs: List[int],
+                        rows_per_batch: int, chunk_len: int, chunk_mask: int) -> Tuple[Tensor, Tensor]:
+    """attn_fwd_seg with the KEY side restricted to the sequence chunks whose bit is set in `chunk_mask` (chunk c =
+    positions [c * chunk_len, (c + 1) * chunk_len)).  Rows without a key there: O = 0, LSE2 = +inf.  One half of the
+    local / remote split of context-parallel attention (no autograd formula of its own: functional._SplitAttention
+    differentiates the MERGED result with one attn_bwd_seg)."""
+    q, k, v = _c(q), _c(k), _c(v)
+    if q.dtype != torch.bfloat16:
+        raise _C.KernelError("packed_attention_sharded: bf16 only")
+    B, R, Nh, D = q.shape
+    T, Nkv = k.shape[1], k.shape[2]
+    if tuple(doc.shape) != (B, T) or R != rows_per_batch:
+        raise _C.KernelError(f"mask {tuple(doc.shape)} / shard {rows_per_batch} vs q {(B, R)} k {(B, T)}")
+    o = torch.empty_like(q)
+    lse2 = torch.empty(B, Nh, R, dtype=torch.float32, device=q.device)
+    _C.check(_lib().tn_attn_fwd_seg_chunks(_p(q), _p(k), _p(v), _p(o), _p(lse2), _p(doc), _p(meta), B, T, Nh, Nkv, D,
+                                           float(scale), len(segs) // 3, _segs_array(segs), R, int(chunk_len),
+                                           int(chunk_mask), _cur()), "tn_attn_fwd_seg_chunks")
+    return o, lse2
+
+
+@attn_fwd_seg_chunks.register_fake
+def _(q, k, v, doc, meta, scale, segs, rows_per_batch, chunk_len, chunk_mask):
+    B, R, Nh, D = q.shape
+    return torch.empty_like(q, memory_format=torch.contiguous_format), q.new_empty(B, Nh, R, dtype=torch.float32)
+
+
+@custom_op(f"{NS}::attn_merge", mutates_args=(), device_types="cuda")
+def attn_merge(o_a: Tensor, lse2_a: Tensor, o_b: Tensor, lse2_b: Tensor) -> Tuple[Tensor, Tensor]:
+    """Two partial attention results over disjoint key sets -> (O, LSE2) of their union (log2-domain LSE, +inf = empty)."""
+    o_a, o_b, la, lb = _c(o_a), _c(o_b), _c(lse2_a), _c(lse2_b)
+    B, R, Nh, D = o_a.shape
+    o, lse2 = torch.empty_like(o_a), torch.empty_like(la)
+    _C.check(_lib().tn_attn_merge(_p(o_a), _p(la), _p(o_b), _p(lb), _p(o), _p(lse2), B, R, Nh, D, _cur()),
+             "tn_attn_merge")
+    return o, lse2
+
+
+@attn_merge.register_fake
+def _(o_a, lse2_a, o_b, lse2_b):
+    return (torch.empty_like(o_a, memory_format=torch.contiguous_format),
+            torch.empty_like(lse2_a, memory_format=torch.contiguous_format))
+
+
 @custom_op(f"{NS}::attn_bwd_seg", mutates_args=(), device_types="cuda")
 def attn_bwd_seg(q: Tensor, k: Tensor, v: Tensor, o: Tensor, do: Tensor, lse2: Tensor, doc: Tensor, meta: Tensor,
                  scale: float, segs: List[int], rows_per_batch: int) -> Tuple[Tensor, Tensor, Tensor]:
@@ -728,6 +773,6 @@ def _(feat, quantizer, codebook):
 
 
 OPS = ("rmsnorm_fwd", "rmsnorm_bwd", "layernorm_fwd", "layernorm_bwd", "swiglu_fwd", "swiglu_bwd", "gelu_fwd",
-       "gelu_bwd", "rope_apply", "attn_fwd", "attn_bwd", "attn_bwd_stacked", "attn_build_meta", "attn_fwd_seg", "attn_bwd_seg", "ce_fwd",
+       "gelu_bwd", "rope_apply", "attn_fwd", "attn_bwd", "attn_bwd_stacked", "attn_build_meta", "attn_fwd_seg", "attn_fwd_seg_chunks", "attn_merge", "attn_bwd_seg", "ce_fwd",
        "ce_bwd", "ce_bwd_", "gemm_tn", "rope_table", "transpose_bf16_", "colsum_bf16", "swiglu_fwd_t", "swiglu_bwd_t",
        "ce_fwd_rows", "ce_reduce", "kaldi_fbank", "log_mel", "audiofeat_stack", "pcm16_to_f32", "bestrq_tokenize")

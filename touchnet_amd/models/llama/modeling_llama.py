@@ -88,20 +88,21 @@ class Attention(nn.Module):
 
 
     def _forward_context_parallel(self, x, cos, sin, mask, cp):
-        """Halo-exchange form: K/V first, their exchange is issued, the QUERY path (projection + RoPE) runs while the
-        chunks travel over xGMI, the compute stream waits for them in front of the attention kernel; the backward
-        returns the partial dK/dV under the query-path backward GEMMs (utils/context_parallel.py::exchange_kv)."""
+        """Halo-exchange form: K/V first, their exchange is issued, the QUERY path (projection + RoPE) and then the
+        attention over the rank's OWN chunks run while the remote chunks travel over xGMI; the compute stream waits for
+        them only in front of the attention over the received chunks, and the two parts are merged by their LSE.  The
+        backward returns the partial dK/dV under the query-path backward GEMMs (utils/context_parallel.py)."""
         from touchnet_amd.utils.context_parallel import exchange_kv
         B, T, _ = x.shape
         k, v = ops().linear_group(x, [(self.k_proj.weight, self.k_proj.bias), (self.v_proj.weight, self.v_proj.bias)])
         k = k.view(B, T, self.num_kv_heads, self.head_dim)
         v = v.view(B, T, self.num_kv_heads, self.head_dim)
         k, _ = ops().apply_rope(k, k.new_empty(B, T, 0, self.head_dim), cos, sin)       # rotate K alone
-        finish = exchange_kv(cp, k, v)
+        exchange = exchange_kv(cp, k, v)
         q = ops().linear_group(x, [(self.q_proj.weight, self.q_proj.bias)])[0].view(B, T, self.num_heads, self.head_dim)
         q, _ = ops().apply_rope(q, q.new_empty(B, T, 0, self.head_dim), cos, sin)
-        k_full, v_full = finish()
-        a = ops().packed_attention_sharded(q, k_full, v_full, mask, cp.seq_shard(), self.scaling)
+        # own-chunk attention while the remote chunks still travel, then the received chunks, merged by LSE
+        a = exchange.attend(q, mask, self.scaling)
         return ops().linear_group(a.view(B, T, self.num_heads * self.head_dim), [(self.o_proj.weight, None)])[0]
 
 
@@ -245,10 +246,15 @@ class PackedCausalLM(nn.Module):
         sl_c = sentence_lens.reshape(-1).index_select(0, rows)[None]
         loss, per_token, acc = fused_linear_cross_entropy(h, self.lm_head.weight, lab_c, sl_c, num_sentence,
                                                           chunk_tokens=ce_chunk_tokens, compact=False)
-        nan = torch.full((), float("nan"), dtype=loss.dtype, device=loss.device)
+        # A bound that is too small must not train on the truncated label set: poison the loss AND — through it — every
+        # gradient (loss * NaN back-propagates NaN), so that the optimizer's device-side non-finite check skips the step;
+        # `torch.where(overflow, nan, loss)` alone would give the real loss a ZERO gradient and AdamW would still apply
+        # its weight decay and stale momentum.  The accuracy is poisoned as well.
         overflow = count > n_max
-        loss = torch.where(overflow, nan, loss)
-        per_token = torch.where(overflow, nan.to(per_token.dtype), per_token)
+        poison = torch.where(overflow, float("nan"), 1.0).to(loss.dtype)
+        loss = loss * poison
+        per_token = per_token * poison.to(per_token.dtype)
+        acc = acc * poison.to(acc.dtype) if isinstance(acc, torch.Tensor) else acc
         return SimpleNamespace(logits=None, loss=loss, loss_per_token=per_token, acc=acc)
 
     def forward(self, input_ids=None, inputs_embeds=None, position_ids=None, attention_mask=None,

@@ -128,7 +128,10 @@ class ContextParallel:
         Host tensor: exact `halo_need`.  Device tensor: `halo_need_ranges` on the device, the [cp, 2cp] table comes
         back through a pinned buffer without blocking (it is waited for at the first exchange of the step)."""
         if not doc_ids.is_cuda:
-            self._need, self._need_pending = halo_need(doc_ids.detach().numpy(), self.cp), None
+            # the RANGE criterion here too: the attention kernels decide per tile by id ranges, and the global K/V
+            # buffers are uninitialised outside the received chunks — an exact (shared-id) table would be a strict
+            # subset of what they may touch as soon as ids are not non-decreasing along a row
+            self._need, self._need_pending = halo_need_ranges(doc_ids.detach(), self.cp).numpy().copy(), None
             return
         table = halo_need_ranges(doc_ids.detach(), self.cp)
         host = torch.empty(table.shape, dtype=torch.bool).pin_memory()
@@ -141,7 +144,8 @@ class ContextParallel:
     def need(self):
         if self._need_pending is not None:
             host, ev = self._need_pending
-            ev.synchronize()             # a few hundred bytes issued when the batch arrived: long done by now
+            if not ev.query():           # (a few hundred bytes issued when the batch arrived: long done by now; pass the
+                ev.synchronize()         #  host copy of the ids to set_documents — bin/train.py does — and there is no event)
             self._need, self._need_pending = host.numpy().copy(), None
         return self._need
 
@@ -334,13 +338,58 @@ class _HaloFinish(torch.autograd.Function):
         return gk_full, gv_full, None
 
 
-def exchange_kv(cp: ContextParallel, k_local: torch.Tensor, v_local: torch.Tensor):
-    """Start the halo exchange of a layer's K/V.  Returns `finish`: call it AFTER the query-path work has been issued,
-    it returns the global (k_full, v_full) ready for `packed_attention_sharded`.  Needs `cp.set_documents` (the
-    all-gather fallback has nothing to overlap with: use `cp.gather_seq`)."""
+class _HaloReturn(torch.autograd.Function):
+    """forward: nothing (the waiting is done INSIDE the split attention, between its local and its remote part);
+    backward: ISSUE the return of the partial dK/dV (the query-path backward runs while they travel)."""
+
+    @staticmethod
+    def forward(ctx, k_full, v_full, link: _Link):
+        ctx.link = link
+        ctx.mark_dirty(k_full, v_full)
+        return k_full, v_full
+
+    @staticmethod
+    def backward(ctx, gk_full, gv_full):
+        link = ctx.link
+        link.g_locals, link.bwd = _start_backward(link.cp, [gk_full.contiguous(), gv_full.contiguous()])
+        return gk_full, gv_full, None
+
+
+class KVExchange:
+    """A layer's K/V halo exchange in flight.  `attend(q, mask, scale)` = the attention with the exchange hidden under
+    its local part; calling the object (`finish()`) = the round-2 form: wait, then hand out the global (k_full, v_full)."""
+
+    def __init__(self, cp, k_full, v_full, link):
+        self.cp, self.k_full, self.v_full, self.link = cp, k_full, v_full, link
+
+    def __call__(self):
+        return _HaloFinish.apply(self.k_full, self.v_full, self.link)
+
+    def attend(self, q_local, mask, scale=None):
+        """Local query rows against (a) the keys of this rank's OWN chunks — already in the global buffers — while the
+        remote chunks travel, then (b) the received chunks; (a) and (b) are merged by their log-sum-exp
+        (functional.packed_attention_sharded_split; the reference's ring merges per-step (out, lse) pairs the same way:
+        torch ... _context_parallel/_attention.py:182-183 via touchnet/utils/distributed.py:292-315)."""
+        from touchnet_amd.models.backend import ops
+        cp, link = self.cp, self.link
+        k_full, v_full = _HaloReturn.apply(self.k_full, self.v_full, link)
+        mine = cp.my_chunks()
+        remote = [c for c in range(2 * cp.cp) if cp.need[cp.rank, c] and c not in mine]
+
+        def wait():
+            link.fwd.wait()
+            link.fwd = None
+        return ops().packed_attention_sharded_split(q_local, k_full, v_full, mask, cp.seq_shard(), cp.Tc, list(mine),
+                                                    remote, wait, scale)
+
+
+def exchange_kv(cp: ContextParallel, k_local: torch.Tensor, v_local: torch.Tensor) -> KVExchange:
+    """Start the halo exchange of a layer's K/V.  Call the result's `attend(q, mask, scale)` AFTER the query-path work
+    has been issued (or call it like a function to get the global (k_full, v_full) once they have landed).  Needs
+    `cp.set_documents` (the all-gather fallback has nothing to overlap with: use `cp.gather_seq`)."""
     link = _Link(cp)
     k_full, v_full = _HaloStart.apply(k_local, v_local, link)
-    return lambda: _HaloFinish.apply(k_full, v_full, link)
+    return KVExchange(cp, k_full, v_full, link)
 
 
 class _GatherSeq(torch.autograd.Function):
