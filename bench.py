@@ -16,7 +16,17 @@ Workloads (BASELINE.json `configs`):
                               length like in the reference's processor (64 clips per GPU instead of 20): shows the audio
                               tower running on the kept frames only (TN_TOWER_VALID_FRAMES=0: the reference's schedule)
     llama_asr_1b              LlamaForASR-1B, fbank-80 stack5/stride4, packed B=1 x T=8192
+    qwen2_audio_7b_long       BASELINE config D: Qwen2-Audio-7B on 20-minute recordings, packed B=1 x T=65536, context
+                              parallel (`--cp 4`: zig-zag chunks, K/V halo exchange over xGMI, FSDP2 over dp x cp)
+    kimi_audio_7b             BASELINE config E: Kimi-Audio-7B decoder (28 + 6 layers, 168448-way text head), interleaved
+                              audio-code / text documents, packed B=2 x T=8192, tensor parallel (`--tp 2`) x FSDP2
     tiny                      2-layer d=256 smoke configuration
+Mesh flags: `--cp N` / `--tp N` split the `--gpus` ranks as dp x cp x tp (dp = gpus / (cp * tp); mesh and process groups are
+the reference's ParallelDims, touchnet/utils/distributed.py:71-196).  `--emulate-rank r` (with --gpus 1) runs rank r of the
+cp- or tp-way group ALONE on one MI355X: its shards, its kernels, its share of the clips and tokens; the exchanges with the
+peers are skipped (context parallelism: the K/V chunks a real run would receive are stand-in copies of local chunks, so the
+attention kernels do the same tile work on other values).  Such a line is the per-GPU compute time of that rank — an upper
+bound on what the group can reach — and says so in `config.emulated`.
 Weights are random-init (HF init, seed 2025), data is synthetic: there is no network for checkpoints/datasets.
 
 Prints ONE JSON line on rank 0.
@@ -65,6 +75,41 @@ def llama_1b_text_config():
                          "original_max_position_embeddings": 8192, "rope_type": "llama3"}})
 
 
+def kimi_audio_7b_config():
+    from touchnet_amd.models.kimi_audio import KimiAudioConfig
+    # examples/audio/sft/asr/wenetspeech/config/Kimi-Audio-7B.json (the decoder keys)
+    return KimiAudioConfig.from_dict({
+        "hidden_size": 3584, "intermediate_size": 18944, "num_attention_heads": 28, "num_key_value_heads": 4,
+        "num_hidden_layers": 28, "head_dim": 128, "rms_norm_eps": 1e-6, "rope_theta": 1000000.0, "vocab_size": 168448,
+        "initializer_range": 0.02, "tie_word_embeddings": False, "kimia_mimo_layers": 6,
+        "kimia_mimo_transformer_from_layer_index": 21, "kimia_token_offset": 152064})
+
+
+def parallel_layout(world: int, cp: int = 1, tp: int = 1, emulate_rank=None) -> dict:
+    """How `--gpus / --cp / --tp / --emulate-rank` split the job: dp x cp x tp real ranks, or ONE process playing rank
+    `emulate_rank` of a cp- or tp-way group."""
+    if cp < 1 or tp < 1:
+        raise SystemExit("--cp / --tp must be >= 1")
+    if emulate_rank is not None:
+        if world != 1:
+            raise SystemExit("--emulate-rank plays one rank of the group on ONE GPU: use --gpus 1")
+        if (cp > 1) == (tp > 1):
+            raise SystemExit("--emulate-rank needs exactly one of --cp N / --tp N")
+        n = cp * tp
+        if not 0 <= emulate_rank < n:
+            raise SystemExit(f"--emulate-rank {emulate_rank} outside the {n}-way group")
+        kind = "cp" if cp > 1 else "tp"
+        return {"dp": 1, "cp": cp, "tp": tp, "emulated": {"group": kind, "size": n, "rank": emulate_rank},
+                "label": f"{kind}{n} (rank {emulate_rank} emulated on one GPU, exchanges skipped)"}
+    if world % (cp * tp):
+        raise SystemExit(f"--gpus {world} is not a multiple of cp x tp = {cp * tp}")
+    dp = world // (cp * tp)
+    parts = [f"cp{cp}"] if cp > 1 else []
+    parts += [f"tp{tp}"] if tp > 1 else []
+    parts += [f"fsdp2-dp{dp}" + (f" (parameters sharded over dp x cp = {dp * cp})" if cp > 1 else "")] if dp * cp > 1 else []
+    return {"dp": dp, "cp": cp, "tp": tp, "emulated": None, "label": " x ".join(parts) or "single-gpu"}
+
+
 def tiny_text_config():
     from touchnet_amd.models.llama import DecoderConfig
     return DecoderConfig.from_dict({
@@ -76,7 +121,10 @@ def tiny_text_config():
 class Workload:
     """Holds the device-resident inputs of one rank and produces the batch dict inside the timed step."""
 
-    def __init__(self, name, device, rank, B=None, T=None):
+    def __init__(self, name, device, rank, B=None, T=None, cp=None):
+        """`rank` seeds the data (the DATA-parallel rank: cp / tp peers hold the same batch); `cp` = (cp, cp_rank): the
+        long-audio workload hands every cp rank the 30 s clips that touch ITS part of the sequence — what a loader under
+        context parallelism does once per batch, ahead of the step."""
         import touchnet_amd.functional as F
         from touchnet_amd.bin.train import TrainConfig
         from touchnet_amd.data import synthetic
@@ -111,6 +159,46 @@ class Workload:
                               + (f"{n_tok} audio tokens in all (U[2, 14.5] s utterances, token count from the valid length)"
                                  if short else "750 audio tokens each")
                               + f", ~14-token prompt, U{{5..40}}-token transcripts, packed B={self.B} x T={self.T}")
+        elif name == "qwen2_audio_7b_long":
+            self.B, self.T = B or 1, T or 65536
+            self.job.training_model_name = "qwen2_audio_mi355"
+            self.job.lr_scheduler_lr = 2e-5
+            self.model_config = qwen2_audio_7b_config()
+            self.seq_cfg = self.model_config.text_config
+            tok, n_audio = synthetic.qwen2_audio_long_plan(self.seq_cfg.vocab_size, self.model_config.audio_token_index,
+                                                           self.B, self.T, seed)
+            self.host_tokens = tok
+            self.n_clips_global = n_audio
+            clips = np.arange(n_audio)
+            if cp is not None and cp[0] > 1:
+                from touchnet_amd.utils.context_parallel import ContextParallel
+                view = ContextParallel(None, self.T, emulate=(cp[0], cp[1]))
+                clips, pos, rows = view.shard_audio(tok["audio_positions"].numpy(), tok["audio_output_lengths"].numpy(), 750)
+                lab = tok["labels"]
+                tok = dict(tok, audio_positions=torch.from_numpy(pos), audio_rows=torch.from_numpy(rows),
+                           audio_output_lengths=tok["audio_output_lengths"][clips], audio_cp_sharded=True,
+                           labelled_rows_max_cp=[int((ContextParallel(None, self.T, emulate=(cp[0], r)).shard(lab, 1)
+                                                      != -100).sum()) for r in range(cp[0])])
+            g = torch.Generator().manual_seed(seed)
+            wav = (torch.randn(n_audio, 480000, generator=g) * 0.1).clamp_(-1, 1)    # consecutive 30 s windows: all speech
+            self.wav = wav[torch.from_numpy(clips)].to(device)
+            self.tokens = {k: (v.to(device) if isinstance(v, torch.Tensor) else v) for k, v in tok.items()}
+            self.data_desc = (f"synthetic long audio: documents of up to 40 consecutive 30 s windows (20 min, 750 audio "
+                              f"tokens each) + ~50 transcript tokens per window, packed B={self.B} x T={self.T}: "
+                              f"{n_audio} clips per row group, {len(clips)} of them on this rank")
+        elif name == "kimi_audio_7b":
+            self.B, self.T = B or 2, T or 8192
+            self.job.training_model_name = "kimi_audio_mi355"
+            self.job.lr_scheduler_lr = 2e-5
+            self.model_config = kimi_audio_7b_config()
+            self.seq_cfg = self.model_config
+            c = self.model_config
+            tok = synthetic.kimi_audio_plan(c.kimia_token_offset, c.kimia_token_offset, c.vocab_size - c.kimia_token_offset,
+                                            self.B, self.T, seed)
+            self.tokens = {k: (v.to(device) if isinstance(v, torch.Tensor) else v) for k, v in tok.items()}
+            self.data_desc = (f"synthetic interleaved audio/text: U[2, 14.5] s of 12.5 Hz audio codes on the audio stream, "
+                              f"then a U{{5..40}}-token transcript on the text stream (labels on the transcript, text head), "
+                              f"packed B={self.B} x T={self.T}")
         elif name in ("llama_asr_1b", "tiny"):
             text = llama_1b_text_config() if name == "llama_asr_1b" else tiny_text_config()
             self.B, self.T = B or 1, T or (8192 if name == "llama_asr_1b" else 512)
@@ -129,6 +217,8 @@ class Workload:
     def make_batch(self):
         """Runs the device frontend and returns the batch dict (everything already on the device)."""
         F = self.F
+        if self.name == "kimi_audio_7b":
+            return dict(self.tokens)                 # (discrete codes: the frozen VQ tokenizer is the loader's, out of scope)
         if self.name.startswith("qwen2_audio_7b"):
             mel = torch.stack([F.log_mel_spectrogram(w, 128) for w in self.wav])       # [n, 3000, 128]
             batch = dict(self.tokens)
@@ -202,6 +292,34 @@ def cpu_baseline(workload: "Workload", seconds_budget: float = 20.0):
                       f"({t1 * 1e3:.3f} / {t2 * 1e3:.3f} ms per token per layer), per-token cost a + b*T evaluated at the "
                       f"workload's T={workload.T}, x{cfg.num_hidden_layers} layers, + lm_head/CE on {Th} tokens; audio "
                       f"tower and optimizer excluded -> an upper bound on CPU throughput"}
+
+
+def executed_flops_per_gpu(wl: "Workload", trainer, layout: dict, lm_head_rows: int) -> float:
+    """FLOPs ONE GPU of a cp / tp layout executes per step (the sharded workloads' counterpart of the headline's
+    `step_mfu_executed_flops`): 6 x parameters x rows for every GEMM on the rows it actually runs on, attention on the
+    allowed (query, key) pairs of this rank's query rows (position_ids + 1 keys per query), fwd + 2.5x bwd."""
+    c, cp, tp = wl.seq_cfg, layout["cp"], layout["tp"]
+    tok = getattr(wl, "host_tokens", None) or {k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in wl.tokens.items()}
+    pos, doc = tok["position_ids"], tok["attention_mask"]
+    if cp > 1:
+        from touchnet_amd.utils.context_parallel import ContextParallel
+        view = ContextParallel(None, wl.T, emulate=(cp, trainer.cp.rank if trainer.cp is not None else 0))
+        pos, doc = view.shard(pos, 1), view.shard(doc, 1)
+    rows = pos.numel()
+    pairs = int(((pos + 1) * (doc > 0)).sum())
+    H, I, Nh, Nkv, D, L = (c.hidden_size, c.intermediate_size, c.num_attention_heads, c.num_key_value_heads, c.head_dim,
+                           c.num_hidden_layers)
+    layer = H * Nh * D * 2 + 2 * H * Nkv * D + 3 * H * I
+    fl = 6.0 * layer * L * rows / tp
+    fl += 3.5 * 4.0 * D * (Nh / tp) * pairs * L
+    fl += 6.0 * c.vocab_size * H * lm_head_rows
+    if hasattr(wl, "wav"):
+        ac = wl.model_config.audio_config
+        tower = sum(p.numel() for p in trainer.model.audio_tower.parameters())
+        n = wl.wav.shape[0]
+        fl += 6.0 * tower * n * 1500 + 3.5 * 4.0 * 64 * ac.encoder_attention_heads * n * (1500 * 1501 // 2) * ac.encoder_layers
+        fl += 6.0 * ac.d_model * H * n * 750
+    return fl
 
 
 def kernel_rooflines(workload: "Workload"):
@@ -315,7 +433,13 @@ def main():
     ap.add_argument("--linear-gemm", choices=("lib", "own"), default=None,
                     help="own (default) = the linear layers' GEMMs on the hand-written MFMA kernel (csrc/gemm.hip) in its "
                          "native operand modes; lib = hipBLASLt on transposed copies (A/B runs; TN_LINEAR_GEMM)")
+    ap.add_argument("--cp", type=int, default=1, help="context-parallel degree (ranks split as dp x cp x tp)")
+    ap.add_argument("--tp", type=int, default=1, help="tensor-parallel degree")
+    ap.add_argument("--emulate-rank", type=int, default=None,
+                    help="with --gpus 1 and --cp N or --tp N: run rank r of the N-way group alone on one GPU")
+    ap.add_argument("--ac", choices=("none", "full", "selective"), default="none", help="activation checkpointing mode")
     args = ap.parse_args()
+    layout = parallel_layout(args.gpus, args.cp, args.tp, args.emulate_rank)
     if args.linear_gemm:
         import touchnet_amd.functional as _F
         _F.LINEAR_GEMM = args.linear_gemm
@@ -334,16 +458,41 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     device = torch.device("cuda", local)
     forced = os.environ.get("TN_FORCE_FSDP") == "1"     # (development: FSDP2 over a 1-rank RCCL mesh on one GPU)
-    mesh = build_dp_mesh("cuda", world) if (world > 1 or forced) else None
+    dp_mesh = cp_mesh = tp_mesh = fsdp_mesh = cp_emulate = None
+    dp_rank, cp_view = rank, None
+    emu = layout["emulated"]
+    if emu:
+        if emu["group"] == "cp":
+            cp_emulate = cp_view = (emu["size"], emu["rank"])
+        else:
+            from touchnet_amd.models.tensor_parallel import EmulatedTPMesh
+            tp_mesh = EmulatedTPMesh(emu["size"], emu["rank"])
+    elif args.cp > 1 or args.tp > 1:
+        from touchnet_amd.utils.distributed import ParallelDims
+        mesh = ParallelDims(dp_replicate=1, dp_shard=layout["dp"], cp=args.cp, tp=args.tp, pp=1,
+                            world_size=world).build_mesh("cuda")
+        names = mesh.mesh_dim_names
+        dp_mesh = mesh["dp"] if "dp_shard" in names else None
+        cp_mesh = mesh["cp"] if "cp" in names else None
+        tp_mesh = mesh["tp"] if "tp" in names else None
+        fsdp_mesh = mesh["dp_shard_cp"] if ("dp_shard" in names or "cp" in names) else None
+        dp_rank = dp_mesh.get_local_rank() if dp_mesh is not None else 0
+        if cp_mesh is not None:
+            cp_view = (args.cp, cp_mesh.get_local_rank())
+    else:
+        dp_mesh = build_dp_mesh("cuda", world) if (world > 1 or forced) else None
+    mesh = dp_mesh
 
-    wl = Workload(args.workload, device, rank, args.batch, args.seqlen)
+    wl = Workload(args.workload, device, dp_rank, args.batch, args.seqlen, cp=cp_view)
     wl.job.training_enable_fused_ce = not args.unfused_ce
     wl.job.training_ce_compact_rows = args.compact_lm_head
+    wl.job.training_activation_checkpoint_mode = args.ac
     if args.all_rows_lm_head and hasattr(wl, "tokens"):
         wl.tokens.pop("labelled_rows_max", None)
     if args.ce_chunk:
         wl.job.training_ce_chunk_tokens = args.ce_chunk
-    trainer = Trainer(wl.job, wl.model_config, device, dp_mesh=mesh)
+    trainer = Trainer(wl.job, wl.model_config, device, dp_mesh=dp_mesh, cp_mesh=cp_mesh, fsdp_mesh=fsdp_mesh,
+                      tp_mesh=tp_mesh, cp_emulate=cp_emulate)
 
     def step():
         batch = trainer.next_batch(wl.make_batch())
@@ -372,10 +521,21 @@ def main():
     elapsed = float(t)
     ev_ms = ev0.elapsed_time(ev1) / args.steps
 
-    tokens_per_step = wl.B * wl.T * world                       # reference convention: labels.numel() (train.py:345)
+    # reference convention: labels.numel() per data-parallel rank (train.py:345); the cp / tp peers of a rank work on the
+    # SAME rows, so the job's tokens are dp x B x T.  An emulated rank reports its own share of them (1/cp of the
+    # sequence; 1/tp of the model on all tokens -> the tokens are credited 1/tp as well): per-GPU numbers throughout.
+    share = layout["cp"] * layout["tp"]
+    tokens_per_step = wl.B * wl.T * layout["dp"] / (share if emu else 1)
     tps = tokens_per_step * args.steps / elapsed
-    fpt = trainer.spec.get_num_flop_per_token_fn(trainer.num_params_wo_emb, wl.model_config, wl.T)
-    mfu = fpt * (tps / world) / MFMA_PEAK
+    gpus_in_job = 1 if emu else world
+    if wl.name == "kimi_audio_7b":
+        # the recipe trains the TEXT head: the mimo branch (6 layers + the audio head) is not executed, and the reference
+        # formula (kimi_audio/__init__.py:63-80: L + L_mimo layers, all parameters) must not be credited with it
+        fpt = trainer.spec.get_num_flop_per_token_fn(trainer.num_params_wo_emb, wl.model_config, wl.T, with_mimo=False,
+                                                     model=trainer.model, tp=layout["tp"])
+    else:
+        fpt = trainer.spec.get_num_flop_per_token_fn(trainer.num_params_wo_emb, wl.model_config, wl.T)
+    mfu = fpt * (tps / gpus_in_job) / MFMA_PEAK
     nonpad = int((wl.tokens["attention_mask"] > 0).sum()) if hasattr(wl, "tokens") else None
     lrm = None if args.all_rows_lm_head else wl.make_batch().get("labelled_rows_max")     # what the packer told the model
     loss = float(stats["loss_per_sample"])
@@ -385,8 +545,16 @@ def main():
             "value": round(tps, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": wl.data_desc + "; random-init weights",
-            "config": {"workload": wl.name, "model": wl.job.training_model_name, "global_batch": wl.B * world,
-                       "seq_len": wl.T, "parallelism": f"fsdp2-dp{world}" if (world > 1 or forced) else "single-gpu",
+            "config": {"workload": wl.name, "model": wl.job.training_model_name, "global_batch": wl.B * layout["dp"],
+                       "seq_len": wl.T,
+                       "parallelism": (layout["label"] if (args.cp > 1 or args.tp > 1) else
+                                       f"fsdp2-dp{world}" if (world > 1 or forced) else "single-gpu"),
+                       **({"emulated": dict(emu, note="ONE rank of the group on one MI355X: its shards, kernels and share "
+                                                      "of the data; exchanges with the peers skipped (cp: stand-in K/V "
+                                                      "chunks of the same shape and document ids).  `value` is this GPU's "
+                                                      "share of the tokens per second, not a group measurement")}
+                          if emu else {}),
+                       "activation_checkpointing": args.ac,
                        "params": trainer.num_params, "flop_per_token": fpt,
                        "fused_linear_ce": wl.job.training_enable_fused_ce,
                        "lm_head_rows": ("labelled only (exact count, host sync)" if args.compact_lm_head else
@@ -408,12 +576,35 @@ def main():
             "nonpad_tokens_per_step_rank0": nonpad,
             "loss_per_sample_last": round(loss, 5), "hip_event_ms_per_step_rank0": round(ev_ms, 2),
             "peak_mem_GB_rank0": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
-            "roofline": {"bound": "mfma", "achieved": round(fpt * (tps / world) / 1e12, 1), "peak": MFMA_PEAK / 1e12,
+            "roofline": {"bound": "mfma", "achieved": round(fpt * (tps / gpus_in_job) / 1e12, 1), "peak": MFMA_PEAK / 1e12,
                          "unit": "TFLOP/s", "frac": round(mfu, 4), "traffic": None,
                          "note": "whole training step per GPU against the dense bf16 MFMA peak (reference MFU "
                                  "formula); per-kernel rooflines of the hand-written HIP kernels in `kernels`"},
         }
-        if not args.no_kernel_rooflines and args.workload != "tiny":
+        if wl.name == "kimi_audio_7b":
+            line["mfu_convention"] = ("6*N + 12*L*H*Dh*T per token over the EXECUTED graph only: 28 decoder layers + text "
+                                      "head (the reference formula, kimi_audio/__init__.py:63-80, also counts the 6 mimo "
+                                      "layers and the audio head, which a text-head step never runs); per GPU: block "
+                                      "parameters / tp, heads replicated")
+        if (args.cp > 1 or args.tp > 1):
+            line["kernels_note"] = "per-kernel rooflines are reported on the headline workload (python bench.py)"
+            rows_local = wl.B * wl.T // layout["cp"]
+            lm_rows = rows_local
+            if wl.job.training_enable_fused_ce and not args.all_rows_lm_head and not args.compact_lm_head:
+                bound = (wl.tokens.get("labelled_rows_max_cp", [None] * layout["cp"])[trainer.cp.rank]
+                         if layout["cp"] > 1 else wl.tokens.get("labelled_rows_max"))
+                if bound is not None:
+                    lm_rows = min(rows_local, (int(bound) + 255) // 256 * 256)
+            line["config"]["lm_head_rows"] = f"{lm_rows} of this rank's {rows_local} positions"
+            ex = executed_flops_per_gpu(wl, trainer, layout, lm_rows) / (elapsed / args.steps) / MFMA_PEAK
+            line["step_mfu_executed_flops"] = round(ex, 4)
+            line["roofline"].update({"achieved": round(ex * MFMA_PEAK / 1e12, 1), "frac": round(ex, 4),
+                                     "formula_achieved": round(fpt * (tps / gpus_in_job) / 1e12, 1),
+                                     "formula_frac": round(mfu, 4),
+                                     "note": "one GPU's training step against the dense bf16 MFMA peak: `frac` on the FLOPs "
+                                             "this rank executes (bench.executed_flops_per_gpu), `formula_frac` by the "
+                                             "reference MFU formula on its share of the tokens"})
+        elif not args.no_kernel_rooflines and args.workload != "tiny":
             try:
                 line["kernels"], allowed_pairs = kernel_rooflines(wl)
                 step_ms = elapsed / args.steps * 1e3
@@ -447,7 +638,7 @@ def main():
                 # the roofline's primary number is the utilisation on EXECUTED flops; the reference-formula value (which
                 # credits attention pairs the document mask never computes) stays beside it and in `step_mfu`
                 line["roofline"].update({"achieved": round(ex_frac * MFMA_PEAK / 1e12, 1), "frac": round(ex_frac, 4),
-                                         "formula_achieved": round(fpt * (tps / world) / 1e12, 1),
+                                         "formula_achieved": round(fpt * (tps / gpus_in_job) / 1e12, 1),
                                          "formula_frac": round(mfu, 4),
                                          "note": "whole training step per GPU against the dense bf16 MFMA peak: `frac` on the "
                                                  "FLOPs the step executes, `formula_frac` by the reference MFU formula; "

@@ -1,0 +1,371 @@
+"""BASELINE configs D (Qwen2-Audio long audio, context parallel) and E (Kimi-Audio, tensor parallel x FSDP2): the host
+logic that splits a batch / a model over the ranks, on CPU (gloo, world size 2 and 4; emulated ranks in one process).
+The per-op arithmetic is the oracle's, injected explicitly — the product has no CPU path."""
+import os
+import socket
+import types
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from test_distributed_cpu import KIMI_TINY, TINY, TorchAdamW, _free_port, _tp_batch, _tp_model
+
+QA_TINY = {"audio_config": {"num_mel_bins": 8, "d_model": 32, "encoder_layers": 2, "encoder_attention_heads": 4,
+                            "encoder_ffn_dim": 64, "max_source_positions": 10, "init_std": 0.2},
+           "audio_token_index": 15,
+           "text_config": dict(TINY, num_hidden_layers=1, tie_word_embeddings=False, model_type="qwen2")}
+TA = 5            # tokens per clip of the tiny tower: 20 mel frames -> conv stride 2 -> pool 2
+
+
+def _qa_batch(T=512, B=1, seed=3):
+    from touchnet_amd.data.synthetic import qwen2_audio_long_plan
+    tok, n = qwen2_audio_long_plan(15, 15, B, T, seed, tokens_per_clip=TA, resp_per_clip=(1, 3))
+    g = torch.Generator().manual_seed(seed)
+    tok["input_features"] = torch.randn(n, 8, 20, generator=g)
+    return tok, n
+
+
+# ------------------------------------------------------------------------------------------------ host split
+@pytest.mark.parametrize("cp", [2, 4])
+def test_shard_audio_partitions_positions_and_rows(cp):
+    from touchnet_amd.utils.context_parallel import ContextParallel
+    T = 1024
+    tok, n = _qa_batch(T, B=2)
+    pos, lens = tok["audio_positions"].numpy(), tok["audio_output_lengths"].numpy()
+    clip_of = np.repeat(np.arange(n), lens)
+    row_of = np.arange(pos.size) - np.repeat(np.cumsum(lens) - lens, lens)
+    seen = {}
+    straddlers = 0
+    for r in range(cp):
+        view = ContextParallel(None, T, emulate=(cp, r))
+        clips, lpos, rows = view.shard_audio(pos, lens, TA)
+        assert len(lpos) == len(rows) and np.all(np.diff(clips) > 0)
+        Tc = view.Tc
+        b, col = lpos // (2 * Tc), lpos % (2 * Tc)
+        gcol = np.where(col < Tc, r * Tc + col, (2 * cp - 1 - r) * Tc + (col - Tc))
+        for gp, row in zip(b * T + gcol, rows):
+            assert gp not in seen                                      # every position has exactly one owner
+            seen[int(gp)] = (int(clips[row // TA]), int(row % TA))
+        # the sharded token grid really holds AUDIO placeholders there
+        ids = view.shard(tok["input_ids"], 1).reshape(-1)
+        assert bool((ids[torch.from_numpy(lpos)] == 15).all())
+        assert int((ids == 15).sum()) == len(lpos)
+        straddlers += len(clips)
+    assert len(seen) == pos.size
+    for p, c, rw in zip(pos, clip_of, row_of):
+        assert seen[int(p)] == (int(c), int(rw))
+    assert straddlers > n                                              # some clips are cut by a chunk boundary: run twice
+
+
+def test_rank_without_audio_still_runs_the_tower_on_one_clip_and_keeps_no_row():
+    from touchnet_amd.utils.context_parallel import ContextParallel
+    T = 1024
+    view = ContextParallel(None, T, emulate=(2, 1))                    # owns chunks 1 and 2: columns [256, 768)
+    pos = np.arange(10, 20)                                            # two clips inside chunk 0
+    clips, lpos, rows = view.shard_audio(pos, np.array([5, 5]), TA)
+    assert clips.tolist() == [0] and lpos.size == 0 and rows.size == 0
+
+
+def test_parallel_layout_of_the_bench_flags():
+    import bench
+    d = bench.parallel_layout(8, cp=4)
+    assert (d["dp"], d["cp"], d["tp"], d["emulated"]) == (2, 4, 1, None) and d["label"].startswith("cp4 x fsdp2-dp2")
+    e = bench.parallel_layout(8, tp=2)
+    assert (e["dp"], e["tp"]) == (4, 2) and e["label"] == "tp2 x fsdp2-dp4"
+    assert bench.parallel_layout(1)["label"] == "single-gpu"
+    m = bench.parallel_layout(1, cp=4, emulate_rank=3)
+    assert m["emulated"] == {"group": "cp", "size": 4, "rank": 3}
+    for bad in (dict(world=8, cp=3), dict(world=2, cp=4, emulate_rank=0), dict(world=1, cp=2, tp=2, emulate_rank=0),
+                dict(world=1, emulate_rank=0), dict(world=1, tp=2, emulate_rank=2)):
+        with pytest.raises(SystemExit):
+            bench.parallel_layout(bad.pop("world"), **bad)
+
+
+def test_synthetic_plans_of_configs_d_and_e():
+    from touchnet_amd.data.synthetic import kimi_audio_plan, qwen2_audio_long_plan
+    tok, n = qwen2_audio_long_plan(156032, 151646, 1, 65536, 2025)
+    ids, lab, doc = tok["input_ids"][0], tok["labels"][0], tok["attention_mask"][0]
+    assert n == int((ids == 151646).sum()) // 750 and n >= 80                      # two 20-minute recordings + filler
+    assert torch.equal(tok["audio_positions"], (ids == 151646).nonzero().squeeze(1))
+    assert int((lab != -100).sum()) == tok["labelled_rows_max"]
+    assert bool((lab[ids == 151646] == -100).all())                                # no label on an audio position
+    first = int((doc == 1).sum())
+    assert first > 30000 and int(tok["position_ids"][0, first - 1]) == first - 1   # one 40-clip document first
+    k = kimi_audio_plan(152064, 152064, 16384, 2, 8192, 2025)
+    a, t = k["audio_input_ids"], k["text_input_ids"]
+    assert a.shape == t.shape == (2, 8192)
+    assert bool(((a >= 152064) <= (t == 0)).all())                                 # audio codes sit on blank text slots
+    assert bool((k["labels"][a >= 152064] == -100).all())
+    assert int((k["labels"] != -100).sum()) == k["labelled_rows_max"]
+    assert int(a.max()) < 168448
+
+
+# ------------------------------------------------------------------------------------------------ config D on 2 ranks
+def _qa_reference(T):
+    import oracle.ops as oops
+    from touchnet_amd.models.backend import use_ops
+    from touchnet_amd.models.qwen2_audio import Qwen2AudioConfig, Qwen2AudioPackedForConditionalGeneration
+    torch.manual_seed(13)
+    model = Qwen2AudioPackedForConditionalGeneration(Qwen2AudioConfig.from_dict(QA_TINY))
+    model.post_init()
+    tok, _ = _qa_batch(T)
+    with use_ops(oops):
+        out = model(**{k: v for k, v in tok.items() if k not in ("num_sentence", "labelled_rows_max")},
+                    num_sentence=tok["num_sentence"])
+        out.loss.backward()
+    return ({k: v.detach().clone() for k, v in model.state_dict().items()},
+            {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}, float(out.loss), tok)
+
+
+def _qa_worker(rank, world, port, ref_state, ref_grads, ref_loss, batch, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import oracle.ops as oops
+    import touchnet_amd.specs  # noqa: F401
+    from torch.distributed.device_mesh import init_device_mesh
+    from touchnet_amd.bin.train import TrainConfig, Trainer
+    from touchnet_amd.models.backend import use_ops
+    from touchnet_amd.models.qwen2_audio import Qwen2AudioConfig
+    from touchnet_amd.utils.distributed import init_distributed
+    try:
+        init_distributed("cpu")
+        mesh = init_device_mesh("cpu", (1, world), mesh_dim_names=("dp", "cp"))
+        flat = mesh["dp", "cp"]._flatten("dp_cp")
+        job = TrainConfig(training_model_name="qwen2_audio_mi355", training_enable_fused_ce=True,
+                          training_mixed_precision_param="float32")
+        with use_ops(oops):
+            tr = Trainer(job, Qwen2AudioConfig.from_dict(QA_TINY), torch.device("cpu"), dp_mesh=mesh["dp"],
+                         cp_mesh=mesh["cp"], fsdp_mesh=flat, optimizer_factory=lambda ps: TorchAdamW(ps))
+            with torch.no_grad():
+                for name, p in tr.model.named_parameters():
+                    full = ref_state[name]
+                    local = p._local_tensor if hasattr(p, "_local_tensor") else p
+                    local.copy_(full.chunk(world, dim=0)[rank] if local.shape != full.shape else full)
+            data = tr.next_batch(batch)
+            n_all = batch["input_features"].shape[0]
+            n_mine = data["input_features"].shape[0]
+            assert 0 < n_mine < n_all and data["audio_rows"].shape == data["audio_positions"].shape
+            want = int((tr.cp.shard(batch["labels"], 1) != -100).sum())
+            assert data["labelled_rows_max"] == want < batch["labelled_rows_max"]
+            tr.optimizer.zero_grad()
+            loss, _, _ = tr.forward_loss(data)
+            total = loss.detach().clone()
+            dist.all_reduce(total)
+            assert float(total) == pytest.approx(ref_loss, rel=1e-5)
+            loss.backward()
+            worst = 0.0
+            for name, p in tr.model.named_parameters():
+                if name not in ref_grads:                                # (the tower's frozen sinusoidal positions)
+                    assert p.grad is None or not p.requires_grad, name
+                    continue
+                g = p.grad.full_tensor() if hasattr(p.grad, "full_tensor") else p.grad
+                worst = max(worst, float((g * world - ref_grads[name]).abs().max()))
+            assert worst < 5e-5, worst
+        ret[rank] = ("ok", n_mine, n_all)
+    except Exception as e:
+        import traceback
+        ret[rank] = ("fail", traceback.format_exc(), repr(e))
+    finally:
+        if dist.is_initialized():
+            dist.barrier()
+            dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,T", [(2, 512), (4, 1024)])
+def test_qwen2_audio_under_context_parallelism_equals_single_process(world, T):
+    """Config D's split of a Qwen2-Audio batch: every cp rank runs the audio tower on the clips that touch its part of
+    the sequence (clips cut by a chunk boundary on both sides), scatters its rows into its part of the embeddings and
+    runs lm_head + CE on its own labelled rows; the loss parts add up to the single-process loss and the FSDP-averaged
+    gradients x cp — of the decoder AND of the tower / projector — equal the single-process gradients."""
+    ref_state, ref_grads, ref_loss, batch = _qa_reference(T)
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_qa_worker, args=(world, _free_port(), ref_state, ref_grads, ref_loss, batch, ret), nprocs=world,
+                 join=True)
+        results = dict(ret)
+    for r in range(world):
+        assert results[r][0] == "ok", results[r][1]
+    assert sum(results[r][1] for r in range(world)) > results[0][2]       # straddling clips ran on two ranks
+
+
+# ------------------------------------------------------------------------------------------------ emulated ranks
+def test_emulated_cp_rank_runs_the_real_ranks_shapes_without_a_process_group():
+    """`bench.py --cp N --emulate-rank r`: one process, no process group; the batch is split exactly like on the real
+    rank r, the K/V buffers have the global length, and the step goes through (values of remote chunks are stand-ins)."""
+    import oracle.ops as oops
+    import touchnet_amd.specs  # noqa: F401
+    from touchnet_amd.bin.train import TrainConfig, Trainer
+    from touchnet_amd.models.backend import use_ops
+    from touchnet_amd.models.qwen2_audio import Qwen2AudioConfig
+    from touchnet_amd.utils.context_parallel import ContextParallel
+    assert not dist.is_initialized()
+    T, cp = 1024, 4
+    batch, n_all = _qa_batch(T)
+    job = TrainConfig(training_model_name="qwen2_audio_mi355", training_enable_fused_ce=True,
+                      training_mixed_precision_param="float32")
+    for r in (0, 3):
+        with use_ops(oops):
+            tr = Trainer(job, Qwen2AudioConfig.from_dict(QA_TINY), torch.device("cpu"), cp_emulate=(cp, r),
+                         optimizer_factory=lambda ps: TorchAdamW(ps))
+            data = tr.next_batch(batch)
+            view = ContextParallel(None, T, emulate=(cp, r))
+            assert torch.equal(data["input_ids"], view.shard(batch["input_ids"], 1))
+            clips, pos, rows = view.shard_audio(batch["audio_positions"].numpy(), batch["audio_output_lengths"].numpy(), TA)
+            assert torch.equal(data["audio_positions"], torch.from_numpy(pos))
+            assert torch.equal(data["input_features"], batch["input_features"][torch.from_numpy(clips)])
+            stats = tr.train_step(data)
+        assert torch.isfinite(stats["loss_per_sample"]) and torch.isfinite(stats["grad_norm"]).all()
+        assert all(p.grad is not None for p in tr.model.audio_tower.parameters() if p.requires_grad)
+    assert not dist.is_initialized()
+
+
+def test_emulated_tp_rank_holds_the_real_ranks_shards():
+    import oracle.ops as oops
+    from touchnet_amd.models.backend import use_ops
+    from touchnet_amd.models.tensor_parallel import EmulatedTPMesh, apply_tp, tp_param_ids
+    full = _tp_model()
+    ref = {n: p.detach().clone() for n, p in full.named_parameters()}
+    for r in range(2):
+        m = apply_tp(_tp_model(), EmulatedTPMesh(2, r))
+        group, ids = tp_param_ids([m])
+        assert getattr(group, "emulated", False) and len(ids) == 4 * 10
+        for n, p in m.named_parameters():
+            if n in m._tn_tp["sharded_names"]:
+                dim = 1 if ("o_proj" in n or "down_proj" in n) else 0
+                assert torch.equal(p, ref[n].chunk(2, dim=dim)[r]), n
+            else:
+                assert torch.equal(p, ref[n]), n
+        inputs, labels, sl = _tp_batch()
+        with use_ops(oops):
+            out = m(**inputs, labels=labels, sentence_lens=sl, num_sentence=4)
+            out.loss.backward()
+        assert torch.isfinite(out.loss)
+
+
+def test_tp_shards_are_not_initialised_identically():
+    """`post_init` on tp-local shards with one seed would give every tp rank the same numbers."""
+    from touchnet_amd.models.kimi_audio import KimiAudioConfig, KimiAudioPackedForCausalLM
+    from touchnet_amd.models.tensor_parallel import EmulatedTPMesh, apply_tp, reinit_tp_shards
+    shards = []
+    for r in range(2):
+        torch.manual_seed(5)
+        m = apply_tp(KimiAudioPackedForCausalLM(KimiAudioConfig(**KIMI_TINY)), EmulatedTPMesh(2, r))
+        m.post_init()
+        reinit_tp_shards(m, seed=5, std=0.02)
+        shards.append({n: p.detach().clone() for n, p in m.named_parameters()})
+    names = m._tn_tp["sharded_names"]
+    for n in shards[0]:
+        same = torch.equal(shards[0][n], shards[1][n])
+        if n in names and not n.endswith("bias"):
+            assert not same, n
+            assert 0.01 < float(shards[0][n].std()) < 0.03
+        else:
+            assert same, n                                             # replicated parameters (and zero biases) agree
+
+
+def test_row_parallel_bias_is_refused():
+    from touchnet_amd.models.kimi_audio import KimiAudioConfig, KimiAudioPackedForCausalLM
+    from touchnet_amd.models.tensor_parallel import EmulatedTPMesh, apply_tp
+    m = KimiAudioPackedForCausalLM(KimiAudioConfig(**KIMI_TINY))
+    m.model.layers[0].self_attn.o_proj.bias = torch.nn.Parameter(torch.zeros(64))
+    with pytest.raises(NotImplementedError):
+        apply_tp(m, EmulatedTPMesh(2, 0))
+
+
+# ------------------------------------------------------------------------------------------------ config E on 4 ranks
+def _tp_fsdp_batches(dp):
+    out = []
+    for r in range(dp):
+        inputs, labels, sl = _tp_batch()
+        g = torch.Generator().manual_seed(40 + r)
+        inputs["text_input_ids"] = torch.randint(0, 64, inputs["text_input_ids"].shape, generator=g)
+        out.append(dict(inputs, labels=labels, sentence_lens=sl, num_sentence=4))
+    return out
+
+
+def _tp_fsdp_worker(rank, world, port, ref_state, ref_grads, ref_losses, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import oracle.ops as oops
+    import touchnet_amd.specs  # noqa: F401
+    from touchnet_amd.bin.train import TrainConfig, Trainer
+    from touchnet_amd.models.backend import use_ops
+    from touchnet_amd.models.kimi_audio import KimiAudioConfig
+    from touchnet_amd.utils.distributed import ParallelDims, init_distributed
+    try:
+        init_distributed("cpu")
+        tp, dp = 2, world // 2
+        mesh = ParallelDims(dp_replicate=1, dp_shard=dp, cp=1, tp=tp, pp=1, world_size=world).build_mesh("cpu")
+        assert mesh.mesh_dim_names == ("dp_shard", "tp")
+        dp_rank, tp_rank = mesh["dp_shard"].get_local_rank(), mesh["tp"].get_local_rank()
+        assert (dp_rank, tp_rank) == divmod(rank, tp)                   # tp innermost: neighbours share xGMI links
+        job = TrainConfig(training_model_name="kimi_audio_mi355", training_enable_fused_ce=True,
+                          training_mixed_precision_param="float32")
+        with use_ops(oops):
+            tr = Trainer(job, KimiAudioConfig(**KIMI_TINY), torch.device("cpu"), dp_mesh=mesh["dp"],
+                         fsdp_mesh=mesh["dp_shard_cp"], tp_mesh=mesh["tp"], optimizer_factory=lambda ps: TorchAdamW(ps))
+            sharded = tr.model._tn_tp["sharded_names"]
+            assert len(sharded) == 4 * 10
+
+            def tp_part(name, full):
+                if name in sharded:
+                    return full.chunk(tp, dim=1 if ("o_proj" in name or "down_proj" in name) else 0)[tp_rank]
+                return full
+            with torch.no_grad():
+                for name, p in tr.model.named_parameters():
+                    full = tp_part(name, ref_state[name])
+                    local = p._local_tensor
+                    assert tuple(p.shape) == tuple(full.shape), (name, p.shape, full.shape)     # DTensor of the tp-local weight
+                    local.copy_(full.chunk(dp, dim=0)[dp_rank])
+            data = tr.next_batch(_tp_fsdp_batches(dp)[dp_rank])
+            assert float(data["num_sentence"]) == 4.0 * dp                # summed over dp only, not over tp
+            tr.optimizer.zero_grad()
+            loss, _, _ = tr.forward_loss(data)
+            assert float(loss) == pytest.approx(ref_losses[dp_rank], rel=1e-5, abs=1e-6)
+            loss.backward()
+            worst = 0.0
+            for name, p in tr.model.named_parameters():
+                if p.grad is None:
+                    assert "mimo" in name, name
+                    continue
+                g = p.grad.full_tensor()
+                worst = max(worst, float((g - tp_part(name, ref_grads[name])).abs().max()))
+            assert worst < 3e-5, worst
+            stats = tr.train_step(data)
+            assert torch.isfinite(stats["grad_norm"]).all()
+        ret[rank] = ("ok", worst)
+    except Exception as e:
+        import traceback
+        ret[rank] = ("fail", traceback.format_exc(), repr(e))
+    finally:
+        if dist.is_initialized():
+            dist.barrier()
+            dist.destroy_process_group()
+
+
+def test_tensor_parallel_times_fsdp2_on_a_2d_mesh_of_four_ranks():
+    """Config E's layout (TP x FSDP2, here 2 x 2 over gloo) through the Trainer and the reference's ParallelDims mesh:
+    tp-local weights are FSDP2-sharded over the dp ranks, the loss of each dp rank equals the single-process one and the
+    dp-averaged gradients equal the tp slices of the single-process gradients."""
+    import oracle.ops as oops
+    from touchnet_amd.models.backend import use_ops
+    ref = _tp_model()
+    dp = 2
+    losses = []
+    with use_ops(oops):
+        for b in _tp_fsdp_batches(dp):
+            b = dict(b, num_sentence=4 * dp)
+            losses.append(ref(**b).loss)
+        (sum(losses) / dp).backward()
+    ref_state = {k: v.detach().clone() for k, v in ref.state_dict().items()}
+    ref_grads = {n: p.grad.clone() for n, p in ref.named_parameters() if p.grad is not None}
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_tp_fsdp_worker, args=(4, _free_port(), ref_state, ref_grads, [float(l) for l in losses], ret),
+                 nprocs=4, join=True)
+        results = dict(ret)
+    for r in range(4):
+        assert results[r][0] == "ok", results[r][1]

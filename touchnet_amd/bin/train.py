@@ -76,16 +76,23 @@ class _ForceShard:
 
 class Trainer:
     def __init__(self, job: TrainConfig, model_config, device: torch.device, dp_mesh=None,
-                 spec: Optional[TrainSpec] = None, optimizer_factory=None, cp_mesh=None, fsdp_mesh=None):
+                 spec: Optional[TrainSpec] = None, optimizer_factory=None, cp_mesh=None, fsdp_mesh=None, tp_mesh=None,
+                 cp_emulate=None):
         """`dp_mesh`: 1-D data-parallel mesh (rows are split over it).  `cp_mesh`: 1-D context-parallel mesh (the
         sequence dim is split over it); with CP, parameters are sharded over `fsdp_mesh` = dp x cp flattened
         (the reference's `dp_shard_cp`, touchnet/utils/distributed.py:150-157) and the loss parts of the cp
-        ranks add up (train.py:485-494 reduces over `dp_cp`)."""
+        ranks add up (train.py:485-494 reduces over `dp_cp`).  `tp_mesh`: 1-D tensor-parallel mesh (or
+        models.tensor_parallel.EmulatedTPMesh): the blocks are sharded over it by the spec's `parallelize_fn`
+        (touchnet/models/llama/parallelize_llama.py:105-196's slot) before FSDP2 shards the tp-local parameters.
+        `cp_emulate = (cp, rank)`: this ONE process plays rank `rank` of a cp-way context-parallel group
+        (utils.context_parallel.ContextParallel.emulate; `bench.py --emulate-rank`)."""
         self.job, self.device, self.dp_mesh = job, device, dp_mesh
         self.spec = spec or get_train_spec(job.training_model_name)
         self.dp_group = dp_mesh.get_group() if dp_mesh is not None else None
         self.dp_world = dp_mesh.size() if dp_mesh is not None else 1
         self.cp_group = cp_mesh.get_group() if cp_mesh is not None and cp_mesh.size() > 1 else None
+        self.cp_emulate = tuple(cp_emulate) if cp_emulate is not None else None
+        self.tp_mesh = tp_mesh if tp_mesh is not None and tp_mesh.size() > 1 else None
         self.cp = None
         if fsdp_mesh is None:
             fsdp_mesh = dp_mesh
@@ -101,20 +108,24 @@ class Trainer:
         self.model_config = model_config
         self.num_params = self.spec.get_num_params_fn(model)
         self.num_params_wo_emb = self.spec.get_num_params_fn(model, exclude_embedding=True)
-        if self.cp_group is not None and not sharded:
+        if self.cp_group is not None and not sharded and self.cp_emulate is None:
             # gradients are only reduced across cp ranks by the FSDP reduce-scatter over dp x cp: without it the
             # replicas would silently diverge (the reference always shards over `dp_shard_cp` when cp > 1)
             raise ValueError("context parallelism needs parameter sharding over a mesh that includes the cp ranks: "
                              "pass fsdp_mesh = the flattened dp x cp mesh")
         ac = job.training_activation_checkpoint_mode != "none"
-        if sharded or ac:
+        tp = self.tp_mesh.size() if self.tp_mesh is not None else 1
+        if sharded or ac or tp > 1:
             # the hook is called the way the reference trainer calls it (train.py:259-261): meta model, the mesh
             # indexed by the reference's dimension names, ParallelDims, job config
             n = fsdp_mesh.size() if sharded else 1
-            dims = ParallelDims(dp_replicate=1, dp_shard=n, cp=1, tp=1, pp=1, world_size=n)
+            dims = ParallelDims(dp_replicate=1, dp_shard=n, cp=1, tp=tp, pp=1, world_size=n * tp)
             if sharded and n == 1:                                 # TN_FORCE_FSDP on one rank: still take the FSDP branch
                 dims = _ForceShard(dims)
-            model = self.spec.parallelize_fn(model, _MeshView({"dp_shard_cp": fsdp_mesh}), dims, job)
+            view = {"dp_shard_cp": fsdp_mesh}
+            if tp > 1:
+                view["tp"] = self.tp_mesh
+            model = self.spec.parallelize_fn(model, _MeshView(view), dims, job)
         if sharded:                                                # fp32 shards, bf16 compute
             model.to_empty(device=device)
             with torch.no_grad():
@@ -129,13 +140,20 @@ class Trainer:
                     self.spec.additional_post_init_fn(model, device)
             if device.type == "cuda":
                 model.to(getattr(torch, job.training_mixed_precision_param))
+        if tp > 1:                                  # shards of one weight must not be drawn identically on the tp ranks
+            from touchnet_amd.models.tensor_parallel import reinit_tp_shards
+            seq_cfg = getattr(model_config, "text_config", model_config)
+            reinit_tp_shards(model, job.training_seed, getattr(seq_cfg, "initializer_range", 0.02))
         self.model = model
         if optimizer_factory is not None:          # (CPU tests drive the host logic with a torch optimizer)
             self.optimizer = optimizer_factory(model.parameters())
         else:
+            from touchnet_amd.models.tensor_parallel import tp_param_ids
+            tp_group, tp_ids = tp_param_ids([model])
             self.optimizer = FusedAdamW(model.named_parameters(), lr=job.lr_scheduler_lr,
                                         weight_decay=job.optimizer_weight_decay, max_norm=job.training_max_norm,
-                                        process_group=fsdp_mesh.get_group() if sharded else None)
+                                        process_group=fsdp_mesh.get_group() if sharded else None,
+                                        tp_group=tp_group, tp_param_ids=tp_ids)
         self.step = 0
 
     # ------------------------------------------------------------------ data
@@ -147,11 +165,11 @@ class Trainer:
         ns = ns.to(self.device, torch.float32) if isinstance(ns, torch.Tensor) else torch.tensor(
             float(ns), dtype=torch.float32, device=self.device)
         out["num_sentence"] = dist_sum(ns.reshape(1), self.dp_group)   # global over dp (train.py:339-343)
-        if self.cp_group is not None:                                   # train.py:354-389: shard buffers on dim 1
+        if self.cp_group is not None or self.cp_emulate is not None:    # train.py:354-389: shard buffers on dim 1
             from touchnet_amd.utils.context_parallel import ContextParallel
             T = out["labels"].shape[1]
             if self.cp is None or self.cp.T != T:
-                self.cp = ContextParallel(self.cp_group, T)
+                self.cp = ContextParallel(self.cp_group, T, emulate=self.cp_emulate)
             if not isinstance(out.get("attention_mask"), torch.Tensor):
                 # plain causal rows (the Qwen2-Audio path without packing): one document per row, GLOBAL length
                 out["attention_mask"] = torch.ones(out["labels"].shape[0], T, dtype=torch.int64, device=self.device)
@@ -160,11 +178,37 @@ class Trainer:
                 self.cp.set_documents(src if isinstance(src, torch.Tensor) else out["attention_mask"])
             else:
                 self.cp.need = None
+            presharded = out.pop("audio_cp_sharded", False)
+            if isinstance(out.get("audio_positions"), torch.Tensor) and not presharded:
+                # Qwen2-Audio: every rank runs the tower on the clips that touch ITS part of the sequence
+                self._shard_audio(batch, out)
+            if "labelled_rows_max" in out:
+                # the packer's bound counts the whole rows; lm_head + CE run on this rank's part of them
+                lab = batch.get("labels")
+                if "labelled_rows_max_cp" in out:                       # (the loader counted per cp rank already)
+                    out["labelled_rows_max"] = int(out.pop("labelled_rows_max_cp")[self.cp.rank])
+                elif isinstance(lab, torch.Tensor) and not lab.is_cuda:
+                    out["labelled_rows_max"] = int((self.cp.shard(lab, dim=1) != -100).sum())
+                else:
+                    out.pop("labelled_rows_max")
             for k in ("input_ids", "labels", "position_ids", "sentence_lens", "input_features", "inputs_embeds"):
-                if isinstance(out.get(k), torch.Tensor):
+                if isinstance(out.get(k), torch.Tensor) and not (k == "input_features" and "audio_rows" in out):
                     out[k] = self.cp.shard(out[k], dim=1)
             out["context_parallel"] = self.cp                           # attention_mask (doc ids) stays global
         return out
+
+    def _shard_audio(self, batch: dict, out: dict) -> None:
+        """host copies of the (small) index tensors decide the split; a loader that hands over device tensors only pays a
+        read-back here — bench.py's long-audio workload shards once, ahead of the timed region (`audio_cp_sharded`)"""
+        host = lambda k: (batch[k] if isinstance(batch.get(k), torch.Tensor) and not batch[k].is_cuda else out[k].cpu()).numpy()
+        feats = out["input_features"]
+        rows_per_clip = ((feats.shape[-1] - 1) // 2 + 1) // 2
+        clips, pos, rows = self.cp.shard_audio(host("audio_positions"), host("audio_output_lengths"), rows_per_clip)
+        dev = lambda a: torch.from_numpy(a).to(self.device, non_blocking=True)
+        clips_d = dev(clips)
+        out["input_features"] = feats.index_select(0, clips_d)
+        out["audio_output_lengths"] = out["audio_output_lengths"].index_select(0, clips_d)
+        out["audio_positions"], out["audio_rows"] = dev(pos), dev(rows)
 
     # ------------------------------------------------------------------ step
     def forward_loss(self, data: dict):

@@ -139,3 +139,104 @@ def qwen2_audio_plan(vocab: int, audio_token: int, batchsize: int, seqlen: int, 
             "audio_positions": t(np.concatenate(audio_pos)),
             "audio_output_lengths": torch.tensor(lengths, dtype=torch.int64),
             "audio_samples": samples, "labelled_rows_max": n_lab}, n_sent
+
+
+def qwen2_audio_long_plan(vocab: int, audio_token: int, batchsize: int, seqlen: int, seed: int = 2025,
+                          clips_per_doc=(40, 20, 10, 4, 1), tokens_per_clip: int = 750, prompt_pre: int = 8,
+                          prompt_post: int = 6, resp_per_clip=(40, 60)):
+    """Config D ("one 20-min recording per row ... 30 000 audio tokens x 2 docs + text to fill
+    T=65536"): a long recording reaches Qwen2-Audio as consecutive 30 s windows (the tower's `max_source_positions`
+    1500 frames -> 750 AUDIO tokens each), so a document = prompt + K x 750 AUDIO tokens + a transcript of
+    K x U{resp_per_clip} tokens + eos.  Rows are filled greedily with the largest K of `clips_per_doc` that still fits
+    (40 clips = 20 min first).  Label / sentence_lens / position conventions are `qwen2_audio_plan`'s.
+    Returns the batch tensors (+ `labelled_rows_max`) and the number of 30 s clips (waveforms are the caller's)."""
+    rng = np.random.RandomState(seed)
+    B, T = batchsize, seqlen
+    top = vocab - 2000 if vocab > 4000 else vocab                       # (plain text ids; tiny test vocabularies: all of it)
+    input_ids = np.zeros((B, T), dtype=np.int64)
+    labels = np.full((B, T), -100, dtype=np.int64)
+    position_ids = np.zeros((B, T), dtype=np.int64)
+    doc = np.zeros((B, T), dtype=np.int64)
+    sentence_lens = np.ones((B, T), dtype=np.int64)
+    audio_pos, lengths, n_sent, n_lab = [], [], 0, 0
+    for b in range(B):
+        col, d = 0, 1
+        while True:
+            pick = None
+            for K in clips_per_doc:
+                nresp = int(sum(rng.randint(resp_per_clip[0], resp_per_clip[1] + 1) for _ in range(K)))
+                plen = prompt_pre + K * tokens_per_clip + prompt_post
+                if col + plen + nresp <= T:
+                    pick = (K, nresp, plen)
+                    break
+            if pick is None:
+                break
+            K, nresp, plen = pick
+            tot = plen + nresp
+            ids = np.concatenate([rng.randint(3, top, size=prompt_pre),
+                                  np.full(K * tokens_per_clip, audio_token),
+                                  rng.randint(3, top, size=prompt_post),
+                                  rng.randint(3, top, size=nresp)])
+            input_ids[b, col:col + tot] = ids
+            labels[b, col + plen - 1:col + tot - 1] = ids[plen:]
+            labels[b, col + tot - 1] = 2
+            position_ids[b, col:col + tot] = np.arange(tot)
+            doc[b, col:col + tot] = d
+            sentence_lens[b, col:col + tot] = nresp + 1
+            audio_pos.append(b * T + col + prompt_pre + np.arange(K * tokens_per_clip))
+            lengths += [tokens_per_clip] * K
+            col += tot
+            d += 1
+            n_sent += 1
+            n_lab += nresp + 1
+    t = torch.from_numpy
+    return {"input_ids": t(input_ids), "labels": t(labels), "position_ids": t(position_ids),
+            "attention_mask": t(doc), "sentence_lens": t(sentence_lens), "num_sentence": n_sent,
+            "audio_positions": t(np.concatenate(audio_pos)),
+            "audio_output_lengths": torch.tensor(lengths, dtype=torch.int64),
+            "labelled_rows_max": n_lab}, len(lengths)
+
+
+def kimi_audio_plan(vocab_text: int, audio_code_base: int, n_codes: int, batchsize: int, seqlen: int, seed: int = 2025,
+                    blank_id: int = 0, audio_s=(2.0, 14.5), codes_per_s: float = 12.5, text_tokens=(5, 40)):
+    """Config E ("text / audio id streams of equal length (processing_kimi_audio.py:112-116),
+    V=168448 logits, text head only"): interleaved audio/text documents — a span of discrete audio codes (12.5 Hz GLM-4
+    voice tokens of a U[audio_s] s utterance) on the AUDIO stream with blanks on the TEXT stream, then its transcript on
+    the text stream with blanks on the audio stream; the text head is trained on the transcript (labels pre-shifted,
+    per-sentence normalisation like the other recipes).  Documents are packed greedily into [B, T]."""
+    rng = np.random.RandomState(seed)
+    B, T = batchsize, seqlen
+    text = np.full((B, T), blank_id, dtype=np.int64)
+    audio = np.full((B, T), blank_id, dtype=np.int64)
+    labels = np.full((B, T), -100, dtype=np.int64)
+    position_ids = np.zeros((B, T), dtype=np.int64)
+    doc = np.zeros((B, T), dtype=np.int64)
+    sentence_lens = np.ones((B, T), dtype=np.int64)
+    n_sent = n_lab = 0
+    for b in range(B):
+        col, d = 0, 1
+        while True:
+            na = int(rng.uniform(*audio_s) * codes_per_s)
+            nt = int(rng.randint(text_tokens[0], text_tokens[1] + 1))
+            tot = 2 + na + nt                                            # <media_begin> codes <media_end> transcript
+            if col + tot > T:
+                break
+            a0 = col + 1
+            audio[b, a0:a0 + na] = audio_code_base + rng.randint(0, n_codes, size=na)
+            text[b, col], text[b, a0 + na] = 3, 4
+            ids = rng.randint(5, vocab_text - 2000, size=nt)
+            t0 = a0 + na + 1
+            text[b, t0:t0 + nt] = ids
+            labels[b, t0 - 1:t0 + nt - 1] = ids
+            labels[b, t0 + nt - 1] = 2
+            position_ids[b, col:col + tot] = np.arange(tot)
+            doc[b, col:col + tot] = d
+            sentence_lens[b, col:col + tot] = nt + 1
+            col += tot
+            d += 1
+            n_sent += 1
+            n_lab += nt + 1
+    t = torch.from_numpy
+    return {"text_input_ids": t(text), "audio_input_ids": t(audio), "labels": t(labels),
+            "position_ids": t(position_ids), "attention_mask": t(doc), "sentence_lens": t(sentence_lens),
+            "num_sentence": n_sent, "labelled_rows_max": n_lab}

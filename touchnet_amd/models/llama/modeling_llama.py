@@ -273,9 +273,10 @@ class PackedCausalLM(nn.Module):
                                                sentence_lens, num_sentence, ce_chunk_tokens, int(labelled_rows_max))
         h = self.model(input_ids=input_ids, inputs_embeds=inputs_embeds, position_ids=position_ids,
                        attention_mask=attention_mask, context_parallel=context_parallel)
-        if labelled_rows_max is not None and ce_compact is not True and context_parallel is None:
+        if labelled_rows_max is not None and ce_compact is not True:
             # the packers know how many positions carry a label: lm_head + CE run on those rows only, without a host
-            # sync (functional._FusedLinearCE); rounded up so that the GEMM shapes repeat from step to step
+            # sync (functional._FusedLinearCE); rounded up so that the GEMM shapes repeat from step to step.  (Under
+            # context parallelism the bound is the one of THIS rank's part of the labels — bin/train.py recounts it.)
             ce_compact = (int(labelled_rows_max) + 255) // 256 * 256
         if labels is None and shift_labels is not None:
             # The reference's liger branch (train.py:434-445 with training_enable_liger_kernel): the trainer pops

@@ -222,11 +222,14 @@ class Qwen2AudioPackedForConditionalGeneration(nn.Module):
                 m.reset_parameters()
 
     def forward(self, input_ids=None, input_features=None, audio_output_lengths=None, audio_positions=None,
-                attention_mask=None, position_ids=None, **loss_kwargs):
+                attention_mask=None, position_ids=None, audio_rows=None, **loss_kwargs):
         """input_ids [B, T] packed, AUDIO placeholder tokens where audio features go;
         input_features [n_audio, n_mels, Tm]; audio_output_lengths int64 [n_audio] (valid tokens per audio,
         `((L-1)//2+1-2)//2+1`, processing_qwen2_audio.py:79-82); audio_positions int64 [sum(lengths)] flat
-        indices into B*T (computed from input_ids when omitted — that costs a host sync)."""
+        indices into B*T (computed from input_ids when omitted — that costs a host sync).
+        `audio_rows` int64 [n_positions] (context parallelism, utils.context_parallel.ContextParallel.shard_audio):
+        `input_ids` is this rank's part of the sequence, `input_features` the clips that touch it, and row
+        `audio_rows[j]` of the tower's [n * Ta] output rows goes to position `audio_positions[j]`."""
         emb = self.language_model.model.embed_tokens(input_ids)
         B, T, H = emb.shape
         if input_features is not None:
@@ -234,7 +237,7 @@ class Qwen2AudioPackedForConditionalGeneration(nn.Module):
                 audio_positions = (input_ids.reshape(-1) == self.config.audio_token_index).nonzero().squeeze(1)
             n = input_features.shape[0]
             Ta = ((input_features.shape[-1] - 1) // 2 + 1) // 2
-            packed_tower = (TOWER_VALID_FRAMES_ONLY and audio_output_lengths is not None
+            packed_tower = (TOWER_VALID_FRAMES_ONLY and audio_output_lengths is not None and audio_rows is None
                             and 0 < audio_positions.numel() < n * Ta)
             if packed_tower:                                 # clips shorter than their padding: skip the padded frames
                 feats = self.multi_modal_projector(self.audio_tower.forward_valid(
@@ -242,7 +245,9 @@ class Qwen2AudioPackedForConditionalGeneration(nn.Module):
             else:
                 feats = self.multi_modal_projector(self.audio_tower(input_features))    # [n, Ta, H]
                 feats = feats.reshape(n * Ta, H)
-            if audio_output_lengths is not None and not packed_tower:
+            if audio_rows is not None:
+                feats = feats.index_select(0, audio_rows)
+            elif audio_output_lengths is not None and not packed_tower:
                 # rows [0, len_i) of clip i, in clip order (`:202-205`'s boolean compaction) WITHOUT a data-dependent
                 # shape: the number of valid rows is the number of AUDIO positions, known from the tensor's size
                 total = audio_positions.numel()

@@ -26,6 +26,30 @@ import torch.nn as nn
 from touchnet_amd.models.helper_func import block_groups
 
 
+class EmulatedTPMesh:
+    """`bench.py --tp N --emulate-rank r`: ONE process plays rank r of an N-way tensor-parallel group — it holds rank r's
+    shards and runs rank r's kernels; the all-reduces (a device-to-device sum of equally shaped tensors) are skipped."""
+    emulated = True
+
+    def __init__(self, size: int, rank: int):
+        self._size, self._rank = int(size), int(rank)
+
+    def get_group(self):
+        return self
+
+    def size(self):
+        return self._size
+
+    def get_local_rank(self):
+        return self._rank
+
+
+def tp_all_reduce(t: torch.Tensor, group) -> None:
+    if getattr(group, "emulated", False):
+        return
+    dist.all_reduce(t, group=group)
+
+
 class _CopyToTP(torch.autograd.Function):
     """identity forward, all-reduce of the gradient backward (input of a column-parallel region)"""
 
@@ -37,7 +61,7 @@ class _CopyToTP(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         g = g.contiguous()
-        dist.all_reduce(g, group=ctx.group)
+        tp_all_reduce(g, ctx.group)
         return g, None
 
 
@@ -47,7 +71,7 @@ class _ReduceFromTP(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, group):
         x = x.contiguous()
-        dist.all_reduce(x, group=group)
+        tp_all_reduce(x, group)
         return x
 
     @staticmethod
@@ -86,6 +110,9 @@ def apply_tp(model: nn.Module, tp_mesh, loss_parallel: bool = False) -> nn.Modul
                 raise ValueError(f"{attn.num_heads} query / {attn.num_kv_heads} kv heads cannot be split {tp} ways")
             for lin, dim in ((attn.q_proj, 0), (attn.k_proj, 0), (attn.v_proj, 0), (attn.o_proj, 1),
                              (mlp.gate_proj, 0), (mlp.up_proj, 0), (mlp.down_proj, 1)):
+                if lin.bias is not None and dim == 1:
+                    # a row-parallel layer's bias would be added on every rank in front of the all-reduce (= tp times)
+                    raise NotImplementedError("bias on a row-parallel layer (o_proj / down_proj) is not part of this TP plan")
                 lin.weight = _shard(lin.weight, dim, rank, tp)
                 sharded.append(lin.weight)
                 if lin.bias is not None and dim == 0:
@@ -96,9 +123,29 @@ def apply_tp(model: nn.Module, tp_mesh, loss_parallel: bool = False) -> nn.Modul
             _wrap(attn, group)
             _wrap(mlp, group)
     ids = {id(p) for p in sharded}
-    model._tn_tp = {"group": group, "size": tp,
+    model._tn_tp = {"group": group, "size": tp, "rank": rank,
                     "sharded_names": {n for n, p in model.named_parameters() if id(p) in ids}}
     return model
+
+
+@torch.no_grad()
+def reinit_tp_shards(model: nn.Module, seed: int, std: float) -> None:
+    """`post_init` draws every parameter from the process RNG, which is seeded identically on all ranks: right for the
+    replicated parameters, but the tp ranks' SHARDS of one weight would come out identical (duplicated heads / MLP
+    columns).  Redraw the sharded ones from a generator keyed by (seed, parameter name, tp rank)."""
+    info = getattr(model, "_tn_tp", None)
+    if not info or info["size"] <= 1:
+        return
+    import zlib
+    for name, p in model.named_parameters():
+        if name in info["sharded_names"] and not p.is_meta:
+            local = p._local_tensor if hasattr(p, "_local_tensor") else p
+            g = torch.Generator(device=local.device)
+            g.manual_seed((int(seed) * 1000003 + zlib.crc32(name.encode()) * 31 + info["rank"]) % (2 ** 63 - 1))
+            if name.endswith("bias"):
+                local.zero_()
+            else:
+                local.normal_(mean=0.0, std=std, generator=g)
 
 
 def tp_param_ids(model_parts):

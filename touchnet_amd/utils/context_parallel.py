@@ -111,10 +111,17 @@ def halo_need_ranges(doc_ids: torch.Tensor, cp: int) -> torch.Tensor:
 class ContextParallel:
     group: object
     T: int                     # global packed length
+    emulate: tuple = None      # (cp, rank): ONE process plays rank `rank` of a cp-way group and moves nothing — the chunks a
+                               # real run would receive are filled with copies of the rank's own first chunk (same bytes
+                               # written, same kernels, same tile work: the document ids decide what the kernels do, not the
+                               # values), the gradients a real run would send back are dropped.  `bench.py --emulate-rank`.
 
     def __post_init__(self):
-        self.cp = dist.get_world_size(self.group)
-        self.rank = dist.get_rank(self.group)
+        if self.emulate is not None:
+            self.cp, self.rank = int(self.emulate[0]), int(self.emulate[1])
+        else:
+            self.cp = dist.get_world_size(self.group)
+            self.rank = dist.get_rank(self.group)
         if self.T % (2 * self.cp * 128):
             raise ValueError(f"T={self.T} must be a multiple of 2*cp*128 = {2 * self.cp * 128}")
         self.Tc = self.T // (2 * self.cp)
@@ -166,6 +173,38 @@ class ContextParallel:
         a = x.narrow(dim, self.rank * self.Tc, self.Tc)
         b = x.narrow(dim, (2 * self.cp - 1 - self.rank) * self.Tc, self.Tc)
         return torch.cat([a, b], dim=dim).contiguous()
+
+    def shard_audio(self, audio_positions, audio_output_lengths, rows_per_clip: int):
+        """Qwen2-Audio under context parallelism (host side, numpy): which clips this rank's audio tower runs and where
+        their rows go.  `audio_positions` int64 [sum(lengths)] are flat indices into the GLOBAL [B, T] token grid (clip
+        after clip, `lengths[i]` consecutive entries each), `rows_per_clip` = rows the tower returns per clip (Ta).
+        A clip belongs to every rank that owns at least one of its token positions (a clip straddling a chunk boundary
+        runs on both sides: the tower is per clip, each side keeps its own rows and backpropagates only through them, so
+        the parameter gradients still add up to the unsharded ones over the dp x cp reduce-scatter).
+        Returns (clips, positions_local, rows): `clips` int64 [n_local] indices into the clip dim of `input_features`,
+        `positions_local` flat indices into this rank's [B, 2*Tc] grid, `rows` int64 indices into the tower's
+        [n_local * rows_per_clip] output rows, one per local position.  A rank without audio still gets clip 0 with
+        zero rows kept, so that every rank runs the tower (FSDP2's collectives stay symmetric)."""
+        import numpy as np
+        pos = np.asarray(audio_positions, dtype=np.int64).reshape(-1)
+        lens = np.asarray(audio_output_lengths, dtype=np.int64).reshape(-1)
+        if int(lens.sum()) != pos.size:
+            raise ValueError(f"audio positions ({pos.size}) and lengths (sum {int(lens.sum())}) disagree")
+        b, col = pos // self.T, pos % self.T
+        chunk = col // self.Tc
+        lo, hi = self.my_chunks()
+        mine = (chunk == lo) | (chunk == hi)
+        local_col = np.where(chunk == lo, col - lo * self.Tc, col - hi * self.Tc + self.Tc)
+        clip_of = np.repeat(np.arange(lens.size), lens)
+        row_in_clip = np.arange(pos.size) - np.repeat(np.cumsum(lens) - lens, lens)
+        clips = np.unique(clip_of[mine])
+        if clips.size == 0:
+            clips = np.zeros(1, dtype=np.int64)
+        slot = np.full(lens.size, -1, dtype=np.int64)
+        slot[clips] = np.arange(clips.size)
+        positions_local = (b * 2 * self.Tc + local_col)[mine]
+        rows = (slot[clip_of] * rows_per_clip + row_in_clip)[mine]
+        return clips.astype(np.int64), positions_local.astype(np.int64), rows.astype(np.int64)
 
     def seq_shard(self):
         from touchnet_amd.functional import SeqShard
@@ -245,6 +284,12 @@ def _start_forward(cp: "ContextParallel", locals_):
     for x, full in zip(locals_, fulls):
         for h, c in enumerate(mine):
             full.narrow(1, c * Tc, Tc).copy_(x.narrow(1, h * Tc, Tc))
+        if cp.emulate is not None:                                # stand-ins for the chunks a real run would receive
+            for c in range(2 * cp.cp):
+                if need[me, c] and c not in mine:
+                    full.narrow(1, c * Tc, Tc).copy_(x.narrow(1, 0, Tc))
+                    cp.halo_bytes += x.narrow(1, 0, Tc).numel() * x.element_size()
+            continue
         for p in range(cp.cp):
             if p == me:
                 continue
@@ -275,6 +320,8 @@ def _start_backward(cp: "ContextParallel", g_fulls):
     g_locals = [torch.cat([g.narrow(1, c * Tc, Tc) for c in mine], dim=1).contiguous() for g in g_fulls]
     ops, after = [], []
     for g, gl in zip(g_fulls, g_locals):
+        if cp.emulate is not None:                                # (the partial sums of the stand-in chunks go nowhere)
+            continue
         for p in range(cp.cp):
             if p == me:
                 continue

@@ -130,7 +130,8 @@ class FusedAdamW:
                                    for dt, items in by_dtype.items()}
             drop_empty = lambda d: {dt: v for dt, v in d.items() if v}
             keep = self._sumsq(drop_empty(pick(True)))
-            torch.distributed.all_reduce(self.norm_sq, group=self.tp_group)
+            from touchnet_amd.models.tensor_parallel import tp_all_reduce
+            tp_all_reduce(self.norm_sq, self.tp_group)
             keep += self._sumsq(drop_empty(pick(False)))
         else:
             keep = self._sumsq(by_dtype)
