@@ -531,8 +531,7 @@ def main():
     if wl.name == "kimi_audio_7b":
         # the recipe trains the TEXT head: the mimo branch (6 layers + the audio head) is not executed, and the reference
         # formula (kimi_audio/__init__.py:63-80: L + L_mimo layers, all parameters) must not be credited with it
-        fpt = trainer.spec.get_num_flop_per_token_fn(trainer.num_params_wo_emb, wl.model_config, wl.T, with_mimo=False,
-                                                     model=trainer.model, tp=layout["tp"])
+        fpt = trainer.spec.get_num_flop_per_token_fn(trainer.num_params_wo_emb, wl.model_config, wl.T, with_mimo=False)
     else:
         fpt = trainer.spec.get_num_flop_per_token_fn(trainer.num_params_wo_emb, wl.model_config, wl.T)
     mfu = fpt * (tps / gpus_in_job) / MFMA_PEAK
@@ -584,8 +583,8 @@ def main():
         if wl.name == "kimi_audio_7b":
             line["mfu_convention"] = ("6*N + 12*L*H*Dh*T per token over the EXECUTED graph only: 28 decoder layers + text "
                                       "head (the reference formula, kimi_audio/__init__.py:63-80, also counts the 6 mimo "
-                                      "layers and the audio head, which a text-head step never runs); per GPU: block "
-                                      "parameters / tp, heads replicated")
+                                      "layers and the audio head, which a text-head step never runs), times this GPU's "
+                                      "share of the tokens")
         if (args.cp > 1 or args.tp > 1):
             line["kernels_note"] = "per-kernel rooflines are reported on the headline workload (python bench.py)"
             rows_local = wl.B * wl.T // layout["cp"]

@@ -38,3 +38,37 @@ def load_file_as(name, relpath):
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     return mod
+
+
+def load_kimi_modeling():
+    """touchnet/models/kimi_audio/modeling_kimi_audio.py under the INSTALLED transformers 5.x (the reference pins 4.51.3,
+    which is not in this image).  Three names it imports from `transformers.models.qwen2.modeling_qwen2` no longer exist:
+    two docstring constants (only ever passed to docstring decorators) and a TypedDict used in a type annotation.  They
+    are put back — in this process's copy of the third-party module, nowhere on disk — as an empty string / an empty
+    TypedDict, which cannot influence any computed value.  Build container only, like everything in this file."""
+    from typing import TypedDict
+
+    import transformers.models.qwen2.modeling_qwen2 as mq
+
+    class KwargsForCausalLM(TypedDict, total=False):
+        pass
+    for name, value in (("QWEN2_INPUTS_DOCSTRING", ""), ("QWEN2_START_DOCSTRING", ""),
+                        ("KwargsForCausalLM", KwargsForCausalLM)):
+        if not hasattr(mq, name):
+            setattr(mq, name, value)
+    import importlib
+    return importlib.import_module("touchnet.models.kimi_audio.modeling_kimi_audio")
+
+
+def adapt_decoder_layers_to_4_51(layers):
+    """The second drift between 4.51.3 and 5.x that the reference's MoonshotKimiaModel.forward meets: it calls
+    `decoder_layer(..., past_key_value=...)` and reads `layer_outputs[0]`; a 5.x Qwen2DecoderLayer names the argument
+    `past_key_values` and returns the hidden-state TENSOR (so `[0]` would silently drop the batch dimension).  Each layer's
+    forward is wrapped to take the old keyword and return the old 1-tuple; the layer's arithmetic is untouched."""
+    for layer in layers:
+        inner = layer.forward
+
+        def forward(hidden_states, *args, _inner=inner, past_key_value=None, output_attentions=False, cache_position=None,
+                    **kw):
+            return (_inner(hidden_states, *args, past_key_values=past_key_value, **kw),)
+        layer.forward = forward

@@ -666,11 +666,65 @@ def qwen2_audio_data_case():
     out["texts"] = np.array(texts)
     save("qwen2_audio_data.npz", **out)
 
+# ------------------------------------------------------------------ Kimi-Audio decoder (config E) — the reference's own module
+def kimi_decoder_case():
+    """MoonshotKimiaModel (modeling_kimi_audio.py:347-556: Qwen2 stack, mimo branch cloned after layer
+    `kimia_mimo_transformer_from_layer_index`, two final norms) RUN from the reference's source with tiny widths, plus the
+    embedding sum and the two heads of MoonshotKimiaForCausalLM.forward (:1026-1068, three lines reproduced here because
+    that class also builds the Whisper encoder and the frozen VQ tokenizer, which are out of scope).  Eager attention with
+    the 4-D document-causal additive mask (`_update_causal_mask` passes a 4-D mask through untouched, :690-692).
+    Import recipe and the two API-drift adapters: _ref_import.py::load_kimi_modeling / adapt_decoder_layers_to_4_51."""
+    mk = R.load_kimi_modeling()
+    from touchnet.models.kimi_audio.configuration_kimi_audio import KimiAudioConfig
+    kw = dict(vocab_size=64, hidden_size=64, intermediate_size=128, num_hidden_layers=4, num_attention_heads=4,
+              num_key_value_heads=2, rms_norm_eps=1e-6, rope_theta=1e6, kimia_mimo_layers=2,
+              kimia_mimo_transformer_from_layer_index=1, use_whisper_feature=False, use_cache=False, pad_token_id=None,
+              initializer_range=0.1)
+    cfg = KimiAudioConfig(**kw)
+    cfg._attn_implementation = "eager"
+    # (5.x reads a per-layer attention type from the config; the mimo layers carry indices L .. L + L_mimo - 1: full
+    # attention for all of them = what 4.51.3's Qwen2Attention does without `use_sliding_window`)
+    cfg.layer_types = ["full_attention"] * (kw["num_hidden_layers"] + kw["kimia_mimo_layers"])
+    torch.manual_seed(0)
+    model = mk.MoonshotKimiaModel(cfg).float().eval()
+    R.adapt_decoder_layers_to_4_51(list(model.layers) + list(model.mimo_layers))
+    lm_head = torch.nn.Linear(64, 64, bias=False)                       # (:860-861: two bias-free heads)
+    mimo_output = torch.nn.Linear(64, 64, bias=False)
+    g = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        for n, p in model.named_parameters():                          # give the q/k/v biases non-zero values
+            if n.endswith("bias"):
+                p.normal_(std=0.05, generator=g)
+    B, T = 2, 48
+    a, t = torch.randint(0, 64, (B, T), generator=g), torch.randint(0, 64, (B, T), generator=g)
+    doc = torch.cat([torch.ones(B, 20), 2 * torch.ones(B, 20), torch.zeros(B, 8)], 1).long()
+    pos = torch.cat([torch.arange(20), torch.arange(20), torch.zeros(8, dtype=torch.long)]).repeat(B, 1)
+    emb = model.get_input_embeddings()
+    inputs_embeds = emb(a) + emb(t)                                     # :1030-1033
+    out = model(input_ids=None, inputs_embeds=inputs_embeds, attention_mask=_allow4d(doc), position_ids=pos,
+                use_cache=False, return_dict=True)
+    hidden, mimo = out.last_hidden_state                                # :549-550
+    text_logits, audio_logits = lm_head(hidden), mimo_output(mimo)      # :1060-1061
+    labels = torch.where(doc > 0, torch.randint(0, 64, (B, T), generator=g), torch.full((B, T), -100))
+    sl = torch.where(doc > 0, torch.full((B, T), 20), torch.ones(B, T, dtype=torch.long))
+    ps, pt = ref_ce(text_logits, labels, sl, 4)
+    ps.backward()
+    arrs = {f"param/model.{n}": npy(p) for n, p in model.named_parameters()}
+    arrs["param/lm_head.weight"], arrs["param/mimo_output.weight"] = npy(lm_head.weight), npy(mimo_output.weight)
+    arrs.update({f"grad/model.{n}": npy(p.grad) for n, p in model.named_parameters() if p.grad is not None})
+    arrs["grad/lm_head.weight"] = npy(lm_head.weight.grad)
+    arrs.update({"batch/audio_input_ids": npy(a), "batch/text_input_ids": npy(t), "batch/attention_mask": npy(doc),
+                 "batch/position_ids": npy(pos), "batch/labels": npy(labels), "batch/sentence_lens": npy(sl),
+                 "text_logits": npy(text_logits), "audio_logits": npy(audio_logits), "loss_per_sample": npy(ps),
+                 "loss_per_token": npy(pt)})
+    arrs["config_json"] = np.array(str({k: v for k, v in kw.items() if k not in ("use_whisper_feature", "use_cache", "pad_token_id")}))
+    save("kimi_decoder.npz", **arrs)
+
 
 if __name__ == "__main__":
     only = set(sys.argv[1:])
     for fn in (text_cases, asr_cases, ce_cases, docmask_cases, rope_cases, tiny_llama_case,
                touch_audio_case, qwen2_audio_tower_case, frontend_cases, fbank_cases, bestrq_cases, touchdataset_case,
-               boundary_case, qwen2_audio_data_case):
+               boundary_case, qwen2_audio_data_case, kimi_decoder_case):
         if not only or fn.__name__ in only:
             fn()

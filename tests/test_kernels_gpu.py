@@ -351,7 +351,11 @@ def test_frontend_log_mel(golden):
 def test_frontend_kaldi_fbank(golden):
     """Against the oracle restatement on random clips and against the third-party Kaldi-compatible fbank fixture
     (transformers.audio_utils on the reference's two test wavs, tests/golden/kaldi_fbank_hf.npz); torchaudio itself is
-    not available in this image."""
+    not available in this image — and against Kaldi's pipeline written from its specification (tests/golden/kaldi_from_spec.py)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import kaldi_from_spec as ks
     F = _f()
     g, wavs = golden("kaldi_fbank_hf.npz"), golden("logmel.npz")
     for i in (0, 1):
@@ -359,6 +363,7 @@ def test_frontend_kaldi_fbank(golden):
         y = F.kaldi_fbank(F.pcm16_to_float(pcm), 80).cpu().numpy()
         assert y.shape == g[f"wav{i}/fbank80"].shape
         np.testing.assert_allclose(y, g[f"wav{i}/fbank80"], atol=3e-3)
+        np.testing.assert_allclose(y, ks.reference_recipe_fbank(pcm.cpu().numpy(), 80), atol=3e-3)   # from-spec Kaldi (fp64)
     rng = np.random.RandomState(0)
     for n in (400, 16000, 16000 * 3 + 77):
         wav = np.clip(rng.randn(n) * 0.1, -1, 1).astype(np.float32)

@@ -355,4 +355,49 @@ def test_kimi_audio_decoder_wiring_equals_oracle_restatement():
     n_wo = get_num_params(m, exclude_embedding=True)
     assert get_num_params(m) - n_wo == 64 * 64
     assert get_num_flop_per_token(n_wo, cfg, 48) == 6 * n_wo + 12 * (4 + 2) * 4 * 16 * 48
+    # the text-head step does not run the mimo branch: its layers, norm and head are not credited
+    executed = sum(p.numel() for n, p in m.named_parameters()
+                   if not n.startswith(("model.mimo_layers.", "model.mimo_norm.", "mimo_output.", "model.embed_tokens.")))
+    assert get_num_flop_per_token(n_wo, cfg, 48, with_mimo=False) == 6 * executed + 12 * 4 * 4 * 16 * 48
     assert any("q_proj.bias" in n for n, _ in m.named_parameters())          # Qwen2DecoderLayer: biased q/k/v
+
+
+def test_kimi_audio_decoder_matches_the_reference_module(golden):
+    """tests/golden/kimi_decoder.npz was produced by RUNNING the reference's MoonshotKimiaModel
+    (modeling_kimi_audio.py:347-556) — make_golden.py::kimi_decoder_case, import recipe in _ref_import.py — on a packed
+    two-document batch with the mimo branch: the product module (on the oracle op set) and the hand restatement
+    oracle/nn.py::kimi_audio_forward both reproduce its text and audio logits, the reference CE loss and the gradients of
+    every parameter the text-head loss reaches."""
+    import ast
+
+    from oracle import nn as onn
+    from touchnet_amd.models.kimi_audio import KimiAudioConfig, KimiAudioPackedForCausalLM
+    g = golden("kimi_decoder.npz")
+    kw = ast.literal_eval(str(g["config_json"]))
+    kw["head_dim"] = kw["hidden_size"] // kw["num_attention_heads"]
+    m = KimiAudioPackedForCausalLM(KimiAudioConfig(**{k: v for k, v in kw.items() if k != "initializer_range"}))
+    sd = {k[len("param/"):]: torch.tensor(g[k]) for k in g.files if k.startswith("param/")}
+    assert set(sd) == {n for n, _ in m.named_parameters()}                    # same parameter names as the reference
+    m.load_state_dict(sd, strict=True)
+    b = {k[len("batch/"):]: torch.tensor(g[k]) for k in g.files if k.startswith("batch/")}
+    valid = b["attention_mask"] > 0
+    with use_ops(oops):
+        out = m(text_input_ids=b["text_input_ids"], audio_input_ids=b["audio_input_ids"],
+                attention_mask=b["attention_mask"], position_ids=b["position_ids"], compute_audio_logits=True)
+        ps, pt = cross_entropy_loss(out.logits, b["labels"], b["sentence_lens"], 4)
+        ps.backward()
+    np.testing.assert_allclose(out.logits[valid].detach().numpy(), g["text_logits"][valid.numpy()], atol=3e-5)
+    np.testing.assert_allclose(out.audio_logits[valid].detach().numpy(), g["audio_logits"][valid.numpy()], atol=3e-5)
+    assert float(ps) == pytest.approx(float(g["loss_per_sample"]), abs=1e-5)
+    assert float(pt) == pytest.approx(float(g["loss_per_token"]), abs=1e-5)
+    checked = 0
+    for n, p in m.named_parameters():
+        if "grad/" + n in g.files:
+            np.testing.assert_allclose(p.grad.numpy(), g["grad/" + n], atol=3e-5, err_msg=n)
+            checked += 1
+        else:
+            assert "mimo" in n and (p.grad is None or float(p.grad.abs().max()) == 0.0), n
+    assert checked == 4 * 12 + 1 + 1 + 1          # 4 layers x (7 weights + 3 biases + 2 norms), embedding, final norm, lm_head
+    tl, al = onn.kimi_audio_forward(sd, kw, b["audio_input_ids"], b["text_input_ids"], b["attention_mask"], b["position_ids"])
+    np.testing.assert_allclose(tl[valid].numpy(), g["text_logits"][valid.numpy()], atol=3e-5)
+    np.testing.assert_allclose(al[valid].numpy(), g["audio_logits"][valid.numpy()], atol=3e-5)

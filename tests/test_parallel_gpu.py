@@ -1,0 +1,169 @@
+"""Tensor and context parallelism THROUGH the HIP kernels on one MI355X (BASELINE configs D / E; world size > 1 is
+covered over gloo on CPU in tests/test_distributed_cpu.py and tests/test_sharded_workloads_cpu.py, the 8-GPU run is the
+driver's):
+  * the tp ranks' parts — each computed by the HIP kernels on that rank's shards — add up to the unsharded block, forward and
+    backward (the sum IS the all-reduce the real group performs);
+  * `apply_tp` and the K/V halo exchange over a 1-rank RCCL group (the collectives really are issued on the device and the
+    HIP autograd nodes run between them) train like the plain model;
+  * an emulated cp rank (bench.py --cp 4 --emulate-rank r) runs a whole Qwen2-Audio step through the split attention."""
+import os
+
+import pytest
+import torch
+import torch.distributed as dist
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+CFG = dict(model_type="qwen2", hidden_size=512, intermediate_size=1536, num_attention_heads=8, num_hidden_layers=2,
+           num_key_value_heads=4, head_dim=64, vocab_size=1024, tie_word_embeddings=False, rope_theta=1e6,
+           rms_norm_eps=1e-6, initializer_range=0.05)
+
+
+@pytest.fixture(scope="module")
+def rccl_single_rank():
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0", WORLD_SIZE="1",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV, 0))
+    yield
+    if created:
+        dist.destroy_process_group()
+
+
+def _packed_batch(B, T, vocab, seed=0):
+    from touchnet_amd.data.synthetic import text_batch
+    b = text_batch(vocab, B, T, seed=seed, min_len=40, max_len=300)
+    return {k: (v.to(DEV) if isinstance(v, torch.Tensor) else v) for k, v in b.items()}
+
+
+def _model(cfg_dict=CFG, seed=0):
+    from touchnet_amd.models.llama import DecoderConfig, PackedCausalLM
+    torch.manual_seed(seed)
+    m = PackedCausalLM(DecoderConfig.from_dict(cfg_dict))
+    m.post_init()
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if n.endswith("bias"):
+                p.normal_(std=0.05)
+    return m.to(DEV, torch.bfloat16)
+
+
+def _rel(a, b):
+    return float((a.float() - b.float()).abs().max()) / float(b.float().abs().max().clamp_min(1e-6))
+
+
+def test_tp_rank_parts_through_hip_kernels_add_up_to_the_unsharded_block():
+    from touchnet_amd.models.tensor_parallel import EmulatedTPMesh, apply_tp
+    import touchnet_amd.functional as F
+    full = _model()
+    state = {k: v.clone() for k, v in full.state_dict().items()}
+    B, T, tp = 2, 1024, 2
+    batch = _packed_batch(B, T, 1024)
+    blk = full.model.layers[0]
+    g = torch.Generator(device=DEV).manual_seed(1)
+    x = (torch.randn(B, T, 512, device=DEV, generator=g) * 0.5).bfloat16().requires_grad_()
+    cos, sin = full.model.rotary_emb(batch["position_ids"], torch.bfloat16)
+    mask = F.build_packed_mask(batch["attention_mask"])
+    da = (torch.randn(B, T, 512, device=DEV, generator=g) * 0.1).bfloat16()
+    dm = (torch.randn(B, T, 512, device=DEV, generator=g) * 0.1).bfloat16()
+
+    def run(block, xin):
+        a = block.self_attn(xin, cos, sin, mask)
+        m = block.mlp(xin)
+        torch.autograd.backward([a, m], [da, dm])
+        return a.detach(), m.detach()
+
+    a_ref, m_ref = run(blk, x)
+    dx_ref = x.grad.clone()
+    ref_grads = {n: p.grad.clone() for n, p in blk.named_parameters() if p.grad is not None}
+    a_sum = m_sum = dx_sum = 0
+    for r in range(tp):
+        part = _model()
+        part.load_state_dict(state)
+        apply_tp(part, EmulatedTPMesh(tp, r))
+        pb = part.model.layers[0]
+        assert pb.self_attn.num_heads == 4 and pb.self_attn.num_kv_heads == 2 and pb.mlp.gate_proj.weight.shape == (768, 512)
+        xr = x.detach().clone().requires_grad_()
+        a, m = run(pb, xr)
+        a_sum, m_sum, dx_sum = a_sum + a.float(), m_sum + m.float(), dx_sum + xr.grad.float()
+        for n, p in pb.named_parameters():
+            if p.grad is None:
+                continue
+            want = ref_grads[n]
+            if p.shape != want.shape:
+                want = want.chunk(tp, dim=1 if ("o_proj" in n or "down_proj" in n) else 0)[r]
+                assert _rel(p.grad, want) < 3e-2, (r, n, _rel(p.grad, want))
+    # the sums are what the forward / backward all-reduces of a real tp group deliver (fp32 here, bf16 ring there)
+    assert _rel(a_sum, a_ref) < 2e-2 and _rel(m_sum, m_ref) < 2e-2, (_rel(a_sum, a_ref), _rel(m_sum, m_ref))
+    assert _rel(dx_sum, dx_ref) < 2e-2, _rel(dx_sum, dx_ref)
+
+
+def _loss_and_grads(model, batch, **kw):
+    model.zero_grad()
+    out = model(input_ids=batch["input_ids"], position_ids=batch["position_ids"], attention_mask=batch["attention_mask"],
+                labels=batch["labels"], sentence_lens=batch["sentence_lens"], num_sentence=batch["num_sentence"], **kw)
+    out.loss.backward()
+    return float(out.loss), {n: p.grad.float().clone() for n, p in model.named_parameters() if p.grad is not None}
+
+
+def test_apply_tp_over_a_single_rank_rccl_group_is_the_plain_model(rccl_single_rank):
+    from torch.distributed.device_mesh import init_device_mesh
+    from touchnet_amd.models.tensor_parallel import apply_tp, tp_param_ids
+    batch = _packed_batch(2, 1024, 1024, seed=2)
+    plain = _model(seed=3)
+    loss0, g0 = _loss_and_grads(plain, batch)
+    wrapped = _model(seed=3)
+    mesh = init_device_mesh("cuda", (1,), mesh_dim_names=("tp",))
+    apply_tp(wrapped, mesh["tp"])                         # all-reduces over RCCL around the attention and MLP nodes
+    group, ids = tp_param_ids([wrapped])
+    assert group is not None and len(ids) == 2 * 10
+    loss1, g1 = _loss_and_grads(wrapped, batch)
+    assert loss1 == pytest.approx(loss0, rel=1e-6)
+    for n in g0:
+        assert torch.equal(g0[n], g1[n]), n
+
+
+@pytest.mark.parametrize("B", [1, 2])
+def test_kv_halo_exchange_path_over_a_single_rank_rccl_group_matches_the_plain_attention(rccl_single_rank, B):
+    """cp = 1 over RCCL: the rank owns both chunks, so `_forward_context_parallel` (K/V first, exchange issued on the side
+    stream, query path, own-chunk attention, LSE merge with an empty remote part, halo return in backward) must reproduce
+    the plain packed attention path."""
+    from touchnet_amd.utils.context_parallel import ContextParallel
+    T = 2048
+    batch = _packed_batch(B, T, 1024, seed=4)
+    model = _model(seed=5)
+    loss0, g0 = _loss_and_grads(model, batch)
+    cp = ContextParallel(dist.group.WORLD, T)
+    assert (cp.cp, cp.rank, cp.Tc) == (1, 0, T // 2)
+    cp.set_documents(batch["attention_mask"].cpu())
+    loss1, g1 = _loss_and_grads(model, batch, context_parallel=cp)
+    assert abs(loss1 - loss0) / abs(loss0) < 2e-3, (loss0, loss1)
+    for n in g0:
+        assert _rel(g1[n], g0[n]) < 4e-2, (n, _rel(g1[n], g0[n]))
+
+
+@pytest.mark.parametrize("rank", [0, 3])
+def test_emulated_cp_rank_steps_qwen2_audio_through_the_split_attention(rank):
+    import touchnet_amd.specs  # noqa: F401
+    from touchnet_amd.bin.train import TrainConfig, Trainer
+    from touchnet_amd.data.synthetic import qwen2_audio_long_plan
+    from touchnet_amd.models.qwen2_audio import Qwen2AudioConfig
+    cfg = Qwen2AudioConfig.from_dict({
+        "audio_config": {"d_model": 128, "encoder_attention_heads": 2, "encoder_ffn_dim": 256, "encoder_layers": 2,
+                         "max_source_positions": 50, "num_mel_bins": 16},
+        "audio_token_index": 1000, "text_config": dict(CFG, vocab_size=1024)})
+    T, cp, ta = 4096, 4, 25                                        # 100 mel frames -> 50 -> 25 tokens per clip
+    tok, n = qwen2_audio_long_plan(1000, 1000, 1, T, 7, tokens_per_clip=ta, resp_per_clip=(2, 5))
+    g = torch.Generator().manual_seed(0)
+    tok["input_features"] = torch.randn(n, 16, 100, generator=g)
+    job = TrainConfig(training_model_name="qwen2_audio_mi355", training_enable_fused_ce=True, lr_scheduler_lr=1e-3,
+                      lr_scheduler_warmup_steps=0)
+    tr = Trainer(job, cfg, torch.device(DEV), cp_emulate=(cp, rank))
+    data = tr.next_batch(tok)
+    assert data["input_ids"].shape == (1, T // cp) and data["attention_mask"].shape == (1, T)
+    assert 0 < data["input_features"].shape[0] < n
+    assert data["labelled_rows_max"] == int((tr.cp.shard(tok["labels"], 1) != -100).sum())
+    losses = [float(tr.train_step(tr.next_batch(tok))["loss_per_sample"]) for _ in range(4)]
+    assert all(l == l and l > 0 for l in losses) and losses[-1] < losses[0], losses

@@ -23,22 +23,19 @@ def post_init(model, init_device: torch.device):
             raise ValueError(f"NaN/inf in model parameters `{name}`.")
 
 
-def get_num_flop_per_token(num_params: int, model_config, seq_len: int, with_mimo: bool = True, model=None,
-                           tp: int = 1) -> int:
+def get_num_flop_per_token(num_params: int, model_config, seq_len: int, with_mimo: bool = True) -> int:
     """kimi_audio/__init__.py:63-80: 6*N + 12*(L + L_mimo)*H*Dh*T (the speech encoder is not counted).
-    `with_mimo=False` (+ `model`): the same formula over what a TEXT-head training step executes — the mimo layers, the
-    mimo norm and the audio head run only with `compute_audio_logits` and are left out; with `tp` > 1 `model` holds a
-    rank's shards (blocks 1/tp, heads replicated) and the result is the per-GPU count."""
+    `with_mimo=False`: the same formula over what a TEXT-head training step executes — the 28 decoder layers, the final
+    norm and lm_head; the mimo layers, the mimo norm and the audio head run only with `compute_audio_logits` and are left
+    out (`num_params` is ignored, the executed parameters follow from the config)."""
     c = model_config
     head_dim = c.hidden_size // c.num_attention_heads
     if with_mimo:
         return 6 * num_params + 12 * (c.num_hidden_layers + c.kimia_mimo_layers) * c.num_attention_heads * head_dim * seq_len
-    if model is None:
-        raise ValueError("with_mimo=False counts the executed parameters of `model`")
-    skip = ("model.mimo_layers.", "model.mimo_norm.", "mimo_output.", "model.embed_tokens.")
-    # (an FSDP2 DTensor reports the shape of the whole tp-local parameter, which is what is counted)
-    executed = sum(p.numel() for n, p in model.named_parameters() if not n.startswith(skip))
-    return 6 * executed + 12 * c.num_hidden_layers * (c.num_attention_heads // tp) * head_dim * seq_len
+    H, I, q, kv = c.hidden_size, c.intermediate_size, c.num_attention_heads * head_dim, c.num_key_value_heads * head_dim
+    layer = H * q + q + 2 * (H * kv + kv) + q * H + 3 * H * I + 2 * H          # Qwen2 layer: biased q/k/v, two norms
+    executed = c.num_hidden_layers * layer + H + c.vocab_size * H              # + final norm + lm_head
+    return 6 * executed + 12 * c.num_hidden_layers * c.num_attention_heads * head_dim * seq_len
 
 
 def get_num_params(model: torch.nn.Module, exclude_embedding: bool = False) -> int:
