@@ -106,7 +106,7 @@ def parallel_layout(world: int, cp: int = 1, tp: int = 1, emulate_rank=None) -> 
     dp = world // (cp * tp)
     parts = [f"cp{cp}"] if cp > 1 else []
     parts += [f"tp{tp}"] if tp > 1 else []
-    parts += [f"fsdp2-dp{dp}" + (f" (parameters sharded over dp x cp = {dp * cp})" if cp > 1 else "")] if dp * cp > 1 else []
+    parts += [f"dp{dp}" + (f" (gradients reduced / optimizer state sharded over dp x cp = {dp * cp})" if cp > 1 else "")] if dp * cp > 1 else []
     return {"dp": dp, "cp": cp, "tp": tp, "emulated": None, "label": " x ".join(parts) or "single-gpu"}
 
 
@@ -438,6 +438,9 @@ def main():
     ap.add_argument("--emulate-rank", type=int, default=None,
                     help="with --gpus 1 and --cp N or --tp N: run rank r of the N-way group alone on one GPU")
     ap.add_argument("--ac", choices=("none", "full", "selective"), default="none", help="activation checkpointing mode")
+    ap.add_argument("--dp-engine", choices=("flat", "fsdp2"), default=None,
+                    help="data parallelism for N > 1: flat (default) = utils/zero_dp.py, flat per-block buffers + sharded "
+                         "optimizer state; fsdp2 = torch fully_shard as the reference applies it (TN_DP_ENGINE)")
     args = ap.parse_args()
     layout = parallel_layout(args.gpus, args.cp, args.tp, args.emulate_rank)
     if args.linear_gemm:
@@ -487,6 +490,8 @@ def main():
     wl.job.training_enable_fused_ce = not args.unfused_ce
     wl.job.training_ce_compact_rows = args.compact_lm_head
     wl.job.training_activation_checkpoint_mode = args.ac
+    if args.dp_engine:
+        wl.job.training_dp_engine = args.dp_engine
     if args.all_rows_lm_head and hasattr(wl, "tokens"):
         wl.tokens.pop("labelled_rows_max", None)
     if args.ce_chunk:
@@ -547,7 +552,12 @@ def main():
             "config": {"workload": wl.name, "model": wl.job.training_model_name, "global_batch": wl.B * layout["dp"],
                        "seq_len": wl.T,
                        "parallelism": (layout["label"] if (args.cp > 1 or args.tp > 1) else
-                                       f"fsdp2-dp{world}" if (world > 1 or forced) else "single-gpu"),
+                                       f"fsdp2-dp{world}" if ((world > 1 or forced) and trainer.dp_engine is None) else
+                                       f"dp{world}" if (world > 1 or forced) else "single-gpu"),
+                       "dp_engine": ("flat per-block buffers: bf16 parameters replicated, one reduce-scatter (fp32) + one "
+                                     "in-place all-gather per block, optimizer state sharded (utils/zero_dp.py)"
+                                     if trainer.dp_engine is not None else
+                                     "torch FSDP2 fully_shard per block" if (world > 1 or forced or args.cp > 1) else None),
                        **({"emulated": dict(emu, note="ONE rank of the group on one MI355X: its shards, kernels and share "
                                                       "of the data; exchanges with the peers skipped (cp: stand-in K/V "
                                                       "chunks of the same shape and document ids).  `value` is this GPU's "

@@ -1,28 +1,17 @@
 #!/bin/bash
-# FSDP2 over a 1-rank RCCL mesh vs the unsharded model on ONE GPU: step time of both + rocprofv3 kernel stats of the
-# sharded run (what FSDP2's copy-in/out, casts and the sharded optimizer add on every rank at N = 8).
-#   usage (GPU box, repo root): bash scripts/fsdp_tax.sh
+# Data parallelism on ONE GPU over a 1-rank RCCL mesh (TN_FORCE_FSDP=1) vs the plain model: what each engine adds to the step
+# on every rank (copies, casts, the sharded optimizer, hooks).  flat = utils/zero_dp.py, fsdp2 = torch fully_shard.
+#   usage (GPU box, repo root): bash scripts/fsdp_tax.sh [--prof]
 R=$(pwd)
-export MASTER_ADDR=127.0.0.1 MASTER_PORT=29541 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0
-echo "== unsharded"; python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-rooflines 2>/dev/null | grep '^{"metric"' | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['peak_mem_GB_rank0'])"
-echo "== FSDP2, 1-rank RCCL mesh"; TN_FORCE_FSDP=1 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-rooflines 2>gpurun_out/fsdp_force.err | grep '^{"metric"' | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['peak_mem_GB_rank0'])"
-[ "$1" = "--no-prof" ] && exit 0
+export MASTER_ADDR=127.0.0.1 MASTER_PORT=29541 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 HSA_ENABLE_IPC_MODE_LEGACY=0
+mkdir -p gpurun_out
+line() { grep '^{"metric"' | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], 'ms,', d['peak_mem_GB_rank0'], 'GB,', d['config']['parallelism'])"; }
+echo "== plain";                 python bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-kernel-rooflines 2>/dev/null | line
+echo "== flat engine, 1 rank";   TN_FORCE_FSDP=1 python bench.py --dp-engine flat --steps 6 --warmup 3 --no-cpu-baseline --no-kernel-rooflines 2>gpurun_out/tax_flat.err | line
+echo "== FSDP2, 1 rank";         TN_FORCE_FSDP=1 python bench.py --dp-engine fsdp2 --steps 6 --warmup 3 --no-cpu-baseline --no-kernel-rooflines 2>gpurun_out/tax_fsdp2.err | line
+echo "== plain (again)";         python bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-kernel-rooflines 2>/dev/null | line
+[ "$1" = "--prof" ] || exit 0
 cd /tmp; export TMPDIR=/tmp
-TN_FORCE_FSDP=1 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/fsdp_prof --output-format csv -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-rooflines > $R/gpurun_out/fsdp_prof.log 2>&1
+TN_FORCE_FSDP=1 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/flat_prof --output-format csv -- python $R/bench.py --dp-engine flat --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-rooflines > $R/gpurun_out/flat_prof.log 2>&1
 cd $R
-python - <<'PY'
-import csv, glob, collections
-f = glob.glob("gpurun_out/fsdp_prof/**/*kernel_trace.csv", recursive=True)[0]
-rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-marks = [i for i, r in enumerate(rows) if "adamw_multi_kernel" in r["Kernel_Name"]]
-n = len(marks) - 1
-acc = collections.defaultdict(lambda: [0, 0])
-for r in rows[marks[0] + 1: marks[-1] + 1]:
-    a = acc[r["Kernel_Name"][:90]]
-    a[0] += 1
-    a[1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
-tot = sum(v[1] for v in acc.values()) / n / 1e6
-print(f"kernel time per step {tot:.1f} ms over {n} steps")
-for k, (c, t) in sorted(acc.items(), key=lambda kv: -kv[1][1])[:45]:
-    print(f"{t / n / 1e6:9.2f} ms {c / n:8.1f} x  {k}")
-PY
+python scripts/summarize_rocprof.py gpurun_out/flat_prof > gpurun_out/flat_prof_summary.md 2>/dev/null || true

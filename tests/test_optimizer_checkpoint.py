@@ -105,3 +105,54 @@ def test_dcp_round_trip_two_rank_fsdp_uneven_shards(tmp_path):
         assert p.exitcode == 0
     assert ret[0][0] and ret[1][0], dict(ret)
     assert ret[0][1][0] == (4, 5) and ret[1][1][0] == (3, 5), dict(ret)       # uneven shards were exercised
+
+
+def _flat_worker(rank, world, port, path, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from torch.distributed.device_mesh import init_device_mesh
+        from torch.distributed.tensor import DTensor
+        from touchnet_amd.models.llama import DecoderConfig, PackedCausalLM
+        from touchnet_amd.utils.zero_dp import FlatShardedDataParallel
+        mesh = init_device_mesh("cpu", (world,))
+        cfg = DecoderConfig.from_dict(dict(vocab_size=16, hidden_size=64, intermediate_size=96, num_hidden_layers=2,
+                                           num_attention_heads=8, num_key_value_heads=4, head_dim=8,
+                                           tie_word_embeddings=False))
+
+        def build():
+            torch.manual_seed(5)
+            m = PackedCausalLM(cfg)
+            eng = FlatShardedDataParallel(m, mesh)
+            return eng, FusedAdamW(eng.named_shards(), lr=1e-3, process_group=mesh.get_group())
+        eng, opt = build()
+        assert opt.names[:2] == ["block.0.0", "block.0.1"]
+        _fill(opt, 1000.0 * rank)
+        want = [{k: v.clone() for k, v in s.items()} for s in opt.state]
+        sd = opt.state_dict()
+        first = sd["state"]["block.0.0"]["exp_avg"]
+        assert isinstance(first, DTensor) and tuple(first.shape) == (eng.buckets[0].total,)      # the whole flat buffer
+        assert first.to_local().numel() == eng.buckets[0].S
+        dcp.save({"optimizer": sd}, checkpoint_id=path)
+        eng2, opt2 = build()
+        sd2 = {"optimizer": opt2.state_dict()}
+        dcp.load(sd2, checkpoint_id=path)
+        opt2.load_state_dict(sd2["optimizer"])
+        ret[rank] = all(torch.equal(s[k], w[k]) for s, w in zip(opt2.state, want) for k in ("master", "m", "v"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dcp_round_trip_of_the_flat_engines_shards(tmp_path):
+    """utils/zero_dp.py: the optimizer state of a bucket is this rank's slice of a flat buffer; it is saved as a dim-0
+    sharded DTensor of the whole buffer and every rank reloads its own slice."""
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_flat_worker, args=(r, 2, port, str(tmp_path / "ck3"), ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    assert ret[0] and ret[1], dict(ret)

@@ -167,3 +167,36 @@ def test_emulated_cp_rank_steps_qwen2_audio_through_the_split_attention(rank):
     assert data["labelled_rows_max"] == int((tr.cp.shard(tok["labels"], 1) != -100).sum())
     losses = [float(tr.train_step(tr.next_batch(tok))["loss_per_sample"]) for _ in range(4)]
     assert all(l == l and l > 0 for l in losses) and losses[-1] < losses[0], losses
+
+
+@pytest.mark.parametrize("reduce", ["float32", "bfloat16"])
+def test_flat_data_parallel_engine_over_a_single_rank_rccl_group_trains_like_the_plain_model(rccl_single_rank, reduce, monkeypatch):
+    """utils/zero_dp.py on the device: parameters re-pointed into flat buffers (the HIP kernels read the views), gradients
+    cast-copied into the staging pool by the hooks, reduce_scatter_tensor / in-place all_gather_into_tensor over RCCL on the
+    side stream, FusedAdamW on the flat slices — three steps give the unsharded trainer's losses."""
+    import touchnet_amd.specs  # noqa: F401
+    from touchnet_amd.bin.train import TrainConfig, Trainer
+    from touchnet_amd.data.synthetic import text_batch
+    from touchnet_amd.models.llama import DecoderConfig
+    from touchnet_amd.utils.distributed import build_dp_mesh
+    cfg = DecoderConfig.from_dict(dict(CFG, model_type="llama"))
+    job = dict(training_model_name="llama_mi355", training_enable_fused_ce=True, lr_scheduler_warmup_steps=0,
+               lr_scheduler_lr=1e-3, training_mixed_precision_reduce=reduce)
+    batches = [text_batch(1024, 4, 512, seed=s, max_len=90) for s in range(3)]
+    plain = Trainer(TrainConfig(**job), cfg, torch.device(DEV))
+    ref = [float(plain.train_step(plain.next_batch(b))["loss_per_sample"]) for b in batches]
+    ref_norm = float(plain.train_step(plain.next_batch(batches[0]))["grad_norm"])
+    monkeypatch.setenv("TN_FORCE_FSDP", "1")
+    tr = Trainer(TrainConfig(**job, training_dp_engine="flat"), cfg, torch.device(DEV, 0), dp_mesh=build_dp_mesh("cuda", 1))
+    eng = tr.dp_engine
+    assert eng is not None and eng.world == 1 and len(eng.buckets) == 2 + 3
+    assert all(p.dtype == torch.bfloat16 and not hasattr(p, "_local_tensor") for p in tr.model.parameters())
+    got = [float(tr.train_step(tr.next_batch(b))["loss_per_sample"]) for b in batches]
+    norm = float(tr.train_step(tr.next_batch(batches[0]))["grad_norm"])
+    assert eng.buckets[0].shard.grad.dtype == getattr(torch, reduce)
+    assert all(p.grad is None for p in tr.model.parameters())
+    tol = 1e-5 if reduce == "float32" else 2e-3            # same init, same kernels: only the gradient dtype differs
+    for a, b in zip(got, ref):
+        assert abs(a - b) / abs(b) < tol, (got, ref)
+    assert abs(norm - ref_norm) / ref_norm < max(tol, 1e-4), (norm, ref_norm)
+    assert got[-1] < got[0]

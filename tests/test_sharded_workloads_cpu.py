@@ -72,9 +72,9 @@ def test_rank_without_audio_still_runs_the_tower_on_one_clip_and_keeps_no_row():
 def test_parallel_layout_of_the_bench_flags():
     import bench
     d = bench.parallel_layout(8, cp=4)
-    assert (d["dp"], d["cp"], d["tp"], d["emulated"]) == (2, 4, 1, None) and d["label"].startswith("cp4 x fsdp2-dp2")
+    assert (d["dp"], d["cp"], d["tp"], d["emulated"]) == (2, 4, 1, None) and d["label"].startswith("cp4 x dp2")
     e = bench.parallel_layout(8, tp=2)
-    assert (e["dp"], e["tp"]) == (4, 2) and e["label"] == "tp2 x fsdp2-dp4"
+    assert (e["dp"], e["tp"]) == (4, 2) and e["label"] == "tp2 x dp4"
     assert bench.parallel_layout(1)["label"] == "single-gpu"
     m = bench.parallel_layout(1, cp=4, emulate_rank=3)
     assert m["emulated"] == {"group": "cp", "size": 4, "rank": 3}
@@ -120,7 +120,7 @@ def _qa_reference(T):
             {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}, float(out.loss), tok)
 
 
-def _qa_worker(rank, world, port, ref_state, ref_grads, ref_loss, batch, ret):
+def _qa_worker(rank, world, port, ref_state, ref_grads, ref_loss, batch, ret, engine="fsdp2"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
     import oracle.ops as oops
@@ -135,10 +135,13 @@ def _qa_worker(rank, world, port, ref_state, ref_grads, ref_loss, batch, ret):
         mesh = init_device_mesh("cpu", (1, world), mesh_dim_names=("dp", "cp"))
         flat = mesh["dp", "cp"]._flatten("dp_cp")
         job = TrainConfig(training_model_name="qwen2_audio_mi355", training_enable_fused_ce=True,
-                          training_mixed_precision_param="float32")
+                          training_mixed_precision_param="float32", training_dp_engine=engine)
+        factory = (lambda ps: TorchAdamW(ps)) if engine == "fsdp2" else (lambda sh: ShardAdamW(sh, group=flat.get_group()))
+        factory.takes_shards = engine == "flat"
         with use_ops(oops):
             tr = Trainer(job, Qwen2AudioConfig.from_dict(QA_TINY), torch.device("cpu"), dp_mesh=mesh["dp"],
-                         cp_mesh=mesh["cp"], fsdp_mesh=flat, optimizer_factory=lambda ps: TorchAdamW(ps))
+                         cp_mesh=mesh["cp"], fsdp_mesh=flat, optimizer_factory=factory)
+            assert (tr.dp_engine is not None) == (engine == "flat")
             with torch.no_grad():
                 for name, p in tr.model.named_parameters():
                     full = ref_state[name]
@@ -157,11 +160,19 @@ def _qa_worker(rank, world, port, ref_state, ref_grads, ref_loss, batch, ret):
             assert float(total) == pytest.approx(ref_loss, rel=1e-5)
             loss.backward()
             worst = 0.0
+            grads = {}
+            if engine == "flat":                  # gradients left the parameters: rebuild them from the reduced shards
+                tr.dp_engine.finish_backward()
+                for b in tr.dp_engine.buckets:
+                    full = torch.empty(b.total)
+                    dist.all_gather_into_tensor(full, b.shard.grad, group=flat.get_group())
+                    for p, o in zip(b.params, b.offsets):
+                        grads[id(p)] = full[o:o + p.numel()].view(p.shape)
             for name, p in tr.model.named_parameters():
                 if name not in ref_grads:                                # (the tower's frozen sinusoidal positions)
                     assert p.grad is None or not p.requires_grad, name
                     continue
-                g = p.grad.full_tensor() if hasattr(p.grad, "full_tensor") else p.grad
+                g = grads[id(p)] if engine == "flat" else p.grad.full_tensor() if hasattr(p.grad, "full_tensor") else p.grad
                 worst = max(worst, float((g * world - ref_grads[name]).abs().max()))
             assert worst < 5e-5, worst
         ret[rank] = ("ok", n_mine, n_all)
@@ -174,8 +185,8 @@ def _qa_worker(rank, world, port, ref_state, ref_grads, ref_loss, batch, ret):
             dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,T", [(2, 512), (4, 1024)])
-def test_qwen2_audio_under_context_parallelism_equals_single_process(world, T):
+@pytest.mark.parametrize("world,T,engine", [(2, 512, "fsdp2"), (4, 1024, "fsdp2"), (2, 512, "flat")])
+def test_qwen2_audio_under_context_parallelism_equals_single_process(world, T, engine):
     """Config D's split of a Qwen2-Audio batch: every cp rank runs the audio tower on the clips that touch its part of
     the sequence (clips cut by a chunk boundary on both sides), scatters its rows into its part of the embeddings and
     runs lm_head + CE on its own labelled rows; the loss parts add up to the single-process loss and the FSDP-averaged
@@ -183,7 +194,7 @@ def test_qwen2_audio_under_context_parallelism_equals_single_process(world, T):
     ref_state, ref_grads, ref_loss, batch = _qa_reference(T)
     with mp.Manager() as mgr:
         ret = mgr.dict()
-        mp.spawn(_qa_worker, args=(world, _free_port(), ref_state, ref_grads, ref_loss, batch, ret), nprocs=world,
+        mp.spawn(_qa_worker, args=(world, _free_port(), ref_state, ref_grads, ref_loss, batch, ret, engine), nprocs=world,
                  join=True)
         results = dict(ret)
     for r in range(world):
@@ -369,3 +380,149 @@ def test_tensor_parallel_times_fsdp2_on_a_2d_mesh_of_four_ranks():
         results = dict(ret)
     for r in range(4):
         assert results[r][0] == "ok", results[r][1]
+
+
+# ------------------------------------------------------------------------------------------------ flat data-parallel engine
+class ShardAdamW:
+    """torch.optim.AdamW over the flat engine's shards (CPU stand-in for FusedAdamW: fp32 everywhere here)."""
+    takes_shards = True
+
+    def __init__(self, named_shards, lr=1e-2, max_norm=1.0, group=None):
+        self.shards = [s for _, s in named_shards]
+        self.params = [torch.nn.Parameter(s.data) for s in self.shards]          # share the slices' storage
+        self.opt = torch.optim.AdamW(self.params, lr=lr, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.1)
+        self.max_norm, self.group = max_norm, group
+
+    def zero_grad(self):
+        self.opt.zero_grad(set_to_none=True)
+
+    def step(self, lr=None):
+        sq = torch.zeros(1)
+        for p, s in zip(self.params, self.shards):
+            p.grad = None if s.grad is None else s.grad.to(p.dtype)
+            if p.grad is not None:
+                sq += p.grad.float().pow(2).sum()
+        dist.all_reduce(sq, group=self.group)
+        norm = sq.sqrt()
+        coef = torch.clamp(self.max_norm / (norm + 1e-6), max=1.0)
+        for p in self.params:
+            if p.grad is not None:
+                p.grad.mul_(coef)
+        self.opt.step()
+        return norm.squeeze(0)
+
+
+def _flat_worker(rank, world, port, model_name, cfg_dict, ref_state, batches, ref_after, ref_norm, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import oracle.ops as oops
+    import touchnet_amd.specs  # noqa: F401
+    from touchnet_amd.bin.train import TrainConfig, Trainer
+    from touchnet_amd.models.backend import use_ops
+    from touchnet_amd.utils.distributed import build_dp_mesh, init_distributed
+    from touchnet_amd.utils.train_spec import get_train_spec
+    try:
+        init_distributed("cpu")
+        mesh = build_dp_mesh("cpu", world)
+        job = TrainConfig(training_model_name=model_name, training_enable_fused_ce=True,
+                          training_mixed_precision_param="float32", training_dp_engine="flat")
+        spec = get_train_spec(model_name)
+        cfg = spec.config_cls.from_dict(cfg_dict) if hasattr(spec.config_cls, "from_dict") else spec.config_cls(**cfg_dict)
+        factory = lambda shards: ShardAdamW(shards, group=mesh.get_group())
+        factory.takes_shards = True
+        with use_ops(oops):
+            tr = Trainer(job, cfg, torch.device("cpu"), dp_mesh=mesh, optimizer_factory=factory)
+            eng = tr.dp_engine
+            assert eng is not None and not any(hasattr(p, "_local_tensor") for p in tr.model.parameters())
+            with torch.no_grad():
+                for name, p in tr.model.named_parameters():
+                    p.copy_(ref_state[name])                                  # (views: writes the flat buffers)
+            # every trainable parameter is a view into exactly one flat buffer
+            owned = sum(p.numel() for b in eng.buckets for p in b.params)
+            assert owned == sum(p.numel() for p in tr.model.parameters() if p.requires_grad)
+            for b in eng.buckets:
+                for p, o in zip(b.params, b.offsets):
+                    assert p.data_ptr() == b.flat_p[o:].data_ptr() and o % 128 == 0
+                assert b.shard.data.data_ptr() == b.flat_p[rank * b.S:].data_ptr()
+            norms = []
+            for step in range(2):
+                stats = tr.train_step(tr.next_batch(batches[step][rank]))
+                norms.append(float(stats["grad_norm"]))
+                assert all(p.grad is None for p in tr.model.parameters())     # gradients live in the staging buffers only
+            worst = max(float((p.detach() - ref_after[n]).abs().max()) for n, p in tr.model.named_parameters())
+            # (AdamW's m / sqrt(v) turns the 1-ulp differences of a mean over 3 ranks into up to ~1e-4 of an lr = 1e-2 step)
+            assert worst < (2e-5 if world == 2 else 3e-4), worst
+            assert norms[0] == pytest.approx(ref_norm[0], rel=1e-4) and norms[1] == pytest.approx(ref_norm[1], rel=1e-4)
+            assert len(eng._pool) <= 3                                        # staging is a small pool, not one per block
+        ret[rank] = ("ok", worst, [b.name for b in eng.buckets])
+    except Exception as e:
+        import traceback
+        ret[rank] = ("fail", traceback.format_exc(), repr(e))
+    finally:
+        if dist.is_initialized():
+            dist.barrier()
+            dist.destroy_process_group()
+
+
+def _flat_reference(model_cls, cfg, batches, world, fwd):
+    """single process: two AdamW steps on the dp-averaged gradient of the per-rank losses"""
+    import oracle.ops as oops
+    from touchnet_amd.models.backend import use_ops
+    torch.manual_seed(17)
+    model = model_cls(cfg)
+    model.post_init()
+    state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.AdamW(params, lr=1e-2, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.1)
+    norms = []
+    with use_ops(oops):
+        for step in range(2):
+            opt.zero_grad(set_to_none=True)
+            total_ns = sum(b["num_sentence"] for b in batches[step])
+            loss = sum(fwd(model, b, total_ns).loss for b in batches[step]) / world
+            loss.backward()
+            norms.append(float(torch.nn.utils.clip_grad_norm_([p for p in params if p.grad is not None], 1.0)))
+            opt.step()
+    return state, {n: p.detach().clone() for n, p in model.named_parameters()}, norms
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_flat_data_parallel_engine_trains_like_one_process(world):
+    """utils/zero_dp.py on gloo: parameters as views of flat per-block buffers, gradients cast-copied into pooled staging
+    buffers by the post-accumulate hooks, reduce-scatter (AVG) per block, AdamW on each rank's slice, in-place all-gather
+    — two optimizer steps end at the same parameters and report the same global gradient norm as one process on the
+    averaged loss.  World size 3: padded buckets (shard boundaries inside parameters)."""
+    from touchnet_amd.data.synthetic import text_batch
+    from touchnet_amd.models.llama import DecoderConfig, PackedCausalLM
+    cfg_dict = dict(TINY, num_hidden_layers=3, tie_word_embeddings=False)
+    batches = [[text_batch(16, 2, 32, seed=100 + 10 * s + r, max_len=9) for r in range(world)] for s in range(2)]
+    fwd = lambda m, b, ns: m(input_ids=b["input_ids"], position_ids=b["position_ids"], attention_mask=b["attention_mask"],
+                             labels=b["labels"], sentence_lens=b["sentence_lens"], num_sentence=ns)
+    state, after, norms = _flat_reference(PackedCausalLM, DecoderConfig.from_dict(cfg_dict), batches, world, fwd)
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_flat_worker, args=(world, _free_port(), "llama_mi355", cfg_dict, state, batches, after, norms, ret),
+                 nprocs=world, join=True)
+        results = dict(ret)
+    for r in range(world):
+        assert results[r][0] == "ok", results[r][1]
+    assert results[0][2] == ["block.0.0", "block.0.1", "block.0.2", "rest.model.embed_tokens", "rest.model.norm",
+                             "rest.lm_head"]
+
+
+def test_flat_engine_with_a_branch_that_takes_no_part_in_the_step():
+    """Kimi-Audio's text-head step never runs the mimo layers: their buckets receive no gradient on any rank, are skipped
+    by the engine and the optimizer alike (no collective is issued for them) and keep their parameters."""
+    world = 2
+    batches = [[dict(_tp_fsdp_batches(world)[r]) for r in range(world)] for _ in range(2)]
+    from touchnet_amd.models.kimi_audio import KimiAudioConfig, KimiAudioPackedForCausalLM
+    fwd = lambda m, b, ns: m(**{k: v for k, v in b.items() if k != "num_sentence"}, num_sentence=ns)
+    state, after, norms = _flat_reference(KimiAudioPackedForCausalLM, KimiAudioConfig(**KIMI_TINY), batches, world, fwd)
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_flat_worker, args=(world, _free_port(), "kimi_audio_mi355", KIMI_TINY, state, batches, after, norms,
+                                     ret), nprocs=world, join=True)
+        results = dict(ret)
+    for r in range(world):
+        assert results[r][0] == "ok", results[r][1]
+    assert "block.1.0" in results[0][2]                                       # the mimo block has a bucket of its own

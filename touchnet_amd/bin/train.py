@@ -36,6 +36,9 @@ class TrainConfig:
     training_mixed_precision_param: str = "bfloat16"
     training_mixed_precision_reduce: str = "float32"
     training_fsdp_reshard_after_forward: str = "never"
+    training_dp_engine: str = "flat"           # data parallelism of THIS driver: "flat" = utils/zero_dp.py (flat per-block
+                                               # buffers, sharded optimizer state), "fsdp2" = the reference's fully_shard
+                                               # (always used under tensor parallelism and behind `parallelize_fn`)
     training_activation_checkpoint_mode: str = "none"             # "none" | "full" | "selective"
     training_activation_checkpoint_selective_ac_option: str = "2"
     training_compile: bool = False
@@ -115,6 +118,13 @@ class Trainer:
                              "pass fsdp_mesh = the flattened dp x cp mesh")
         ac = job.training_activation_checkpoint_mode != "none"
         tp = self.tp_mesh.size() if self.tp_mesh is not None else 1
+        engine = os.environ.get("TN_DP_ENGINE", job.training_dp_engine)
+        if engine not in ("flat", "fsdp2"):
+            raise ValueError(f"training_dp_engine: {engine!r} (flat | fsdp2)")
+        # (a test's optimizer stand-in must declare that it takes the engine's flat shards: `takes_shards = True`)
+        flat = (sharded and engine == "flat" and tp == 1
+                and (optimizer_factory is None or getattr(optimizer_factory, "takes_shards", False)))
+        sharded = sharded and not flat                             # from here on: "FSDP2-sharded parameters"
         if sharded or ac or tp > 1:
             # the hook is called the way the reference trainer calls it (train.py:259-261): meta model, the mesh
             # indexed by the reference's dimension names, ParallelDims, job config
@@ -145,8 +155,17 @@ class Trainer:
             seq_cfg = getattr(model_config, "text_config", model_config)
             reinit_tp_shards(model, job.training_seed, getattr(seq_cfg, "initializer_range", 0.02))
         self.model = model
+        self.dp_engine = None
+        if flat:
+            from touchnet_amd.utils.zero_dp import FlatShardedDataParallel
+            self.dp_engine = FlatShardedDataParallel(model, fsdp_mesh,
+                                                     reduce_dtype=getattr(torch, job.training_mixed_precision_reduce))
         if optimizer_factory is not None:          # (CPU tests drive the host logic with a torch optimizer)
-            self.optimizer = optimizer_factory(model.parameters())
+            self.optimizer = optimizer_factory(self.dp_engine.named_shards() if flat else model.parameters())
+        elif flat:
+            self.optimizer = FusedAdamW(self.dp_engine.named_shards(), lr=job.lr_scheduler_lr,
+                                        weight_decay=job.optimizer_weight_decay, max_norm=job.training_max_norm,
+                                        process_group=fsdp_mesh.get_group())
         else:
             from touchnet_amd.models.tensor_parallel import tp_param_ids
             tp_group, tp_ids = tp_param_ids([model])
@@ -227,13 +246,19 @@ class Trainer:
 
     def train_step(self, data: dict) -> dict:
         self.optimizer.zero_grad()
+        if self.dp_engine is not None:
+            self.dp_engine.zero_grad()
         loss, per_token, acc = self.forward_loss(data)
         # Exactly the reference (train.py:456): backward on the loss normalised by the GLOBAL num_sentence;
         # FSDP2's reduce-scatter then AVERAGES over dp, i.e. gradients are 1/dp of the global-batch mean
         # gradient.  We keep that scale for parity (AdamW is invariant to it, the clip threshold is not).
         loss.backward()
+        if self.dp_engine is not None:
+            self.dp_engine.finish_backward()     # reduce-scatters ran under the backward; shards go to the optimizer
         lr = self.job.lr_scheduler_lr * linear_warmup_linear_decay(
             self.step, self.job.lr_scheduler_warmup_steps, self.job.lr_scheduler_steps)
         grad_norm = self.optimizer.step(lr)
+        if self.dp_engine is not None:
+            self.dp_engine.gather_params()       # all-gathers of the updated slices travel under the next forward
         self.step += 1
         return {"loss_per_sample": loss.detach(), "loss_per_token": per_token, "acc": acc, "grad_norm": grad_norm}

@@ -1,0 +1,260 @@
+"""Data parallelism for the packed path laid out for 288 GB of HBM: flat per-block buffers, ONE reduce-scatter and ONE
+all-gather per block and step, optimizer state sharded (ZeRO-1 over buckets).
+
+Role in the reference: `apply_fsdp` (touchnet/models/helper_func.py:134-202; FSDP2 `fully_shard` per block with
+MixedPrecisionPolicy(param=bf16, reduce=fp32)) — which stays available behind `parallelize_fn` (models/parallelize.py)
+and is what the tensor-parallel layout composes with.  Why a second engine: a 7-8 B model in bf16 is 17 GB of a 288 GB
+device, so sharding the PARAMETERS buys nothing here, and FSDP2's per-parameter DTensor plumbing costs (measured on one
+MI355X, profiles/r02_fsdp2_single_rank_tax.md: +108 ms on a 807 ms step) an fp32->bf16 cast into the all-gather input, a
+copy-out of the gathered block into parameter tensors, a bf16->fp32 concatenating copy into the reduce-scatter input and
+fp32 gradient shards — the latter two on every rank whatever the world size.  Here instead:
+
+  * the bf16 parameters of a block are VIEWS into one flat buffer (`flat_p`); rank r owns the contiguous slice
+    [r S, (r+1) S) of it: the in-place `all_gather_into_tensor(flat_p, flat_p[slice])` needs no copy-in and no copy-out;
+  * a parameter's gradient is moved (one cast-copy, bf16 -> reduce dtype) into the block's flat staging buffer the moment
+    autograd has accumulated it, and freed; when the block's last gradient has arrived `reduce_scatter_tensor` runs on a
+    side stream under the rest of the backward; staging buffers are a small pool (a block's buffer is reused two blocks
+    later), the reduced shards are persistent;
+  * the optimizer (utils/optimizer.FusedAdamW: fp32 master + moments) sees ONE tensor per block — the rank's slice of
+    `flat_p` with the reduced gradient shard — and rewrites the bf16 slice in the same pass; the global norm is the
+    all-reduced sum over the shards;
+  * the all-gathers of the updated slices are issued right after the optimizer step on the side stream; a block's forward
+    waits (stream-side, no host sync) for its own buffer only, so they travel under the next step's frontend and forward.
+
+Memory per GPU at N ranks for P parameters: 2 P (bf16) + 12 P / N (fp32 master, m, v) + the staging pool, against
+16 P unsharded: Qwen2-Audio-7B at N = 8: 17 + 12.6 + 8 GB.  Gradient averaging, the fp32 reduction and the
+skip-on-nonfinite semantics are FSDP2's / the reference's; `reduce_dtype=bfloat16` halves the xGMI bytes.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from touchnet_amd.models.helper_func import block_groups
+
+ALIGN = 128          # elements: every parameter starts on a 256-byte boundary inside its flat buffer
+
+
+class Shard:
+    """What the optimizer sees of a bucket: this rank's slice of the flat parameter buffer + its reduced gradient.  (Not
+    an nn.Parameter: the gradient shard is in the REDUCE dtype, which torch does not allow to differ from the data's.)
+    `device_mesh` / `placements` / `shape` / `stride()` describe it as a dim-0 sharded 1-D DTensor for DCP
+    (FusedAdamW._as_saved)."""
+    requires_grad = True
+
+    def __init__(self, data: torch.Tensor, total: int, mesh=None):
+        self.data, self.grad = data, None
+        self.shape = torch.Size((total,))
+        self.device_mesh = mesh
+        if mesh is not None:
+            from torch.distributed.tensor import Shard as _S
+            self.placements = (_S(0),)
+
+    def stride(self):
+        return (1,)
+
+    def numel(self):
+        return self.data.numel()
+
+    device = property(lambda self: self.data.device)
+    dtype = property(lambda self: self.data.dtype)
+
+
+class _Bucket:
+    def __init__(self, name: str, params: List[nn.Parameter], world: int, rank: int, mesh):
+        self.name, self.params = name, params
+        self.offsets, off = [], 0
+        for p in params:
+            self.offsets.append(off)
+            off += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+        self.total = (off + world * ALIGN - 1) // (world * ALIGN) * (world * ALIGN)
+        self.S = self.total // world
+        # gaps between parameters + the tail: staging bytes no gradient ever lands on (kept zero)
+        self.gaps = [(o + p.numel(), (self.offsets[i + 1] if i + 1 < len(params) else self.total))
+                     for i, (o, p) in enumerate(zip(self.offsets, params))]
+        self.gaps = [(a, b) for a, b in self.gaps if b > a]
+        p0 = params[0]
+        self.flat_p = torch.zeros(self.total, dtype=p0.dtype, device=p0.device)
+        with torch.no_grad():
+            for p, o in zip(params, self.offsets):
+                view = self.flat_p[o:o + p.numel()].view(p.shape)
+                view.copy_(p.data)
+                p.data = view
+        self.shard = Shard(self.flat_p[rank * self.S:(rank + 1) * self.S], self.total, mesh)
+        self.gshard: Optional[torch.Tensor] = None      # reduced gradient shard (persistent, allocated on first use)
+        self.stage: Optional[torch.Tensor] = None       # staging buffer of this step (from the pool)
+        self.arrived = [False] * len(params)
+        self.pending = len(params)
+        self.launched = False
+        self.reduced = None                             # event: the reduce-scatter has finished
+        self.params_ready = None                        # event: the all-gather of the updated slices has finished
+
+
+class FlatShardedDataParallel:
+    def __init__(self, model: nn.Module, mesh, reduce_dtype: torch.dtype = torch.float32):
+        """`mesh`: the 1-D device mesh gradients are averaged over (dp, or dp x cp flattened).  Buckets: one per
+        transformer block (models.helper_func.block_groups, the reference's FSDP units) + one per module that owns any of
+        the remaining parameters.  Inside a bucket that does take part, a parameter without a gradient counts as a zero
+        gradient (torch would skip it; no such parameter exists in the models of this path)."""
+        self.model, self.mesh = model, mesh
+        self.group = mesh.get_group()
+        self.world, self.rank = dist.get_world_size(self.group), dist.get_rank(self.group)
+        self.reduce_dtype = reduce_dtype
+        params = [p for p in model.parameters() if p.requires_grad]
+        self.device = params[0].device
+        self.cuda = self.device.type == "cuda"
+        seen, self.buckets, self._hooked_modules = set(), [], []
+        blocks = [(f"{gi}.{bi}", blk) for gi, grp in enumerate(block_groups(model)) for bi, blk in enumerate(grp)]
+        for name, blk in blocks:
+            ps = [p for p in blk.parameters() if p.requires_grad and id(p) not in seen]
+            seen.update(id(p) for p in ps)
+            if ps:
+                self.buckets.append(_Bucket(f"block.{name}", ps, self.world, self.rank, mesh))
+                self._hooked_modules.append((blk, self.buckets[-1]))
+        # the remaining parameters: one bucket per owning module (embedding, final norm, each head, projector, stem ...).
+        # A bucket is all-or-nothing for the optimizer: one NONE of whose parameters took part in a step is skipped like
+        # torch skips `grad is None` parameters (no weight decay either) — Kimi-Audio's audio head and mimo norm in a
+        # text-head step — so parameters of different modules must not share one.
+        self.rest = []
+        for mname, mod in model.named_modules():
+            ps = [p for p in mod.parameters(recurse=False) if p.requires_grad and id(p) not in seen]
+            seen.update(id(p) for p in ps)
+            if ps:
+                self.rest.append(_Bucket(f"rest.{mname or 'root'}", ps, self.world, self.rank, mesh))
+        self.buckets += self.rest
+        self._of = {}
+        for b in self.buckets:
+            for i, p in enumerate(b.params):
+                self._of[id(p)] = (b, i)
+                p.register_post_accumulate_grad_hook(self._on_grad)
+        # every replica starts from rank 0's numbers (the seeds agree already; this makes it unconditional)
+        for b in self.buckets:
+            dist.broadcast(b.flat_p, src=dist.get_global_rank(self.group, 0), group=self.group)
+        self.comm = torch.cuda.Stream(device=self.device) if self.cuda else None
+        self._pool, self._pool_free_at = [], []          # staging buffers + the event after which each is reusable
+        self._pool_numel = max(b.total for b in self.buckets if b not in self.rest) if len(self.rest) < len(self.buckets) else 0
+        for blk, b in self._hooked_modules:
+            blk.register_forward_pre_hook(lambda m, a, _b=b: self._wait_params(_b))
+
+        def wait_rest(module, args):
+            for b in self.rest:
+                self._wait_params(b)
+        model.register_forward_pre_hook(wait_rest)
+        self.avg = dist.ReduceOp.AVG
+        self.staged_bytes = 0                            # diagnostics (tests): bytes moved into staging this step
+
+    # ------------------------------------------------------------------ optimizer view
+    def named_shards(self):
+        return [(b.name, b.shard) for b in self.buckets]
+
+    # ------------------------------------------------------------------ gradients
+    def _acquire(self, b: _Bucket) -> torch.Tensor:
+        if b in self.rest:                               # open during the whole backward: a buffer of its own
+            if b.stage is None:
+                b.stage = torch.zeros(b.total, dtype=self.reduce_dtype, device=self.device)
+            if b.reduced is not None and self.cuda:
+                torch.cuda.current_stream().wait_event(b.reduced)
+            return b.stage
+        for i, ev in enumerate(self._pool_free_at):
+            if ev is not False:                          # False = in use by an open bucket
+                if ev is not None and self.cuda:
+                    torch.cuda.current_stream().wait_event(ev)
+                self._pool_free_at[i] = False
+                b._slot = i
+                return self._pool[i][:b.total]
+        self._pool.append(torch.zeros(self._pool_numel, dtype=self.reduce_dtype, device=self.device))
+        self._pool_free_at.append(False)
+        b._slot = len(self._pool) - 1
+        return self._pool[-1][:b.total]
+
+    def _on_grad(self, p: nn.Parameter) -> None:
+        b, i = self._of[id(p)]
+        if b.launched:
+            raise RuntimeError(f"gradient of a parameter of bucket {b.name} arrived after its reduce-scatter was issued "
+                               "(gradient accumulation over several backward passes is not supported by this engine)")
+        first = b.pending == len(b.params) and not any(b.arrived)
+        if first:
+            b.stage = self._acquire(b)
+            for a, e in b.gaps:                          # (stale numbers of the buffer's previous user)
+                b.stage[a:e].zero_()
+        o = b.offsets[i]
+        b.stage[o:o + p.numel()].view(p.shape).copy_(p.grad)          # the one cast-copy of this gradient
+        self.staged_bytes += p.numel() * (p.grad.element_size() + b.stage.element_size())
+        p.grad = None
+        if not b.arrived[i]:
+            b.arrived[i] = True
+            b.pending -= 1
+        if b.pending == 0:
+            self._launch(b)
+
+    def _launch(self, b: _Bucket) -> None:
+        if b.gshard is None:
+            b.gshard = torch.empty(b.S, dtype=self.reduce_dtype, device=self.device)
+        if self.cuda:
+            ready = torch.cuda.Event()
+            ready.record()
+            self.comm.wait_event(ready)
+            with torch.cuda.stream(self.comm):
+                dist.reduce_scatter_tensor(b.gshard, b.stage, op=self.avg, group=self.group)
+                b.reduced = torch.cuda.Event()
+                b.reduced.record()
+            if b not in self.rest:
+                self._pool_free_at[b._slot] = b.reduced
+        else:
+            dist.reduce_scatter_tensor(b.gshard, b.stage, op=self.avg, group=self.group)
+            if b not in self.rest:
+                self._pool_free_at[b._slot] = None
+        b.launched = True
+
+    def finish_backward(self) -> None:
+        """After `loss.backward()`: issue what is still open (blocks some of whose parameters took no part in this step
+        get zeros there; blocks NONE of whose parameters did are skipped on every rank alike and keep `grad = None`),
+        make the compute stream wait for the reductions and hand the shards to the optimizer."""
+        for b in self.buckets:
+            if not b.launched and any(b.arrived):
+                for i, (p, o) in enumerate(zip(b.params, b.offsets)):
+                    if not b.arrived[i]:
+                        b.stage[o:o + p.numel()].zero_()
+                self._launch(b)
+        for b in self.buckets:
+            if b.launched:
+                if self.cuda:
+                    torch.cuda.current_stream().wait_event(b.reduced)
+                b.shard.grad = b.gshard
+            else:
+                b.shard.grad = None
+
+    def zero_grad(self) -> None:
+        for b in self.buckets:
+            b.arrived = [False] * len(b.params)
+            b.pending, b.launched = len(b.params), False
+            b.shard.grad = None
+            for p in b.params:
+                p.grad = None
+        self.staged_bytes = 0
+
+    # ------------------------------------------------------------------ parameters
+    def gather_params(self) -> None:
+        """After the optimizer step (it rewrote this rank's slice of every flat buffer): all-gather the slices in the order
+        the next forward needs them, on the side stream."""
+        order = self.rest + [b for b in self.buckets if b not in self.rest]
+        if self.cuda:
+            done = torch.cuda.Event()
+            done.record()
+            self.comm.wait_event(done)
+            with torch.cuda.stream(self.comm):
+                for b in order:
+                    dist.all_gather_into_tensor(b.flat_p, b.shard.data, group=self.group)
+                    b.params_ready = torch.cuda.Event()
+                    b.params_ready.record()
+        else:
+            for b in order:
+                dist.all_gather_into_tensor(b.flat_p, b.shard.data, group=self.group)
+
+    def _wait_params(self, b: _Bucket) -> None:
+        if self.cuda and b.params_ready is not None:
+            torch.cuda.current_stream().wait_event(b.params_ready)
+            b.params_ready = None
