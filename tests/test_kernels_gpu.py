@@ -994,6 +994,47 @@ def test_gemm_operand_modes_match_fp64_reference(mode, M, N, K):
     _close(got, ref, atol=float(ref.abs().max()) * 2 ** -8, rtol=2 ** -7, what=f"gemm {mode} {M}x{N}x{K}")
 
 
+@pytest.mark.parametrize("mode,M,N,K", [
+    ("wgrad", 1280, 1280, 30000),     # the audio tower's q/k/v/o weight gradients: 25 tiles, ragged depth, 10 parts
+    ("wgrad", 520, 264, 2500),        # ragged everything; the last part is cut by the descriptor
+    ("wgrad", 1280, 5120, 30000),     # 100 tiles: 2 parts
+    ("fwd", 1024, 512, 4096),         # contraction-contiguous operands: 64 stages split evenly
+    ("dgrad", 1000, 776, 2048),
+])
+def test_gemm_split_k_matches_fp64_reference(mode, M, N, K, monkeypatch):
+    """Outputs of few tiles with a deep contraction run as tiles x parts units (tn_gemm_bf16_splitk: fp32 partial sums
+    through a workspace, summed with bias / accumulate by a second kernel) — same result as the unsplit kernel up to the
+    summation order, equal to fp64 rounded once."""
+    F = _f()
+    parts = F.split_k(M, N, K, mode == "wgrad", mode != "fwd")
+    assert parts > 1
+    g = torch.Generator().manual_seed(M + 3 * N + 7 * K)
+    r = lambda *sh: (torch.rand(*sh, generator=g) * 2 - 1).to(torch.bfloat16)
+    if mode == "fwd":
+        a, b = r(M, K), r(N, K)
+        ref, ak, bk = a.double() @ b.double().t(), False, False
+    elif mode == "dgrad":
+        a, b = r(M, K), r(K, N)
+        ref, ak, bk = a.double() @ b.double(), False, True
+    else:
+        a, b = r(K, M), r(K, N)
+        ref, ak, bk = a.double().t() @ b.double(), True, True
+    a, b = a.to(DEV), b.to(DEV)
+    got = F.gemm([(a, b)], ak, bk)
+    tol = dict(atol=float(ref.abs().max()) * 2 ** -8, rtol=2 ** -7)
+    _close(got, ref, **tol, what=f"split-k gemm {mode} {M}x{N}x{K} / {parts}")
+    monkeypatch.setattr(F, "SPLIT_K", False)
+    whole = F.gemm([(a, b)], ak, bk)
+    assert float((whole.float() - got.float()).abs().max()) <= float(ref.abs().max()) * 2 ** -7
+    monkeypatch.setattr(F, "SPLIT_K", True)
+    bias = r(N).to(DEV)
+    base = r(M, N).to(DEV)
+    out = base.clone()
+    F.gemm([(a, b)], ak, bk, bias=bias, out=out, accumulate=True)
+    _close(out, ref + bias.double().cpu() + base.double().cpu(), **tol, what="split-k bias + accumulate")
+    assert torch.equal(F.gemm([(a, b)], ak, bk), got)                      # deterministic
+
+
 def test_gemm_segments_accumulate_in_fp32_and_reject_bad_shapes():
     """dX = dQ Wq + dK Wk + dV Wv as ONE launch (three segments of different depth and row pitch) and dW over two token
     ranges: equal to the fp64 sum rounded once — better than three bf16 round trips through C."""

@@ -526,3 +526,16 @@ def test_flat_engine_with_a_branch_that_takes_no_part_in_the_step():
     for r in range(world):
         assert results[r][0] == "ok", results[r][1]
     assert "block.1.0" in results[0][2]                                       # the mimo block has a bucket of its own
+
+
+def test_split_k_plan_of_the_hand_written_gemm():
+    """functional.split_k: parts only for outputs of at most half the CUs' worth of tiles with >= 16 stages; tiles x parts
+    <= 256; >= 8 stages per part; contraction-contiguous operands need an even split."""
+    import touchnet_amd.functional as F
+    assert F.split_k(1280, 1280, 30000, True, True) == 10            # 25 tiles: 250 units of 47 stages
+    assert F.split_k(1280, 5120, 30000, True, True) == 2
+    assert F.split_k(4096, 4096, 16384, True, True) == 1             # 256 tiles already
+    assert F.split_k(1280, 1280, 512, True, True) == 1               # too shallow
+    assert F.split_k(1024, 512, 4096, False, False) == 8             # 8 tiles, 64 stages: min(32, 8) parts, even
+    assert F.split_k(1024, 512, 4096 + 64 * 3, False, False) == 1    # 67 stages (prime): no even split
+    assert F.split_k(1000, 776, 2048, False, True) == 4

@@ -74,6 +74,11 @@ struct Params {
   int accumulate;      // C += result
   int nbm, nbn;
   int stages;          // sum over segments of K / 64
+  // split-K (outputs of few tiles with a deep contraction: the tower's 1280 x 1280 weight gradients over 30000 frames are
+  // 25 tiles for 256 CUs): unit u = (split u / tiles, tile u % tiles) contracts stages [split * kchunk, (split+1) * kchunk)
+  // of the ONE segment and leaves fp32 partial sums in ws[split][M][N]; splitk_reduce_kernel adds them up
+  int splitk, kchunk;
+  float* ws;
 };
 
 // XCD-aware, bijective workgroup -> tile map
@@ -201,7 +206,7 @@ __device__ __forceinline__ u32x4_t ds_b128(uint32_t addr) {
   return r;
 }
 
-template <bool AK, bool BK, int PLACE, int ASYM, int ILV, bool HAS_CT>
+template <bool AK, bool BK, int PLACE, int ASYM, int ILV, bool HAS_CT, bool SPLITK = false>
 struct Kernel {
   // ---- per-lane LDS read offsets ------------------------------------------------------------------------------------------
   //  ROW : xr[q] = (row0 + l31) * 128 + (((2 q + hi) ^ ((l31 >> 1) & 7)) << 4); block b at + b * 4096
@@ -277,13 +282,16 @@ struct Kernel {
     // persistent: workgroup b of G owns tiles b, b + G, b + 2 G, ... of the XCD-aware order (G is a multiple of 8 or
     // the grid covers every tile at once, so a workgroup's tiles stay on its XCD)
     const int bid = blockIdx.x, G = gridDim.x;
-    const int mine = (p.nbm * p.nbn - bid + G - 1) / G;
+    const int tiles = p.nbm * p.nbn;
+    const int mine = ((SPLITK ? tiles * p.splitk : tiles) - bid + G - 1) / G;
     auto origin = [&](int k, int& m0, int& n0) {
-      int tm, tn;
-      tile_of_block(bid + k * G, p.nbm, p.nbn, tm, tn);
+      int tm, tn, u = bid + k * G;
+      if constexpr (SPLITK) u -= (u / tiles) * tiles;
+      tile_of_block(u, p.nbm, p.nbn, tm, tn);
       m0 = tm * BM;
       n0 = tn * BN;
     };
+    auto split_of = [&](int k) { return (bid + k * G) / tiles; };
 
     Stream<AK> sA;
     Stream<BK> sB;
@@ -291,13 +299,31 @@ struct Kernel {
     auto open_a = [&](int s) {
       int m0, n0;
       origin(ka, m0, n0);
-      sA.open(p.seg[s].A, p.seg[s].lda, p.seg[s].K, p.M, m0, wave, lane);
+      if constexpr (SPLITK) {
+        // the unit's share of the contraction: `kchunk` stages from k0 on (a share that starts behind K reads nothing;
+        // one that crosses K is cut by the descriptor — contraction-major operands only, the host sees to that)
+        const int k0 = split_of(ka) * p.kchunk * 64, klen = min(p.seg[0].K - k0, p.kchunk * 64);
+        if (klen > 0) sA.open(p.seg[0].A + (AK ? (long long)k0 * p.seg[0].lda : (long long)k0), p.seg[0].lda, klen, p.M,
+                              m0, wave, lane);
+        else sA.kill(p.C);
+        sA.left = p.kchunk;
+      } else {
+        sA.open(p.seg[s].A, p.seg[s].lda, p.seg[s].K, p.M, m0, wave, lane);
+      }
       sA.seg = s;
     };
     auto open_b = [&](int s) {
       int m0, n0;
       origin(kb, m0, n0);
-      sB.open(p.seg[s].B, p.seg[s].ldb, p.seg[s].K, p.N, n0, wave, lane);
+      if constexpr (SPLITK) {
+        const int k0 = split_of(kb) * p.kchunk * 64, klen = min(p.seg[0].K - k0, p.kchunk * 64);
+        if (klen > 0) sB.open(p.seg[0].B + (BK ? (long long)k0 * p.seg[0].ldb : (long long)k0), p.seg[0].ldb, klen, p.N,
+                              n0, wave, lane);
+        else sB.kill(p.C);
+        sB.left = p.kchunk;
+      } else {
+        sB.open(p.seg[s].B, p.seg[s].ldb, p.seg[s].K, p.N, n0, wave, lane);
+      }
       sB.seg = s;
     };
     auto adv_a = [&]() {
@@ -496,7 +522,7 @@ struct Kernel {
       sb = sb1;
     };
 
-    const int np = p.stages;
+    const int np = SPLITK ? p.kchunk : p.stages;
     for (int kc = 0; kc < mine; ++kc) {
       read_all(I0{}, sa, sb, ae, be);
       wait_frags(ae, be);
@@ -507,7 +533,9 @@ struct Kernel {
       // the two slots the last barrier freed (now pb / pa) are the park, then they take their deferred pieces.
       int m0, n0;
       origin(kc, m0, n0);
-      if constexpr (TN_GEMM_ABLATE != 4)
+      if constexpr (SPLITK)
+        epilogue_ws(p, acc, split_of(kc), m0 + wr * 128, n0 + wc * 64, lane);
+      else if constexpr (TN_GEMM_ABLATE != 4)
         epilogue(p, acc, smem + (wave < 4 ? pb : pa) * SLOT + (wave & 3) * 8192, m0 + wr * 128, n0 + wc * 64, lane);
       zero_acc();
       __builtin_amdgcn_s_waitcnt(0xc07f);               // my park reads are done ...
@@ -529,6 +557,27 @@ struct Kernel {
       else body<1>(p, smem);
     } else {
       body<0>(p, smem);
+    }
+  }
+
+  // Split-K epilogue: the fp32 accumulators go to this split's slab of the workspace as they are (a lane holds 4
+  // consecutive n of one m per register quad: 16-byte stores; the L2 merges the quads of a line before it is written back)
+  static __device__ __forceinline__ void epilogue_ws(const Params& p, Acc& acc, int split, int wm0, int wn0, int lane) {
+    const int l31 = lane & 31, hi = lane >> 5;
+    float* base = p.ws + (long long)split * p.M * p.N;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = wm0 + i * 32 + l31;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n = wn0 + j * 32 + 8 * g + 4 * hi;
+          if (m < p.M && n < p.N) {
+            const f32x4_t v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+            *reinterpret_cast<f32x4_t*>(base + (long long)m * p.N + n) = v;
+          }
+        }
     }
   }
 
@@ -627,10 +676,49 @@ struct Kernel {
   }
 };
 
-template <bool AK, bool BK, int PLACE, int ASYM, int ILV, bool HAS_CT>
+template <bool AK, bool BK, int PLACE, int ASYM, int ILV, bool HAS_CT, bool SPLITK = false>
 __global__ __launch_bounds__(NT, 2) void gemm_kernel(const Params p) {
   __shared__ __attribute__((aligned(1024))) char smem[LDS_BYTES];
-  Kernel<AK, BK, PLACE, ASYM, ILV, HAS_CT>::run(p, smem);
+  Kernel<AK, BK, PLACE, ASYM, ILV, HAS_CT, SPLITK>::run(p, smem);
+}
+
+// ws[S][M][N] fp32 partial sums -> C = bf16(sum_s ws[s] (+ bias) (+ C)); one thread per 8 consecutive columns
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int S, int M, int N,
+                                                            bf16_t* __restrict__ C, long long ldc,
+                                                            const bf16_t* __restrict__ bias, int accumulate) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int n8 = N >> 3;
+  if (idx >= (long long)M * n8) return;
+  const int m = (int)(idx / n8), n = (int)(idx % n8) * 8;
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const long long slab = (long long)M * N;
+  const float* src = ws + (long long)m * N + n;
+  for (int sp = 0; sp < S; ++sp) {
+    const float4 x = *reinterpret_cast<const float4*>(src + sp * slab);
+    const float4 y = *reinterpret_cast<const float4*>(src + sp * slab + 4);
+    a[0] += x.x; a[1] += x.y; a[2] += x.z; a[3] += x.w;
+    a[4] += y.x; a[5] += y.y; a[6] += y.z; a[7] += y.w;
+  }
+  bf16_t* dst = C + (long long)m * ldc + n;
+  if (bias != nullptr) {
+    Vec16<bf16_t> b;
+    float fb[8];
+    b.load(bias + n);
+    b.unpack(fb);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] += fb[e];
+  }
+  if (accumulate) {
+    Vec16<bf16_t> o;
+    float fo[8];
+    o.load(dst);
+    o.unpack(fo);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] += fo[e];
+  }
+  Vec16<bf16_t> out;
+  out.pack(a);
+  out.store(dst);
 }
 
 // =====================================================================================================================
@@ -709,6 +797,7 @@ struct Stream32 {
 
 template <bool AK, bool BK, int PLACE32, bool HAS_CT>
 struct Kernel32 {
+  static constexpr bool SPLITK = false;      // (split-K exists in the 64-deep-ring kernel only)
   template <bool KMAJ, int NB>
   struct Reader {
     int x[4];
@@ -747,13 +836,16 @@ struct Kernel32 {
     const int wr = wave >> 2, wc = wave & 3;
 
     const int bid = blockIdx.x, G = gridDim.x;
-    const int mine = (p.nbm * p.nbn - bid + G - 1) / G;
+    const int tiles = p.nbm * p.nbn;
+    const int mine = ((SPLITK ? tiles * p.splitk : tiles) - bid + G - 1) / G;
     auto origin = [&](int k, int& m0, int& n0) {
-      int tm, tn;
-      tile_of_block(bid + k * G, p.nbm, p.nbn, tm, tn);
+      int tm, tn, u = bid + k * G;
+      if constexpr (SPLITK) u -= (u / tiles) * tiles;
+      tile_of_block(u, p.nbm, p.nbn, tm, tn);
       m0 = tm * BM;
       n0 = tn * BN;
     };
+    auto split_of = [&](int k) { return (bid + k * G) / tiles; };
 
     Stream32<AK> sA;
     Stream32<BK> sB;
@@ -761,13 +853,31 @@ struct Kernel32 {
     auto open_a = [&](int s) {
       int m0, n0;
       origin(ka, m0, n0);
-      sA.open(p.seg[s].A, p.seg[s].lda, p.seg[s].K, p.M, m0, wave, lane);
+      if constexpr (SPLITK) {
+        // the unit's share of the contraction: `kchunk` stages from k0 on (a share that starts behind K reads nothing;
+        // one that crosses K is cut by the descriptor — contraction-major operands only, the host sees to that)
+        const int k0 = split_of(ka) * p.kchunk * 64, klen = min(p.seg[0].K - k0, p.kchunk * 64);
+        if (klen > 0) sA.open(p.seg[0].A + (AK ? (long long)k0 * p.seg[0].lda : (long long)k0), p.seg[0].lda, klen, p.M,
+                              m0, wave, lane);
+        else sA.kill(p.C);
+        sA.left = p.kchunk;
+      } else {
+        sA.open(p.seg[s].A, p.seg[s].lda, p.seg[s].K, p.M, m0, wave, lane);
+      }
       sA.seg = s;
     };
     auto open_b = [&](int s) {
       int m0, n0;
       origin(kb, m0, n0);
-      sB.open(p.seg[s].B, p.seg[s].ldb, p.seg[s].K, p.N, n0, wave, lane);
+      if constexpr (SPLITK) {
+        const int k0 = split_of(kb) * p.kchunk * 64, klen = min(p.seg[0].K - k0, p.kchunk * 64);
+        if (klen > 0) sB.open(p.seg[0].B + (BK ? (long long)k0 * p.seg[0].ldb : (long long)k0), p.seg[0].ldb, klen, p.N,
+                              n0, wave, lane);
+        else sB.kill(p.C);
+        sB.left = p.kchunk;
+      } else {
+        sB.open(p.seg[s].B, p.seg[s].ldb, p.seg[s].K, p.N, n0, wave, lane);
+      }
       sB.seg = s;
     };
     auto adv_a = [&]() {
@@ -1190,6 +1300,7 @@ struct Stream4 {
 // stage, A over the second); 2 -> behind MFMA 2 p + (W >> 1) (waves 0/1 and 2/3 share a slot; everything in the first half)
 template <bool AK, bool BK, int DENS, bool HAS_CT>
 struct Kernel4 {
+  static constexpr bool SPLITK = false;
   // Every LDS read of this kernel is inline asm: with plain loads hipcc's waitcnt pass cannot tell the ring's slots apart
   // and puts `s_waitcnt vmcnt(5)` in front of some fragment reads ("a pending LDS-DMA may alias this load"), which
   // drains the DMA queue twice per stage — and with one wave per SIMD nothing covers that.  The reads are retired by
@@ -1277,13 +1388,16 @@ struct Kernel4 {
     const unsigned long long t_start = (TN_GEMM_ABL4 & 32) ? __builtin_amdgcn_s_memtime() : 0ull;
 
     const int bid = blockIdx.x, G = gridDim.x;
-    const int mine = (p.nbm * p.nbn - bid + G - 1) / G;
+    const int tiles = p.nbm * p.nbn;
+    const int mine = ((SPLITK ? tiles * p.splitk : tiles) - bid + G - 1) / G;
     auto origin = [&](int k, int& m0, int& n0) {
-      int tm, tn;
-      tile_of_block(bid + k * G, p.nbm, p.nbn, tm, tn);
+      int tm, tn, u = bid + k * G;
+      if constexpr (SPLITK) u -= (u / tiles) * tiles;
+      tile_of_block(u, p.nbm, p.nbn, tm, tn);
       m0 = tm * BM;
       n0 = tn * BN;
     };
+    auto split_of = [&](int k) { return (bid + k * G) / tiles; };
 
     Stream4<AK> sA;
     Stream4<BK> sB;
@@ -1291,13 +1405,31 @@ struct Kernel4 {
     auto open_a = [&](int s) {
       int m0, n0;
       origin(ka, m0, n0);
-      sA.open(p.seg[s].A, p.seg[s].lda, p.seg[s].K, p.M, m0, wave, lane);
+      if constexpr (SPLITK) {
+        // the unit's share of the contraction: `kchunk` stages from k0 on (a share that starts behind K reads nothing;
+        // one that crosses K is cut by the descriptor — contraction-major operands only, the host sees to that)
+        const int k0 = split_of(ka) * p.kchunk * 64, klen = min(p.seg[0].K - k0, p.kchunk * 64);
+        if (klen > 0) sA.open(p.seg[0].A + (AK ? (long long)k0 * p.seg[0].lda : (long long)k0), p.seg[0].lda, klen, p.M,
+                              m0, wave, lane);
+        else sA.kill(p.C);
+        sA.left = p.kchunk;
+      } else {
+        sA.open(p.seg[s].A, p.seg[s].lda, p.seg[s].K, p.M, m0, wave, lane);
+      }
       sA.seg = s;
     };
     auto open_b = [&](int s) {
       int m0, n0;
       origin(kb, m0, n0);
-      sB.open(p.seg[s].B, p.seg[s].ldb, p.seg[s].K, p.N, n0, wave, lane);
+      if constexpr (SPLITK) {
+        const int k0 = split_of(kb) * p.kchunk * 64, klen = min(p.seg[0].K - k0, p.kchunk * 64);
+        if (klen > 0) sB.open(p.seg[0].B + (BK ? (long long)k0 * p.seg[0].ldb : (long long)k0), p.seg[0].ldb, klen, p.N,
+                              n0, wave, lane);
+        else sB.kill(p.C);
+        sB.left = p.kchunk;
+      } else {
+        sB.open(p.seg[s].B, p.seg[s].ldb, p.seg[s].K, p.N, n0, wave, lane);
+      }
       sB.seg = s;
     };
     auto adv_a = [&]() {
@@ -1615,7 +1747,18 @@ static int launch_variant(int variant, dim3 grid, hipStream_t st, Params p) {
     hipLaunchKernelGGL((gemm32_kernel<AK, BK, TN_GEMM_DEFAULT_VARIANT - 1000, HAS_CT>), grid, dim3(NT), 0, st, p);
   else {
     p.stages = stages64;
-    hipLaunchKernelGGL((gemm_kernel<AK, BK, DPL, DAS, DIL, HAS_CT>), grid, dim3(NT), 0, st, p);
+    if (p.splitk > 1) {
+      if constexpr (!HAS_CT) {
+        hipLaunchKernelGGL((gemm_kernel<AK, BK, DPL, DAS, DIL, false, true>), grid, dim3(NT), 0, st, p);
+        const long long n8 = (long long)p.M * (p.N / 8);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, st, p.ws, p.splitk,
+                           p.M, p.N, p.C, p.ldc, p.bias, p.accumulate);
+      } else {
+        return -1;
+      }
+    } else {
+      hipLaunchKernelGGL((gemm_kernel<AK, BK, DPL, DAS, DIL, HAS_CT>), grid, dim3(NT), 0, st, p);
+    }
   }
   return 0;
 #undef TN_V
@@ -1633,9 +1776,10 @@ extern "C" {
 //   A, B, lda, ldb, K: arrays of nseg (1..3) entries.
 // Requirements (else -22): every K % 64 == 0 (any K when both operands are contraction-major), N % 8 == 0, ld % 8 == 0, 16-byte aligned bases; KMAJ operands span
 // < 2 GB ((K-1) * ld + rows) * 2 bytes); with Ct: M % 8 == 0, ldct % 8 == 0.
-int tn_gemm_bf16(const void* const* A, const void* const* B, const long long* lda, const long long* ldb, const int* K,
-                 int nseg, int a_kmaj, int b_kmaj, void* C, void* Ct, const void* bias, int M, int N, long long ldc,
-                 long long ldct, int accumulate, void* stream) {
+static int gemm_launch(const void* const* A, const void* const* B, const long long* lda, const long long* ldb,
+                       const int* K, int nseg, int a_kmaj, int b_kmaj, void* C, void* Ct, const void* bias, int M, int N,
+                       long long ldc, long long ldct, int accumulate, int splitk, void* workspace,
+                       long long workspace_bytes, void* stream) {
   using namespace tn::gemm;
   if (M <= 0 || N <= 0 || nseg < 1 || nseg > MAXSEG || (N % 8) != 0) return TN_EINVAL;
   if ((ldc % 8) || ldc < N || ((uintptr_t)C & 15)) return TN_EINVAL;
@@ -1681,6 +1825,21 @@ int tn_gemm_bf16(const void* const* A, const void* const* B, const long long* ld
   p.accumulate = accumulate;
   p.nbm = (M + BM - 1) / BM;
   p.nbn = (N + BN - 1) / BN;
+  p.splitk = 1;
+  p.kchunk = 0;
+  p.ws = nullptr;
+  if (splitk > 1) {
+    // one segment, no transposed copy; a contraction-contiguous operand cannot be cut inside a stage or read behind K
+    if (nseg != 1 || Ct != nullptr || TN_GEMM_DEFAULT_VARIANT >= 1000 || getenv("TN_GEMM_VARIANT") != nullptr)
+      return TN_EINVAL;
+    if (!(a_kmaj && b_kmaj) && (p.stages % splitk) != 0) return TN_EINVAL;
+    if (workspace == nullptr || ((uintptr_t)workspace & 15) ||
+        workspace_bytes < (long long)splitk * M * N * (long long)sizeof(float))
+      return TN_EINVAL;
+    p.splitk = splitk;
+    p.kchunk = (p.stages + splitk - 1) / splitk;
+    p.ws = (float*)workspace;
+  }
   // persistent: one workgroup per CU walks its tiles (TN_GEMM_PERSIST=0: one workgroup per tile, kernel-development A/B)
   static const int ncu = [] {
     int dev = 0, n = 256;
@@ -1689,7 +1848,7 @@ int tn_gemm_bf16(const void* const* A, const void* const* B, const long long* ld
   }();
   const char* pe = getenv("TN_GEMM_PERSIST");
   const bool persist = pe ? atoi(pe) != 0 : true;
-  const int tiles = p.nbm * p.nbn;
+  const int tiles = p.nbm * p.nbn * p.splitk;
   const dim3 grid(persist && tiles > ncu ? ncu : tiles);
   hipStream_t st = (hipStream_t)stream;
   const char* e = getenv("TN_GEMM_VARIANT");     // kernel-development A/B switch (read per call: the sweep changes it)
@@ -1706,6 +1865,25 @@ int tn_gemm_bf16(const void* const* A, const void* const* B, const long long* ld
   if (rc != 0) return TN_EINVAL;
   TN_LAUNCH_CHECK();
   return TN_OK;
+}
+
+int tn_gemm_bf16(const void* const* A, const void* const* B, const long long* lda, const long long* ldb, const int* K,
+                 int nseg, int a_kmaj, int b_kmaj, void* C, void* Ct, const void* bias, int M, int N, long long ldc,
+                 long long ldct, int accumulate, void* stream) {
+  return gemm_launch(A, B, lda, ldb, K, nseg, a_kmaj, b_kmaj, C, Ct, bias, M, N, ldc, ldct, accumulate, 1, nullptr, 0,
+                     stream);
+}
+
+// The same product with the contraction cut into `splitk` parts that run as independent units (outputs of few 256 x 256
+// tiles with a deep contraction); fp32 partial sums go through `workspace` (>= splitk * M * N * 4 bytes, 16-byte aligned)
+// and a second kernel adds them up (+ bias, + C).  One segment, no transposed copy; with a contraction-contiguous operand
+// the number of 64-deep stages must be a multiple of splitk (else -22).
+int tn_gemm_bf16_splitk(const void* A, const void* B, long long lda, long long ldb, int K, int a_kmaj, int b_kmaj,
+                        void* C, const void* bias, int M, int N, long long ldc, int accumulate, int splitk,
+                        void* workspace, long long workspace_bytes, void* stream) {
+  if (splitk < 2) return TN_EINVAL;
+  return gemm_launch(&A, &B, &lda, &ldb, &K, 1, a_kmaj, b_kmaj, C, nullptr, bias, M, N, ldc, 0, accumulate, splitk,
+                     workspace, workspace_bytes, stream);
 }
 
 // C[M,N] = A[M,K] · B[N,K]^T (+ bias) (+ C if accumulate); optional transposed copy Ct[N,M]: the round-2 entry point,

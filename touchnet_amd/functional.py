@@ -393,18 +393,44 @@ def gemm(segs, a_kmaj: bool = False, b_kmaj: bool = False, bias: Optional[torch.
     if bias is not None:
         bias = _c(bias).to(torch.bfloat16)
     n = len(segs)
+    if not a0.is_cuda:
+        raise _C.KernelError("touchnet_amd kernels need device (HIP) tensors; got a CPU tensor")
+    split = split_k(M, N, Ks[0], a_kmaj, b_kmaj) if (n == 1 and out_t is None and SPLIT_K) else 1
+    if split > 1:
+        ws = torch.empty(split * M * N, dtype=torch.float32, device=a0.device)
+        _C.check(_C.lib().tn_gemm_bf16_splitk(_p(a0), _p(b0), a0.stride(0), b0.stride(0), Ks[0], int(a_kmaj), int(b_kmaj),
+                                              _p(out), _p(bias), M, N, out.stride(0), int(accumulate), split, _p(ws),
+                                              ws.numel() * 4, _cur()), "tn_gemm_bf16_splitk")
+        return out
     import ctypes as C
     Ap = (C.c_void_p * n)(*[a.data_ptr() for a, _ in segs])
     Bp = (C.c_void_p * n)(*[b.data_ptr() for _, b in segs])
     la = (C.c_longlong * n)(*[a.stride(0) for a, _ in segs])
     lb = (C.c_longlong * n)(*[b.stride(0) for _, b in segs])
     Kc = (C.c_int * n)(*Ks)
-    if not a0.is_cuda:
-        raise _C.KernelError("touchnet_amd kernels need device (HIP) tensors; got a CPU tensor")
     _C.check(_C.lib().tn_gemm_bf16(Ap, Bp, la, lb, Kc, n, int(a_kmaj), int(b_kmaj), _p(out), _p(out_t), _p(bias), M, N,
                                    out.stride(0), out_t.stride(0) if out_t is not None else 0, int(accumulate),
                                    _cur()), "tn_gemm_bf16")
     return out
+
+
+SPLIT_K = os.environ.get("TN_GEMM_SPLITK", "1") != "0"      # (A/B switch)
+_NUM_CU = 256
+
+
+def split_k(M: int, N: int, K: int, a_kmaj: bool, b_kmaj: bool) -> int:
+    """Parts the contraction of a single-segment product is cut into (1 = no split): outputs of fewer 256 x 256 tiles than
+    half the CUs, at least 8 stages (512 deep) per part, tiles x parts <= CUs; with a contraction-contiguous operand the
+    number of 64-deep stages has to divide evenly."""
+    tiles = ((M + 255) // 256) * ((N + 255) // 256)
+    stages = (K + 63) // 64
+    if tiles * 2 > _NUM_CU or stages < 16 or os.environ.get("TN_GEMM_VARIANT"):
+        return 1
+    s = min(_NUM_CU // tiles, stages // 8)
+    if not (a_kmaj and b_kmaj):
+        while s > 1 and stages % s:
+            s -= 1
+    return max(s, 1)
 
 
 def gemm_supported(M: int, N: int, Ks, a_kmaj: bool = False, b_kmaj: bool = False) -> bool:
@@ -438,8 +464,13 @@ _OWN_MIN_TILES = 96          # below this many 256 x 256 output tiles most CUs w
 
 def _own(M: int, N: int, Ks, a_kmaj: bool = False, b_kmaj: bool = False) -> bool:
     """The hand-written kernel takes this product (and is the configured choice)."""
-    return (LINEAR_GEMM == "own" and gemm_supported(M, N, Ks, a_kmaj, b_kmaj)
-            and ((M + 255) // 256) * ((N + 255) // 256) >= _OWN_MIN_TILES)
+    if not (LINEAR_GEMM == "own" and gemm_supported(M, N, Ks, a_kmaj, b_kmaj)):
+        return False
+    tiles = ((M + 255) // 256) * ((N + 255) // 256)
+    if tiles >= _OWN_MIN_TILES:
+        return True
+    # few tiles: taken when the contraction can be split over enough units to fill the chip
+    return SPLIT_K and len(Ks) == 1 and tiles * split_k(M, N, Ks[0], a_kmaj, b_kmaj) >= _OWN_MIN_TILES
 
 
 def _bf16_rows(*ts) -> bool:

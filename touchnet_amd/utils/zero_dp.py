@@ -103,6 +103,12 @@ class FlatShardedDataParallel:
         self.group = mesh.get_group()
         self.world, self.rank = dist.get_world_size(self.group), dist.get_rank(self.group)
         self.reduce_dtype = reduce_dtype
+        # One rank (TN_FORCE_FSDP=1 on a single GPU): reduce-scatter and all-gather are the identity, so the hooks write
+        # straight into the persistent gradient shard and no collective is issued — RCCL would run its generic one-rank
+        # kernel instead (oneRankReduce<PreMulSum>, measured 48.5 ms per step for 34 GB: 1.4 TB/s), which says nothing
+        # about what a rank pays at N > 1.  TN_DP_FORCE_COLLECTIVES=1 issues them anyway (the 1-rank RCCL test).
+        import os
+        self.identity = self.world == 1 and os.environ.get("TN_DP_FORCE_COLLECTIVES") != "1"
         params = [p for p in model.parameters() if p.requires_grad]
         self.device = params[0].device
         self.cuda = self.device.type == "cuda"
@@ -152,6 +158,10 @@ class FlatShardedDataParallel:
 
     # ------------------------------------------------------------------ gradients
     def _acquire(self, b: _Bucket) -> torch.Tensor:
+        if self.identity:
+            if b.gshard is None:
+                b.gshard = torch.zeros(b.S, dtype=self.reduce_dtype, device=self.device)
+            return b.gshard
         if b in self.rest:                               # open during the whole backward: a buffer of its own
             if b.stage is None:
                 b.stage = torch.zeros(b.total, dtype=self.reduce_dtype, device=self.device)
@@ -191,6 +201,9 @@ class FlatShardedDataParallel:
             self._launch(b)
 
     def _launch(self, b: _Bucket) -> None:
+        if self.identity:
+            b.launched = True
+            return
         if b.gshard is None:
             b.gshard = torch.empty(b.S, dtype=self.reduce_dtype, device=self.device)
         if self.cuda:
@@ -221,7 +234,7 @@ class FlatShardedDataParallel:
                 self._launch(b)
         for b in self.buckets:
             if b.launched:
-                if self.cuda:
+                if self.cuda and b.reduced is not None:
                     torch.cuda.current_stream().wait_event(b.reduced)
                 b.shard.grad = b.gshard
             else:
@@ -240,6 +253,8 @@ class FlatShardedDataParallel:
     def gather_params(self) -> None:
         """After the optimizer step (it rewrote this rank's slice of every flat buffer): all-gather the slices in the order
         the next forward needs them, on the side stream."""
+        if self.identity:
+            return
         order = self.rest + [b for b in self.buckets if b not in self.rest]
         if self.cuda:
             done = torch.cuda.Event()
