@@ -312,7 +312,7 @@ def executed_flops_per_gpu(wl: "Workload", trainer, layout: dict, lm_head_rows: 
     layer = H * Nh * D * 2 + 2 * H * Nkv * D + 3 * H * I
     fl = 6.0 * layer * L * rows / tp
     fl += 3.5 * 4.0 * D * (Nh / tp) * pairs * L
-    fl += 6.0 * c.vocab_size * H * lm_head_rows
+    fl += 6.0 * c.vocab_size * H * lm_head_rows / (tp if wl.job.training_enable_loss_parallel else 1)
     if hasattr(wl, "wav"):
         ac = wl.model_config.audio_config
         tower = sum(p.numel() for p in trainer.model.audio_tower.parameters())
@@ -438,6 +438,10 @@ def main():
     ap.add_argument("--emulate-rank", type=int, default=None,
                     help="with --gpus 1 and --cp N or --tp N: run rank r of the N-way group alone on one GPU")
     ap.add_argument("--ac", choices=("none", "full", "selective"), default="none", help="activation checkpointing mode")
+    ap.add_argument("--loss-parallel", action="store_true",
+                    help="with --tp: vocabulary-parallel lm_head + CE (the reference's enable_loss_parallel)")
+    ap.add_argument("--no-sequence-parallel", action="store_true",
+                    help="with --tp: keep the residual stream / norms replicated (all-reduce per block output)")
     ap.add_argument("--dp-engine", choices=("flat", "fsdp2"), default=None,
                     help="data parallelism for N > 1: flat (default) = utils/zero_dp.py, flat per-block buffers + sharded "
                          "optimizer state; fsdp2 = torch fully_shard as the reference applies it (TN_DP_ENGINE)")
@@ -492,6 +496,8 @@ def main():
     wl.job.training_activation_checkpoint_mode = args.ac
     if args.dp_engine:
         wl.job.training_dp_engine = args.dp_engine
+    wl.job.training_enable_loss_parallel = bool(args.loss_parallel and args.tp > 1)
+    wl.job.training_tp_sequence_parallel = not args.no_sequence_parallel
     if args.all_rows_lm_head and hasattr(wl, "tokens"):
         wl.tokens.pop("labelled_rows_max", None)
     if args.ce_chunk:
@@ -563,6 +569,10 @@ def main():
                                                       "chunks of the same shape and document ids).  `value` is this GPU's "
                                                       "share of the tokens per second, not a group measurement")}
                           if emu else {}),
+                       **({"tensor_parallel_plan": ("sequence parallel" if wl.job.training_tp_sequence_parallel else
+                                                    "replicated residual stream")
+                                                   + (" + vocabulary-parallel lm_head/CE" if wl.job.training_enable_loss_parallel
+                                                      else ", lm_head replicated")} if args.tp > 1 else {}),
                        "activation_checkpointing": args.ac,
                        "params": trainer.num_params, "flop_per_token": fpt,
                        "fused_linear_ce": wl.job.training_enable_fused_ce,

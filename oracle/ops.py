@@ -95,10 +95,32 @@ def packed_cross_entropy(pred, labels, sentence_lens, num_sentence, ignore_index
     return ps, torch.stack([ps.detach(), pt.detach(), acc.float(), nvalid])
 
 
+class _GatherVocab(torch.autograd.Function):
+    """all-gather of vocabulary-sharded logits along the last dim; the loss behind it is computed identically on every
+    rank, so the gradient of the local logits is the local slice of d(logits) (nothing to sum)"""
+
+    @staticmethod
+    def forward(ctx, x, group, rank, size):
+        import torch.distributed as dist
+        ctx.rank, ctx.v = rank, x.shape[-1]
+        parts = [torch.empty_like(x) for _ in range(size)]
+        dist.all_gather(parts, x.contiguous(), group=group)
+        return torch.cat(parts, dim=-1)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[..., ctx.rank * ctx.v:(ctx.rank + 1) * ctx.v].contiguous(), None, None, None
+
+
 def fused_linear_cross_entropy(hidden, weight, labels, sentence_lens, num_sentence, ignore_index=-100,
-                               chunk_tokens=16384, compact=False):
-    return packed_cross_entropy(torch.nn.functional.linear(hidden, weight), labels, sentence_lens, num_sentence,
-                                ignore_index)
+                               chunk_tokens=16384, compact=False, tp=None):
+    """`tp = (group, rank, size)`: `weight` is this rank's vocabulary shard (loss parallel,
+    touchnet/loss/cross_entropy.py:29-33 / parallelize_llama.py:177-186): the full logits are gathered and the plain
+    reference loss is evaluated on them; d(hidden) comes out as the partial sum over the local shard, like in the product."""
+    logits = torch.nn.functional.linear(hidden, weight)
+    if tp is not None:
+        logits = _GatherVocab.apply(logits, *tp)
+    return packed_cross_entropy(logits, labels, sentence_lens, num_sentence, ignore_index)
 
 
 def packed_attention_sharded(q_local, k_full, v_full, mask, shard, scale=None):

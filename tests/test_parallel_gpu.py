@@ -200,3 +200,75 @@ def test_flat_data_parallel_engine_over_a_single_rank_rccl_group_trains_like_the
     for a, b in zip(got, ref):
         assert abs(a - b) / abs(b) < tol, (got, ref)
     assert abs(norm - ref_norm) / ref_norm < max(tol, 1e-4), (norm, ref_norm)
+
+
+def _lp_worker(rank, world, port, ret):
+    """one of two processes on the SAME GPU (gloo carries the device tensors of the tiny statistics exchanges)"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    try:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import touchnet_amd.functional as F
+        g = torch.Generator().manual_seed(11)
+        n, H, V = 700, 256, 4096
+        h = (torch.randn(1, n, H, generator=g) * 0.5).bfloat16().to(DEV)
+        w = (torch.randn(V, H, generator=g) * 0.2).bfloat16().to(DEV)
+        labels = torch.randint(0, V, (1, n), generator=g)
+        labels[0, ::3] = -100
+        labels[0, 5] = V - 1
+        labels[0, 7] = V // 2                                        # first row of the second shard
+        sl = torch.randint(1, 9, (1, n), generator=g)
+        labels, sl = labels.to(DEV), sl.to(DEV)
+        # single-process truth on the full head
+        hf = h.clone().requires_grad_()
+        wf = w.clone().requires_grad_()
+        loss, stats = F.fused_linear_cross_entropy(hf, wf, labels, sl, 37, -100, 256)
+        loss.backward()
+        # this rank's vocabulary shard, three chunks, with and without the compact row selection
+        out = {}
+        for compact in (False, 512):
+            hl = h.clone().requires_grad_()
+            wl = w[rank * V // world:(rank + 1) * V // world].clone().requires_grad_()
+            l2, s2 = F.fused_linear_cross_entropy(hl, wl, labels, sl, 37, -100, 256, compact,
+                                                  tp=(dist.group.WORLD, rank, world))
+            l2.backward()
+            dh = hl.grad.float().clone()
+            dist.all_reduce(dh)                                      # (in the model: the sequence gather's reduce-scatter)
+            out[compact] = (abs(float(l2) - float(loss)) / abs(float(loss)),
+                            float((s2 - stats).abs().max()),
+                            float((dh - hf.grad.float()).abs().max()) / float(hf.grad.float().abs().max()),
+                            float((wl.grad.float() - wf.grad.float()[rank * V // world:(rank + 1) * V // world]).abs().max())
+                            / float(wf.grad.float().abs().max()))
+        ret[rank] = ("ok", out)
+    except Exception as e:
+        import traceback
+        ret[rank] = ("fail", traceback.format_exc(), repr(e))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_vocabulary_parallel_fused_lm_head_ce_on_the_hip_kernels_two_processes_one_gpu():
+    """Loss parallel through the product path (functional._FusedLinearCE with tp=): local logits + row statistics from the
+    unchanged CE kernels, max / sum-exp / target / argmax combined over the group, backward with the global log-sum-exp.
+    Two processes share the one GPU (their exchange goes over gloo); loss, statistics (incl. accuracy), d(hidden) summed
+    over the shards and each shard's d(weight) equal the single-process fused lm_head + CE."""
+    import socket
+
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        ret = mgr.dict()
+        procs = [ctx.Process(target=_lp_worker, args=(r, 2, port, ret)) for r in range(2)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(600)
+        results = dict(ret)
+    for r in range(2):
+        assert r in results and results[r][0] == "ok", results.get(r)
+        for compact, (e_loss, e_stats, e_dh, e_dw) in results[r][1].items():
+            assert e_loss < 1e-5 and e_stats < 1e-4, (r, compact, results[r][1])
+            assert e_dh < 2e-2 and e_dw < 2e-2, (r, compact, results[r][1])      # bf16 GEMMs of different shapes

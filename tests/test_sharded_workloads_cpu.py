@@ -297,7 +297,7 @@ def _tp_fsdp_batches(dp):
     return out
 
 
-def _tp_fsdp_worker(rank, world, port, ref_state, ref_grads, ref_losses, ret):
+def _tp_fsdp_worker(rank, world, port, ref_state, ref_grads, ref_losses, ret, loss_parallel=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
     import oracle.ops as oops
@@ -314,12 +314,13 @@ def _tp_fsdp_worker(rank, world, port, ref_state, ref_grads, ref_losses, ret):
         dp_rank, tp_rank = mesh["dp_shard"].get_local_rank(), mesh["tp"].get_local_rank()
         assert (dp_rank, tp_rank) == divmod(rank, tp)                   # tp innermost: neighbours share xGMI links
         job = TrainConfig(training_model_name="kimi_audio_mi355", training_enable_fused_ce=True,
-                          training_mixed_precision_param="float32")
+                          training_mixed_precision_param="float32", training_enable_loss_parallel=loss_parallel)
         with use_ops(oops):
             tr = Trainer(job, KimiAudioConfig(**KIMI_TINY), torch.device("cpu"), dp_mesh=mesh["dp"],
                          fsdp_mesh=mesh["dp_shard_cp"], tp_mesh=mesh["tp"], optimizer_factory=lambda ps: TorchAdamW(ps))
             sharded = tr.model._tn_tp["sharded_names"]
-            assert len(sharded) == 4 * 10
+            assert len(sharded) == 4 * 10 + (1 if loss_parallel else 0)
+            assert tr.model._tn_tp["sequence_parallel"] and len(tr.model._tn_tp["seq_partial_names"]) == 2 * 4 + 2
 
             def tp_part(name, full):
                 if name in sharded:
@@ -337,6 +338,8 @@ def _tp_fsdp_worker(rank, world, port, ref_state, ref_grads, ref_losses, ret):
             loss, _, _ = tr.forward_loss(data)
             assert float(loss) == pytest.approx(ref_losses[dp_rank], rel=1e-5, abs=1e-6)
             loss.backward()
+            from touchnet_amd.models.tensor_parallel import reduce_sequence_partial_grads
+            reduce_sequence_partial_grads(tr.model)                       # (train_step does this behind the backward)
             worst = 0.0
             for name, p in tr.model.named_parameters():
                 if p.grad is None:
@@ -357,10 +360,12 @@ def _tp_fsdp_worker(rank, world, port, ref_state, ref_grads, ref_losses, ret):
             dist.destroy_process_group()
 
 
-def test_tensor_parallel_times_fsdp2_on_a_2d_mesh_of_four_ranks():
+@pytest.mark.parametrize("loss_parallel", [False, True])
+def test_tensor_parallel_times_fsdp2_on_a_2d_mesh_of_four_ranks(loss_parallel):
     """Config E's layout (TP x FSDP2, here 2 x 2 over gloo) through the Trainer and the reference's ParallelDims mesh:
     tp-local weights are FSDP2-sharded over the dp ranks, the loss of each dp rank equals the single-process one and the
-    dp-averaged gradients equal the tp slices of the single-process gradients."""
+    dp-averaged gradients equal the tp slices of the single-process gradients.  Sequence parallel (the Trainer's default
+    under TP), with and without the vocabulary-parallel head."""
     import oracle.ops as oops
     from touchnet_amd.models.backend import use_ops
     ref = _tp_model()
@@ -375,8 +380,8 @@ def test_tensor_parallel_times_fsdp2_on_a_2d_mesh_of_four_ranks():
     ref_grads = {n: p.grad.clone() for n, p in ref.named_parameters() if p.grad is not None}
     with mp.Manager() as mgr:
         ret = mgr.dict()
-        mp.spawn(_tp_fsdp_worker, args=(4, _free_port(), ref_state, ref_grads, [float(l) for l in losses], ret),
-                 nprocs=4, join=True)
+        mp.spawn(_tp_fsdp_worker, args=(4, _free_port(), ref_state, ref_grads, [float(l) for l in losses], ret,
+                                        loss_parallel), nprocs=4, join=True)
         results = dict(ret)
     for r in range(4):
         assert results[r][0] == "ok", results[r][1]

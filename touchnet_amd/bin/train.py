@@ -36,6 +36,8 @@ class TrainConfig:
     training_mixed_precision_param: str = "bfloat16"
     training_mixed_precision_reduce: str = "float32"
     training_fsdp_reshard_after_forward: str = "never"
+    training_tp_sequence_parallel: bool = True  # TP: norms / residual stream on T/tp rows per rank (the reference's plan)
+    training_enable_loss_parallel: bool = False  # TP: vocabulary-parallel lm_head + CE (touchnet/utils/distributed.py:318-323)
     training_dp_engine: str = "flat"           # data parallelism of THIS driver: "flat" = utils/zero_dp.py (flat per-block
                                                # buffers, sharded optimizer state), "fsdp2" = the reference's fully_shard
                                                # (always used under tensor parallelism and behind `parallelize_fn`)
@@ -129,7 +131,8 @@ class Trainer:
             # the hook is called the way the reference trainer calls it (train.py:259-261): meta model, the mesh
             # indexed by the reference's dimension names, ParallelDims, job config
             n = fsdp_mesh.size() if sharded else 1
-            dims = ParallelDims(dp_replicate=1, dp_shard=n, cp=1, tp=tp, pp=1, world_size=n * tp)
+            dims = ParallelDims(dp_replicate=1, dp_shard=n, cp=1, tp=tp, pp=1, world_size=n * tp,
+                                enable_loss_parallel=job.training_enable_loss_parallel)
             if sharded and n == 1:                                 # TN_FORCE_FSDP on one rank: still take the FSDP branch
                 dims = _ForceShard(dims)
             view = {"dp_shard_cp": fsdp_mesh}
@@ -253,6 +256,9 @@ class Trainer:
         # FSDP2's reduce-scatter then AVERAGES over dp, i.e. gradients are 1/dp of the global-batch mean
         # gradient.  We keep that scale for parity (AdamW is invariant to it, the clip threshold is not).
         loss.backward()
+        if self.tp_mesh is not None:
+            from touchnet_amd.models.tensor_parallel import reduce_sequence_partial_grads
+            reduce_sequence_partial_grads(self.model)    # norm weights saw T/tp rows: sum their gradients over tp
         if self.dp_engine is not None:
             self.dp_engine.finish_backward()     # reduce-scatters ran under the backward; shards go to the optimizer
         lr = self.job.lr_scheduler_lr * linear_warmup_linear_decay(

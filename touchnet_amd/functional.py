@@ -225,7 +225,14 @@ class _FusedLinearCE(torch.autograd.Function):
     gradient in backward."""
 
     @staticmethod
-    def forward(ctx, hidden, weight, labels, sentence_lens, num_sentence, ignore_index, chunk, compact=False):
+    def forward(ctx, hidden, weight, labels, sentence_lens, num_sentence, ignore_index, chunk, compact=False, tp=None):
+        """`tp = (group, rank, size)` — loss parallel (models/tensor_parallel.py): `weight` holds rows
+        [rank V/size, (rank+1) V/size) of the vocabulary.  Every chunk computes the LOCAL logits and row statistics with the
+        unchanged CE kernels (a label outside the shard is passed as V_local = "no local target": the forward kernel then
+        returns nll = lse_local, the backward kernel a pure softmax), combines max / sum-exp / target logit over the group
+        (three [rows] all-reduces) and back-propagates with the GLOBAL log-sum-exp.  d(hidden) is this rank's PARTIAL sum
+        over its vocabulary shard: the sequence gather in front of the head (`SequenceParallel.gather`, partial=True)
+        reduce-scatters it."""
         H = hidden.shape[-1]
         h2 = hidden.reshape(-1, H)
         lab = labels.reshape(-1).to(torch.int64).contiguous()
@@ -263,11 +270,38 @@ class _FusedLinearCE(torch.autograd.Function):
         dh = torch.empty_like(h2)
         dw = None
         parts = []
+        lab_k = lab                                        # the labels the kernels see
+        if tp is not None:
+            from touchnet_amd.models.tensor_parallel import tp_all_reduce
+            group, tp_rank, _ = tp
+            v0 = tp_rank * V
+            mine = (lab >= v0) & (lab < v0 + V)
+            lab_k = torch.where(lab == ignore_index, lab, torch.where(mine, lab - v0, torch.full_like(lab, V)))
         for s in range(0, n, chunk):
             e = min(s + chunk, n)
             logits = torch.nn.functional.linear(h2[s:e], weight)              # [c, V]: the only logits alive
-            nll_c, lse_c, hit_c = L.ce_fwd_rows(logits, lab[s:e], sl[s:e], ns, int(ignore_index))
-            L.ce_bwd_(logits, lab[s:e], sl[s:e], lse_c, ns, one, int(ignore_index))       # logits := dlogits
+            nll_c, lse_c, hit_c = L.ce_fwd_rows(logits, lab_k[s:e], sl[s:e], ns, int(ignore_index))
+            if tp is not None:
+                valid = lab[s:e] != ignore_index
+                target = lse_c - nll_c                                        # the target's logit where it is local, else 0
+                top_v, top_i = logits.float().max(dim=1)
+                mx = torch.where(valid, lse_c, torch.full_like(lse_c, float("-inf")))
+                tp_all_reduce(mx, group, torch.distributed.ReduceOp.MAX)
+                se = torch.where(valid, torch.exp(lse_c - mx), torch.zeros_like(lse_c))
+                tp_all_reduce(se, group)
+                tp_all_reduce(target, group)
+                lse_c = torch.where(valid, mx + torch.log(se), torch.zeros_like(lse_c))
+                nll_c = torch.where(valid, lse_c - target, torch.zeros_like(lse_c))
+                # accuracy: the argmax over ALL shards (first index on ties: lowest shard, then lowest index inside it)
+                best = torch.stack([top_v, (top_i + v0).float()], dim=1)                      # indices < 2^24: exact
+                if not getattr(group, "emulated", False):
+                    every = torch.empty((torch.distributed.get_world_size(group),) + tuple(best.shape),
+                                        dtype=best.dtype, device=best.device)
+                    torch.distributed.all_gather_into_tensor(every, best.contiguous(), group=group)
+                    win = every[..., 0].argmax(dim=0)
+                    best = every.gather(0, win[None, :, None].expand(1, -1, 2))[0]
+                hit_c = ((best[:, 1].to(torch.int64) == lab[s:e]) & valid).to(hit_c.dtype)
+            L.ce_bwd_(logits, lab_k[s:e], sl[s:e], lse_c, ns, one, int(ignore_index))     # logits := dlogits
             parts.append((nll_c, hit_c))
             torch.mm(logits, weight, out=dh[s:e])                             # dh = dlogits @ W
             if dw is None:
@@ -300,16 +334,16 @@ class _FusedLinearCE(torch.autograd.Function):
         # (same-dtype operands: a bf16 tensor times an fp32 0-dim DEVICE tensor takes TensorIterator's casting kernel,
         #  1.4 TB/s on the [V, H] weight gradient — 1.8 ms/step at V = 156 k; the upstream gradient is 1 or a power of two)
         return ((dh * g.to(dh.dtype)).view(ctx.hshape), (dw * g.to(dw.dtype)).to(ctx.wdtype), None, None, None, None, None,
-                None)
+                None, None)
 
 
 def fused_linear_cross_entropy(hidden, weight, labels, sentence_lens, num_sentence, ignore_index=-100,
-                               chunk_tokens=4096, compact=False):
+                               chunk_tokens=4096, compact=False, tp=None):
     """Returns ``(loss_per_sample [differentiable], stats)`` like packed_cross_entropy, from hidden states.
     ``compact``: run lm_head only on the labelled positions — an int upper bound from the data loader (no host sync)
-    or True (exact, one sync); see _FusedLinearCE.forward."""
+    or True (exact, one sync); ``tp``: vocabulary-parallel head (loss parallel); see _FusedLinearCE.forward."""
     return _FusedLinearCE.apply(hidden, weight, labels, sentence_lens, num_sentence, ignore_index, chunk_tokens,
-                                compact)
+                                compact, tp)
 
 
 # ------------------------------------------------------------------------------------ linear layers

@@ -42,9 +42,14 @@ def cached_accuracy(pred, labels):
 
 
 def fused_linear_cross_entropy(hidden, weight, labels, sentence_lens, num_sentence, ignore_index: int = -100,
-                               chunk_tokens: int = 4096, compact: bool = False):
+                               chunk_tokens: int = 4096, compact: bool = False, tp=None):
     """(loss_per_sample, loss_per_token, accuracy) straight from the final hidden states: lm_head GEMM +
-    packed CE chunked over tokens (touchnet_amd.functional.fused_linear_cross_entropy)."""
-    loss, stats = ops().fused_linear_cross_entropy(hidden, weight, labels, sentence_lens, num_sentence,
-                                                   ignore_index, chunk_tokens, compact)
+    packed CE chunked over tokens (touchnet_amd.functional.fused_linear_cross_entropy).  `tp = (group, rank, size)`: the
+    head is vocabulary-sharded over the tensor-parallel group (loss parallel, touchnet/loss/cross_entropy.py:29-33)."""
+    if tp is None:
+        loss, stats = ops().fused_linear_cross_entropy(hidden, weight, labels, sentence_lens, num_sentence,
+                                                       ignore_index, chunk_tokens, compact)
+    else:
+        loss, stats = ops().fused_linear_cross_entropy(hidden, weight, labels, sentence_lens, num_sentence,
+                                                       ignore_index, chunk_tokens, compact, tp=tp)
     return loss, stats[1], stats[2]

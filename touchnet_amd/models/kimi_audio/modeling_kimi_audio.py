@@ -64,19 +64,22 @@ class KimiDecoderModel(nn.Module):
             mask = ops().causal_mask(B, T, inputs_embeds.device)
         elif isinstance(mask, torch.Tensor):
             mask = ops().build_packed_mask(mask)
-        delta, residual = inputs_embeds, None
+        sp = getattr(self, "_tn_sp", None)                  # sequence parallelism (models/tensor_parallel.py)
+        delta, residual = (inputs_embeds if sp is None else sp.scatter(inputs_embeds)), None
         tap = None
         for idx, layer in enumerate(self.layers):
             delta, residual = layer(delta, residual, cos, sin, mask)
             if with_mimo and idx == self.config.kimia_mimo_transformer_from_layer_index:
                 tap = residual + delta               # the hidden state after this layer (`:506-507`)
         h, _ = self.norm(delta, residual)
+        h = h if sp is None else sp.gather(h)
         mimo = None
         if with_mimo:
             d, r = tap, None
             for layer in self.mimo_layers:
                 d, r = layer(d, r, cos, sin, mask)
             mimo, _ = self.mimo_norm(d, r)
+            mimo = mimo if sp is None else sp.gather(mimo)
         return h, mimo
 
 
@@ -120,8 +123,11 @@ class KimiAudioPackedForCausalLM(nn.Module):
         if labelled_rows_max is not None and ce_compact is not True:
             ce_compact = (int(labelled_rows_max) + 255) // 256 * 256
         if labels is None:
+            if getattr(self, "_tn_loss_parallel", None) is not None:
+                raise RuntimeError("loss parallel: the head is vocabulary-sharded, use the fused lm_head + CE (pass labels)")
             return SimpleNamespace(logits=self.lm_head(h), audio_logits=audio_logits, loss=None)
         from touchnet_amd.loss.cross_entropy import fused_linear_cross_entropy
+        lp = getattr(self, "_tn_loss_parallel", None)
         loss, per_token, acc = fused_linear_cross_entropy(h, self.lm_head.weight, labels, sentence_lens, num_sentence,
-                                                          chunk_tokens=ce_chunk_tokens, compact=ce_compact)
+                                                          chunk_tokens=ce_chunk_tokens, compact=ce_compact, tp=lp)
         return SimpleNamespace(logits=None, audio_logits=audio_logits, loss=loss, loss_per_token=per_token, acc=acc)

@@ -181,7 +181,12 @@ class DecoderModel(nn.Module):
             mask = ops().build_packed_mask(mask)
         if context_parallel is not None:
             mask.cp = context_parallel
-        delta, residual = inputs_embeds, None
+        # tensor parallelism with sequence parallelism (models/tensor_parallel.py): the residual stream is this rank's
+        # T/tp rows between the blocks; attention and MLP gather / reduce-scatter around their own bodies
+        sp = getattr(self, "_tn_sp", None)
+        if sp is not None and keep_rows is not None:
+            raise RuntimeError("keep_rows is not available under sequence parallelism")
+        delta, residual = (inputs_embeds if sp is None else sp.scatter(inputs_embeds)), None
         last = len(self.layers) - 1
         for i, layer in enumerate(self.layers):
             if keep_rows is not None and i == last:
@@ -189,7 +194,7 @@ class DecoderModel(nn.Module):
             else:
                 delta, residual = layer(delta, residual, cos, sin, mask)
         h, _ = self.norm(delta, residual)
-        return h
+        return h if sp is None else sp.gather(h)
 
 
 class PackedCausalLM(nn.Module):
@@ -267,7 +272,7 @@ class PackedCausalLM(nn.Module):
         with the per-sentence normalisation kept — and `.loss` / `.loss_per_token` / `.acc` are returned
         with `.logits = None`.  Being inside forward keeps lm_head under FSDP2's unshard/reshard hooks."""
         if (LAST_LAYER_LABELLED_ROWS and labels is not None and labelled_rows_max is not None and ce_compact is not True
-                and context_parallel is None and len(self.model.layers) > 1
+                and context_parallel is None and len(self.model.layers) > 1 and getattr(self.model, "_tn_sp", None) is None
                 and 2 * ((int(labelled_rows_max) + 255) // 256 * 256) <= labels.numel()):    # (pays for sparse labels only)
             return self._forward_labelled_rows(input_ids, inputs_embeds, position_ids, attention_mask, labels,
                                                sentence_lens, num_sentence, ce_chunk_tokens, int(labelled_rows_max))
@@ -289,9 +294,12 @@ class PackedCausalLM(nn.Module):
                                                               torch.ones_like(shift_labels), n_valid,
                                                               chunk_tokens=ce_chunk_tokens, compact=ce_compact)
             return SimpleNamespace(logits=None, loss=loss, loss_per_token=per_token, acc=acc)
+        lp = getattr(self, "_tn_loss_parallel", None)       # (group, rank, tp): lm_head holds V/tp rows of the vocabulary
         if labels is None:
+            if lp is not None:
+                raise RuntimeError("loss parallel: the head is vocabulary-sharded, use the fused lm_head + CE (pass labels)")
             return SimpleNamespace(logits=self.lm_head(h), loss=None)
         from touchnet_amd.loss.cross_entropy import fused_linear_cross_entropy
         loss, per_token, acc = fused_linear_cross_entropy(h, self.lm_head.weight, labels, sentence_lens, num_sentence,
-                                                          chunk_tokens=ce_chunk_tokens, compact=ce_compact)
+                                                          chunk_tokens=ce_chunk_tokens, compact=ce_compact, tp=lp)
         return SimpleNamespace(logits=None, loss=loss, loss_per_token=per_token, acc=acc)

@@ -75,7 +75,10 @@ def parallelize_packed(model: nn.Module, world_mesh, parallel_dims, job_config) 
         raise NotImplementedError("pipeline parallelism is outside the MI355X path (SURVEY §2.2)")
     if parallel_dims.tp_enabled:
         from touchnet_amd.models.tensor_parallel import apply_tp
-        apply_tp(model, world_mesh["tp"], loss_parallel=parallel_dims.loss_parallel_enabled)
+        # the reference's TP plan is sequence parallel throughout (parallelize_llama.py:133-176); loss parallel follows
+        # `enable_loss_parallel` (touchnet/utils/distributed.py:318-323)
+        apply_tp(model, world_mesh["tp"], loss_parallel=parallel_dims.loss_parallel_enabled,
+                 sequence_parallel=getattr(job_config, "training_tp_sequence_parallel", True))
     if getattr(job_config, "training_activation_checkpoint_mode", "none") != "none":
         apply_ac(model, job_config)
     if getattr(job_config, "training_compile", False):

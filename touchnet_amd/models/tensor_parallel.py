@@ -9,9 +9,20 @@ dispatch on the hot path):
   attention   q / k / v projections COLUMN-parallel by heads (rank r owns query heads [r Nh/tp, (r+1) Nh/tp) and the
               kv heads they read — GQA groups never straddle ranks), o_proj ROW-parallel over the same heads
   MLP         gate / up column-parallel, down row-parallel
-  per block   ONE all-reduce of the attention output and ONE of the MLP output in forward (xGMI, RCCL), their
-              mirrors (all-reduce of the input gradients) in backward; the residual stream, norms, embeddings and the
-              heads stay replicated over the tp ranks (no sequence parallelism in this first plan)
+  per block   without sequence parallelism: ONE all-reduce of the attention output and ONE of the MLP output in forward
+              (xGMI, RCCL), their mirrors (all-reduce of the input gradients) in backward; the residual stream, norms,
+              embeddings and the heads stay replicated over the tp ranks
+  sequence parallel (`sequence_parallel=True`; the reference's plan: embed Rowwise(out Shard(1)), norms SequenceParallel,
+              o/down Rowwise(out Shard(1)), parallelize_llama.py:133-176): the residual stream, the fused add+norm kernels
+              and the residual adds run on T/tp rows per rank; the all-reduce of a block output becomes a reduce-scatter
+              along the sequence and the input of a column-parallel region an all-gather (same bytes on the wire, 1/tp of
+              the norm / residual work and activation memory).  Norm weights see T/tp rows: their gradients are summed
+              over the tp group after the backward (`reduce_sequence_partial_grads`, ONE flat all-reduce).
+  loss parallel (`loss_parallel=True`; parallelize_llama.py:177-186 + touchnet/loss/cross_entropy.py:29-33): lm_head is
+              sharded over the VOCABULARY; the fused lm_head + CE computes local logits, combines the row statistics over
+              the tp group (max / sum-exp / target logit: three [rows] all-reduces per chunk) and back-propagates with the
+              GLOBAL log-sum-exp through the unchanged CE kernels (a label outside the local shard simply has no local
+              target); d(hidden) is summed over the group.
 
 FSDP2 then shards the (already tp-local) parameters over the `dp_shard_cp` mesh as usual.  The optimizer has to know
 which parameters are tp-sharded: their squared gradient norm is summed over the tp group, the replicated ones'
@@ -44,10 +55,108 @@ class EmulatedTPMesh:
         return self._rank
 
 
-def tp_all_reduce(t: torch.Tensor, group) -> None:
+def tp_all_reduce(t: torch.Tensor, group, op=None) -> None:
     if getattr(group, "emulated", False):
         return
-    dist.all_reduce(t, group=group)
+    dist.all_reduce(t, op=op or dist.ReduceOp.SUM, group=group)
+
+
+def _tp_size(group) -> int:
+    return group.size() if getattr(group, "emulated", False) else dist.get_world_size(group)
+
+
+def _tp_rank(group) -> int:
+    return group.get_local_rank() if getattr(group, "emulated", False) else dist.get_rank(group)
+
+
+def tp_all_gather_seq(x: torch.Tensor, group) -> torch.Tensor:
+    """[B, T/tp, ...] -> [B, T, ...] (rank r holds rows [r T/tp, (r+1) T/tp)).  An emulated rank tiles its own rows."""
+    tp = _tp_size(group)
+    if getattr(group, "emulated", False):
+        return x.repeat(1, tp, *([1] * (x.dim() - 2)))
+    x = x.contiguous()
+    out = torch.empty((tp * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)   # rank-major concatenation
+    dist.all_gather_into_tensor(out, x, group=group)
+    out = out.view((tp,) + tuple(x.shape))
+    if x.shape[0] == 1:
+        return out.view((1, tp * x.shape[1]) + tuple(x.shape[2:]))
+    return out.transpose(0, 1).reshape((x.shape[0], tp * x.shape[1]) + tuple(x.shape[2:]))
+
+
+def tp_reduce_scatter_seq(x: torch.Tensor, group) -> torch.Tensor:
+    """sum over the tp ranks of [B, T, ...], this rank keeps rows [r T/tp, (r+1) T/tp).  Emulated: the slice, unsummed."""
+    tp, r = _tp_size(group), _tp_rank(group)
+    B, T = x.shape[:2]
+    if T % tp:
+        raise ValueError(f"sequence length {T} is not divisible by tp = {tp}")
+    if getattr(group, "emulated", False):
+        return x.narrow(1, r * (T // tp), T // tp).contiguous()
+    parts = x.reshape((B, tp, T // tp) + tuple(x.shape[2:])).transpose(0, 1).contiguous()       # [tp, B, T/tp, ...]
+    out = torch.empty(parts.shape[1:], dtype=x.dtype, device=x.device)
+    dist.reduce_scatter_tensor(out, parts.view((tp * B,) + tuple(parts.shape[2:])), group=group)
+    return out
+
+
+class _GatherSeq(torch.autograd.Function):
+    """all-gather along the sequence; backward: `partial=True` -> reduce-scatter (what follows differs per rank: a
+    column-parallel region, a vocabulary-parallel head), False -> this rank's slice (what follows is replicated)"""
+
+    @staticmethod
+    def forward(ctx, x, group, partial):
+        ctx.group, ctx.partial = group, partial
+        return tp_all_gather_seq(x, group)
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.partial:
+            return tp_reduce_scatter_seq(g, ctx.group), None, None
+        tp, r = _tp_size(ctx.group), _tp_rank(ctx.group)
+        n = g.shape[1] // tp
+        return g.narrow(1, r * n, n).contiguous(), None, None
+
+
+class _ReduceScatterSeq(torch.autograd.Function):
+    """sum over the tp ranks + scatter along the sequence (output of a row-parallel region); backward: all-gather"""
+
+    @staticmethod
+    def forward(ctx, x, group):
+        ctx.group = group
+        return tp_reduce_scatter_seq(x, group)
+
+    @staticmethod
+    def backward(ctx, g):
+        return tp_all_gather_seq(g, ctx.group), None
+
+
+class _ScatterSeq(torch.autograd.Function):
+    """this rank's rows of a replicated [B, T, ...] tensor (the embedding output); backward: all-gather, so that what
+    produced the tensor — the replicated embedding — sees the gradient of every row on every rank"""
+
+    @staticmethod
+    def forward(ctx, x, group):
+        ctx.group = group
+        tp, r = _tp_size(group), _tp_rank(group)
+        if x.shape[1] % tp:
+            raise ValueError(f"sequence length {x.shape[1]} is not divisible by tp = {tp}")
+        n = x.shape[1] // tp
+        return x.narrow(1, r * n, n).contiguous()
+
+    @staticmethod
+    def backward(ctx, g):
+        return tp_all_gather_seq(g, ctx.group), None
+
+
+class SequenceParallel:
+    """What the decoder stacks consult (`model._tn_sp`): scatter behind the embedding, gather in front of the head."""
+
+    def __init__(self, group, loss_parallel: bool):
+        self.group, self.loss_parallel = group, loss_parallel
+
+    def scatter(self, x):
+        return _ScatterSeq.apply(x, self.group)
+
+    def gather(self, h):
+        return _GatherSeq.apply(h, self.group, self.loss_parallel)
 
 
 class _CopyToTP(torch.autograd.Function):
@@ -88,18 +197,36 @@ def _shard(param: nn.Parameter, dim: int, rank: int, tp: int) -> nn.Parameter:
     return nn.Parameter(local, requires_grad=param.requires_grad)
 
 
-def _wrap(module: nn.Module, group) -> None:
+def _wrap(module: nn.Module, group, sequence_parallel: bool = False) -> None:
     inner = module.forward
 
-    def forward(x, *args, **kwargs):
-        return _ReduceFromTP.apply(inner(_CopyToTP.apply(x, group), *args, **kwargs), group)
+    if sequence_parallel:
+        def forward(x, *args, **kwargs):
+            return _ReduceScatterSeq.apply(inner(_GatherSeq.apply(x, group, True), *args, **kwargs), group)
+    else:
+        def forward(x, *args, **kwargs):
+            return _ReduceFromTP.apply(inner(_CopyToTP.apply(x, group), *args, **kwargs), group)
     module.forward = forward
 
 
-def apply_tp(model: nn.Module, tp_mesh, loss_parallel: bool = False) -> nn.Module:
-    if loss_parallel:
-        raise NotImplementedError("loss parallel (vocabulary-sharded lm_head + CE) is not part of this TP plan")
+def _decoder_stacks(model: nn.Module):
+    """the modules that own an embedding -> layers -> final norm loop (DecoderModel / KimiDecoderModel)"""
+    lm = getattr(model, "language_model", model)
+    return [lm.model]
+
+
+def apply_tp(model: nn.Module, tp_mesh, loss_parallel: bool = False, sequence_parallel: bool = False) -> nn.Module:
     group, tp, rank = tp_mesh.get_group(), tp_mesh.size(), tp_mesh.get_local_rank()
+    lm = getattr(model, "language_model", model)
+    if loss_parallel:
+        if getattr(lm.config, "tie_word_embeddings", False):
+            raise NotImplementedError("loss parallel with tied embeddings: the embedding would have to be vocabulary-"
+                                      "parallel as well")
+        if lm.lm_head.weight.shape[0] % tp:
+            raise ValueError(f"vocabulary {lm.lm_head.weight.shape[0]} is not divisible by tp = {tp}")
+        if not sequence_parallel:
+            raise NotImplementedError("loss parallel is built on the sequence-parallel plan (as in the reference): pass "
+                                      "sequence_parallel=True")
     sharded = []
     for blocks in block_groups(model):
         for blk in blocks:
@@ -120,12 +247,48 @@ def apply_tp(model: nn.Module, tp_mesh, loss_parallel: bool = False) -> nn.Modul
                     sharded.append(lin.bias)
             attn.num_heads //= tp
             attn.num_kv_heads //= tp
-            _wrap(attn, group)
-            _wrap(mlp, group)
-    ids = {id(p) for p in sharded}
-    model._tn_tp = {"group": group, "size": tp, "rank": rank,
-                    "sharded_names": {n for n, p in model.named_parameters() if id(p) in ids}}
+            _wrap(attn, group, sequence_parallel)
+            _wrap(mlp, group, sequence_parallel)
+    seq_partial = []
+    if sequence_parallel:
+        for stack in _decoder_stacks(model):
+            stack._tn_sp = SequenceParallel(group, loss_parallel)
+            for m in stack.modules():                     # every norm of the stack runs on T/tp rows of the sequence
+                if type(m).__name__ == "RMSNorm":
+                    seq_partial.append(m.weight)
+    if loss_parallel:
+        lm.lm_head.weight = _shard(lm.lm_head.weight, 0, rank, tp)
+        sharded.append(lm.lm_head.weight)
+        lm._tn_loss_parallel = (group, rank, tp)
+    ids, pids = {id(p) for p in sharded}, {id(p) for p in seq_partial}
+    model._tn_tp = {"group": group, "size": tp, "rank": rank, "sequence_parallel": sequence_parallel,
+                    "loss_parallel": loss_parallel,
+                    "sharded_names": {n for n, p in model.named_parameters() if id(p) in ids},
+                    "seq_partial_names": {n for n, p in model.named_parameters() if id(p) in pids}}
     return model
+
+
+@torch.no_grad()
+def reduce_sequence_partial_grads(model: nn.Module) -> None:
+    """Sequence parallelism: a norm weight saw T/tp rows per rank, its gradient is the sum over the tp group.  ONE flat
+    all-reduce for all of them, after the backward (under FSDP2 on the local shards of the reduced gradients: the sum
+    commutes with the dp average)."""
+    info = getattr(model, "_tn_tp", None)
+    if not info or not info.get("seq_partial_names"):
+        return
+    grads = []
+    for n, p in model.named_parameters():
+        if n.replace("_checkpoint_wrapped_module.", "") in info["seq_partial_names"] and p.grad is not None:
+            g = p.grad
+            grads.append(g._local_tensor if hasattr(g, "_local_tensor") else g)
+    if not grads:
+        return
+    flat = torch.cat([g.reshape(-1).float() for g in grads])
+    tp_all_reduce(flat, info["group"])
+    off = 0
+    for g in grads:
+        g.copy_(flat[off:off + g.numel()].view_as(g))
+        off += g.numel()
 
 
 @torch.no_grad()
