@@ -295,9 +295,10 @@ class _FusedLinearCE(torch.autograd.Function):
                 # accuracy: the argmax over ALL shards (first index on ties: lowest shard, then lowest index inside it)
                 best = torch.stack([top_v, (top_i + v0).float()], dim=1)                      # indices < 2^24: exact
                 if not getattr(group, "emulated", False):
-                    every = torch.empty((torch.distributed.get_world_size(group),) + tuple(best.shape),
-                                        dtype=best.dtype, device=best.device)
+                    size = torch.distributed.get_world_size(group)
+                    every = torch.empty((size * best.shape[0], 2), dtype=best.dtype, device=best.device)
                     torch.distributed.all_gather_into_tensor(every, best.contiguous(), group=group)
+                    every = every.view(size, best.shape[0], 2)                                # rank-major
                     win = every[..., 0].argmax(dim=0)
                     best = every.gather(0, win[None, :, None].expand(1, -1, 2))[0]
                 hit_c = ((best[:, 1].to(torch.int64) == lab[s:e]) & valid).to(hit_c.dtype)
