@@ -311,7 +311,8 @@ def test_fsdp2_single_rank_rccl_matches_unsharded():
     if created:
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV, 0))
     try:
-        tr = Trainer(TrainConfig(**job), cfg, torch.device(DEV, 0), dp_mesh=build_dp_mesh("cuda", 1))
+        tr = Trainer(TrainConfig(**job, training_dp_engine="fsdp2"), cfg, torch.device(DEV, 0),
+                     dp_mesh=build_dp_mesh("cuda", 1))       # (the Trainer's own default is the flat engine: test_parallel_gpu.py)
         from torch.distributed.tensor import DTensor
         assert all(isinstance(p, DTensor) for p in tr.model.parameters()), "parameters are not sharded DTensors"
         with torch.no_grad():
