@@ -228,12 +228,15 @@ int tn_gemm_bf16(const void* const* A, const void* const* B, const long long* ld
                  int nseg, int a_kmaj, int b_kmaj, void* C, void* Ct, const void* bias, int M, int N, long long ldc,
                  long long ldct, int accumulate, void* stream);
 /*      The same product (one segment, no transposed copy) with the contraction cut into `splitk` >= 2 parts that run as
- *      independent units — for outputs of few 256 x 256 tiles with a deep contraction (the audio tower's 1280 x 1280 weight
- *      gradients contract 30000 frames: 25 tiles for 256 CUs).  fp32 partial sums travel through `workspace`
- *      (>= splitk * M * N * 4 bytes, 16-byte aligned); a second kernel adds them (+ bias, + C when accumulate).
- *      -22 additionally when an operand is contraction-contiguous and ceil(K / 64) % splitk != 0. */
+ *      independent units.  tail_only = 0: every tile is split — outputs of few 256 x 256 tiles with a deep contraction (the
+ *      audio tower's 1280 x 1280 weight gradients contract 30000 frames: 25 tiles for 256 CUs).  tail_only = 1: the whole
+ *      rounds of tiles run unsplit and only the last partial round is split (the MLP weight gradients are 688 tiles = 2
+ *      rounds + 176: cut in 4 the remainder costs 0.75 of a round instead of 1).  fp32 partial sums travel through
+ *      `workspace` (whole-tile slabs: >= splitk * split_tiles * 262144 bytes, 16-byte aligned); a second kernel adds them
+ *      (+ bias, + C when accumulate).  -22 additionally when an operand is contraction-contiguous and
+ *      ceil(K / 64) % splitk != 0, or tail_only without a whole round / without a remainder. */
 int tn_gemm_bf16_splitk(const void* A, const void* B, long long lda, long long ldb, int K, int a_kmaj, int b_kmaj,
-                        void* C, const void* bias, int M, int N, long long ldc, int accumulate, int splitk,
+                        void* C, const void* bias, int M, int N, long long ldc, int accumulate, int splitk, int tail_only,
                         void* workspace, long long workspace_bytes, void* stream);
 /*      Single segment, both operands contraction-contiguous (the round-2 entry point): */
 int tn_gemm_bf16_tn(const void* A, const void* B, void* C, void* Ct, const void* bias, int M, int N, int K,

@@ -1000,6 +1000,9 @@ def test_gemm_operand_modes_match_fp64_reference(mode, M, N, K):
     ("wgrad", 1280, 5120, 30000),     # 100 tiles: 2 parts
     ("fwd", 1024, 512, 4096),         # contraction-contiguous operands: 64 stages split evenly
     ("dgrad", 1000, 776, 2048),
+    ("wgrad", 11008, 4096, 2048),     # TAIL split: 688 tiles = 2 whole rounds unsplit + 176 tiles in 4 parts
+    ("fwd", 4360, 4104, 1024),        # 306 tiles = 1 round + 50 ragged-edge tiles in 2 parts
+    ("dgrad", 4360, 4104, 1024),
 ])
 def test_gemm_split_k_matches_fp64_reference(mode, M, N, K, monkeypatch):
     """Outputs of few tiles with a deep contraction run as tiles x parts units (tn_gemm_bf16_splitk: fp32 partial sums
@@ -1007,6 +1010,10 @@ def test_gemm_split_k_matches_fp64_reference(mode, M, N, K, monkeypatch):
     summation order, equal to fp64 rounded once."""
     F = _f()
     parts = F.split_k(M, N, K, mode == "wgrad", mode != "fwd")
+    if parts == 1:                                   # tail split: off by default (measured neutral), exercised here
+        monkeypatch.setattr(F, "TAIL_SPLIT", True)
+        parts = F.tail_split(M, N, K, mode == "wgrad", mode != "fwd")
+        assert ((M + 255) // 256) * ((N + 255) // 256) > 256
     assert parts > 1
     g = torch.Generator().manual_seed(M + 3 * N + 7 * K)
     r = lambda *sh: (torch.rand(*sh, generator=g) * 2 - 1).to(torch.bfloat16)

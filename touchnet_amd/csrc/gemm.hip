@@ -78,7 +78,11 @@ struct Params {
   // 25 tiles for 256 CUs): unit u = (split u / tiles, tile u % tiles) contracts stages [split * kchunk, (split+1) * kchunk)
   // of the ONE segment and leaves fp32 partial sums in ws[split][M][N]; splitk_reduce_kernel adds them up
   int splitk, kchunk;
-  float* ws;
+  float* ws;           // [splitk][ntiles][256 x 256] fp32, tile-local
+  // the linear tile ids (XCD-aware order, tile_of_block) this launch covers: all of them, or — "tail split" — the whole
+  // rounds [0, main) unsplit in one launch and the last partial round [main, tiles) split-K in a second one (688 tiles on
+  // 256 CUs are 2 rounds + 176 tiles: whole, the 176 take a third round at 69 % occupancy; cut in 4 they take 0.75)
+  int tile0, ntiles;
 };
 
 // XCD-aware, bijective workgroup -> tile map
@@ -282,12 +286,12 @@ struct Kernel {
     // persistent: workgroup b of G owns tiles b, b + G, b + 2 G, ... of the XCD-aware order (G is a multiple of 8 or
     // the grid covers every tile at once, so a workgroup's tiles stay on its XCD)
     const int bid = blockIdx.x, G = gridDim.x;
-    const int tiles = p.nbm * p.nbn;
+    const int tiles = p.ntiles;
     const int mine = ((SPLITK ? tiles * p.splitk : tiles) - bid + G - 1) / G;
     auto origin = [&](int k, int& m0, int& n0) {
       int tm, tn, u = bid + k * G;
       if constexpr (SPLITK) u -= (u / tiles) * tiles;
-      tile_of_block(u, p.nbm, p.nbn, tm, tn);
+      tile_of_block(p.tile0 + u, p.nbm, p.nbn, tm, tn);
       m0 = tm * BM;
       n0 = tn * BN;
     };
@@ -533,8 +537,10 @@ struct Kernel {
       // the two slots the last barrier freed (now pb / pa) are the park, then they take their deferred pieces.
       int m0, n0;
       origin(kc, m0, n0);
-      if constexpr (SPLITK)
-        epilogue_ws(p, acc, split_of(kc), m0 + wr * 128, n0 + wc * 64, lane);
+      if constexpr (SPLITK) {
+        const int u = bid + kc * G, sp = u / tiles;
+        epilogue_ws(p, acc, sp * tiles + (u - sp * tiles), wr * 128, wc * 64, lane);
+      }
       else if constexpr (TN_GEMM_ABLATE != 4)
         epilogue(p, acc, smem + (wave < 4 ? pb : pa) * SLOT + (wave & 3) * 8192, m0 + wr * 128, n0 + wc * 64, lane);
       zero_acc();
@@ -560,23 +566,22 @@ struct Kernel {
     }
   }
 
-  // Split-K epilogue: the fp32 accumulators go to this split's slab of the workspace as they are (a lane holds 4
-  // consecutive n of one m per register quad: 16-byte stores; the L2 merges the quads of a line before it is written back)
-  static __device__ __forceinline__ void epilogue_ws(const Params& p, Acc& acc, int split, int wm0, int wn0, int lane) {
+  // Split-K epilogue: the fp32 accumulators go to this unit's [256 x 256] slab of the workspace as they are (a lane holds 4
+  // consecutive n of one m per register quad: 16-byte stores; the L2 merges the quads of a line before it is written back).
+  // Slabs are whole tiles: no bounds checks here, the reduce kernel clips to M x N.
+  static __device__ __forceinline__ void epilogue_ws(const Params& p, Acc& acc, int slab, int lm0, int ln0, int lane) {
     const int l31 = lane & 31, hi = lane >> 5;
-    float* base = p.ws + (long long)split * p.M * p.N;
+    float* base = p.ws + (long long)slab * (BM * BN);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int m = wm0 + i * 32 + l31;
+      const int m = lm0 + i * 32 + l31;
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const int n = wn0 + j * 32 + 8 * g + 4 * hi;
-          if (m < p.M && n < p.N) {
-            const f32x4_t v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-            *reinterpret_cast<f32x4_t*>(base + (long long)m * p.N + n) = v;
-          }
+          const int n = ln0 + j * 32 + 8 * g + 4 * hi;
+          const f32x4_t v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+          *reinterpret_cast<f32x4_t*>(base + m * BN + n) = v;
         }
     }
   }
@@ -682,17 +687,22 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const Params p) {
   Kernel<AK, BK, PLACE, ASYM, ILV, HAS_CT, SPLITK>::run(p, smem);
 }
 
-// ws[S][M][N] fp32 partial sums -> C = bf16(sum_s ws[s] (+ bias) (+ C)); one thread per 8 consecutive columns
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int S, int M, int N,
-                                                            bf16_t* __restrict__ C, long long ldc,
-                                                            const bf16_t* __restrict__ bias, int accumulate) {
-  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-  const int n8 = N >> 3;
-  if (idx >= (long long)M * n8) return;
-  const int m = (int)(idx / n8), n = (int)(idx % n8) * 8;
+// ws[S][ntiles][256 x 256] fp32 partial sums -> C = bf16(sum_s ws[s] (+ bias) (+ C)) on the tiles [tile0, tile0 + ntiles);
+// 32 blocks of 256 threads per tile, one thread per 8 consecutive columns
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int S, int M, int N, int nbm,
+                                                            int nbn, int tile0, int ntiles, bf16_t* __restrict__ C,
+                                                            long long ldc, const bf16_t* __restrict__ bias,
+                                                            int accumulate) {
+  const int t = blockIdx.x >> 5, part = blockIdx.x & 31;
+  int tm, tn;
+  tile_of_block(tile0 + t, nbm, nbn, tm, tn);
+  const int idx = part * 256 + threadIdx.x;                 // 0 .. 8191: (row, 8-column group) of the tile
+  const int lm = idx >> 5, ln = (idx & 31) * 8;
+  const int m = tm * BM + lm, n = tn * BN + ln;
+  if (m >= M || n >= N) return;
   float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  const long long slab = (long long)M * N;
-  const float* src = ws + (long long)m * N + n;
+  const float* src = ws + (long long)t * (BM * BN) + lm * BN + ln;
+  const long long slab = (long long)ntiles * (BM * BN);
   for (int sp = 0; sp < S; ++sp) {
     const float4 x = *reinterpret_cast<const float4*>(src + sp * slab);
     const float4 y = *reinterpret_cast<const float4*>(src + sp * slab + 4);
@@ -836,12 +846,12 @@ struct Kernel32 {
     const int wr = wave >> 2, wc = wave & 3;
 
     const int bid = blockIdx.x, G = gridDim.x;
-    const int tiles = p.nbm * p.nbn;
+    const int tiles = p.ntiles;
     const int mine = ((SPLITK ? tiles * p.splitk : tiles) - bid + G - 1) / G;
     auto origin = [&](int k, int& m0, int& n0) {
       int tm, tn, u = bid + k * G;
       if constexpr (SPLITK) u -= (u / tiles) * tiles;
-      tile_of_block(u, p.nbm, p.nbn, tm, tn);
+      tile_of_block(p.tile0 + u, p.nbm, p.nbn, tm, tn);
       m0 = tm * BM;
       n0 = tn * BN;
     };
@@ -1388,12 +1398,12 @@ struct Kernel4 {
     const unsigned long long t_start = (TN_GEMM_ABL4 & 32) ? __builtin_amdgcn_s_memtime() : 0ull;
 
     const int bid = blockIdx.x, G = gridDim.x;
-    const int tiles = p.nbm * p.nbn;
+    const int tiles = p.ntiles;
     const int mine = ((SPLITK ? tiles * p.splitk : tiles) - bid + G - 1) / G;
     auto origin = [&](int k, int& m0, int& n0) {
       int tm, tn, u = bid + k * G;
       if constexpr (SPLITK) u -= (u / tiles) * tiles;
-      tile_of_block(u, p.nbm, p.nbn, tm, tn);
+      tile_of_block(p.tile0 + u, p.nbm, p.nbn, tm, tn);
       m0 = tm * BM;
       n0 = tn * BN;
     };
@@ -1750,9 +1760,8 @@ static int launch_variant(int variant, dim3 grid, hipStream_t st, Params p) {
     if (p.splitk > 1) {
       if constexpr (!HAS_CT) {
         hipLaunchKernelGGL((gemm_kernel<AK, BK, DPL, DAS, DIL, false, true>), grid, dim3(NT), 0, st, p);
-        const long long n8 = (long long)p.M * (p.N / 8);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, st, p.ws, p.splitk,
-                           p.M, p.N, p.C, p.ldc, p.bias, p.accumulate);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)p.ntiles * 32u), dim3(256), 0, st, p.ws, p.splitk, p.M,
+                           p.N, p.nbm, p.nbn, p.tile0, p.ntiles, p.C, p.ldc, p.bias, p.accumulate);
       } else {
         return -1;
       }
@@ -1778,7 +1787,7 @@ extern "C" {
 // < 2 GB ((K-1) * ld + rows) * 2 bytes); with Ct: M % 8 == 0, ldct % 8 == 0.
 static int gemm_launch(const void* const* A, const void* const* B, const long long* lda, const long long* ldb,
                        const int* K, int nseg, int a_kmaj, int b_kmaj, void* C, void* Ct, const void* bias, int M, int N,
-                       long long ldc, long long ldct, int accumulate, int splitk, void* workspace,
+                       long long ldc, long long ldct, int accumulate, int splitk, int tail_only, void* workspace,
                        long long workspace_bytes, void* stream) {
   using namespace tn::gemm;
   if (M <= 0 || N <= 0 || nseg < 1 || nseg > MAXSEG || (N % 8) != 0) return TN_EINVAL;
@@ -1828,39 +1837,60 @@ static int gemm_launch(const void* const* A, const void* const* B, const long lo
   p.splitk = 1;
   p.kchunk = 0;
   p.ws = nullptr;
+  p.tile0 = 0;
+  p.ntiles = p.nbm * p.nbn;
+  // persistent: one workgroup per CU walks its tiles (TN_GEMM_PERSIST=0: one workgroup per tile, kernel-development A/B)
+  static const int ncu = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n >= 8 ? n / 8 * 8 : 8;
+  }();
+  int main_tiles = 0;                                // tail split: tiles [0, main_tiles) run unsplit first
   if (splitk > 1) {
     // one segment, no transposed copy; a contraction-contiguous operand cannot be cut inside a stage or read behind K
     if (nseg != 1 || Ct != nullptr || TN_GEMM_DEFAULT_VARIANT >= 1000 || getenv("TN_GEMM_VARIANT") != nullptr)
       return TN_EINVAL;
     if (!(a_kmaj && b_kmaj) && (p.stages % splitk) != 0) return TN_EINVAL;
+    if (tail_only) {
+      main_tiles = p.ntiles / ncu * ncu;
+      if (main_tiles <= 0 || main_tiles >= p.ntiles) return TN_EINVAL;
+    }
     if (workspace == nullptr || ((uintptr_t)workspace & 15) ||
-        workspace_bytes < (long long)splitk * M * N * (long long)sizeof(float))
+        workspace_bytes < (long long)splitk * (p.ntiles - main_tiles) * BM * BN * (long long)sizeof(float))
       return TN_EINVAL;
     p.splitk = splitk;
     p.kchunk = (p.stages + splitk - 1) / splitk;
     p.ws = (float*)workspace;
   }
-  // persistent: one workgroup per CU walks its tiles (TN_GEMM_PERSIST=0: one workgroup per tile, kernel-development A/B)
-  static const int ncu = [] {
-    int dev = 0, n = 256;
-    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-    return n >= 8 ? n / 8 * 8 : 8;
-  }();
   const char* pe = getenv("TN_GEMM_PERSIST");
   const bool persist = pe ? atoi(pe) != 0 : true;
-  const int tiles = p.nbm * p.nbn * p.splitk;
-  const dim3 grid(persist && tiles > ncu ? ncu : tiles);
   hipStream_t st = (hipStream_t)stream;
   const char* e = getenv("TN_GEMM_VARIANT");     // kernel-development A/B switch (read per call: the sweep changes it)
   const int variant = e ? atoi(e) : TN_GEMM_DEFAULT_VARIANT;
-  int rc;
-#define TN_MODE(AKM, BKM)                                                                  \
-  rc = (Ct != nullptr) ? launch_variant<AKM, BKM, true>(variant, grid, st, p)              \
-                       : launch_variant<AKM, BKM, false>(variant, grid, st, p)
-  if (!a_kmaj && !b_kmaj) TN_MODE(false, false);
-  else if (!a_kmaj && b_kmaj) TN_MODE(false, true);
-  else if (a_kmaj && b_kmaj) TN_MODE(true, true);
-  else return TN_EINVAL;                       // (A contraction-major with B contraction-contiguous: no caller)
+  int rc = 0;
+#define TN_MODE(AKM, BKM, GRID, PRM)                                                       \
+  rc |= (Ct != nullptr) ? launch_variant<AKM, BKM, true>(variant, GRID, st, PRM)           \
+                        : launch_variant<AKM, BKM, false>(variant, GRID, st, PRM)
+#define TN_LAUNCH(GRID, PRM)                                                               \
+  if (!a_kmaj && !b_kmaj) TN_MODE(false, false, GRID, PRM);                                \
+  else if (!a_kmaj && b_kmaj) TN_MODE(false, true, GRID, PRM);                             \
+  else if (a_kmaj && b_kmaj) TN_MODE(true, true, GRID, PRM);                               \
+  else return TN_EINVAL /* (A contraction-major with B contraction-contiguous: no caller) */
+  if (main_tiles > 0) {                          // whole rounds first, unsplit ...
+    Params pm = p;
+    pm.splitk = 1;
+    pm.ntiles = main_tiles;
+    const dim3 gm(ncu);
+    TN_LAUNCH(gm, pm);
+    p.tile0 = main_tiles;                        // ... then the last partial round, split
+    p.ntiles -= main_tiles;
+  }
+  {
+    const int units = p.ntiles * p.splitk;
+    const dim3 grid(persist && units > ncu ? ncu : units);
+    TN_LAUNCH(grid, p);
+  }
+#undef TN_LAUNCH
 #undef TN_MODE
   if (rc != 0) return TN_EINVAL;
   TN_LAUNCH_CHECK();
@@ -1870,20 +1900,22 @@ static int gemm_launch(const void* const* A, const void* const* B, const long lo
 int tn_gemm_bf16(const void* const* A, const void* const* B, const long long* lda, const long long* ldb, const int* K,
                  int nseg, int a_kmaj, int b_kmaj, void* C, void* Ct, const void* bias, int M, int N, long long ldc,
                  long long ldct, int accumulate, void* stream) {
-  return gemm_launch(A, B, lda, ldb, K, nseg, a_kmaj, b_kmaj, C, Ct, bias, M, N, ldc, ldct, accumulate, 1, nullptr, 0,
+  return gemm_launch(A, B, lda, ldb, K, nseg, a_kmaj, b_kmaj, C, Ct, bias, M, N, ldc, ldct, accumulate, 1, 0, nullptr, 0,
                      stream);
 }
 
-// The same product with the contraction cut into `splitk` parts that run as independent units (outputs of few 256 x 256
-// tiles with a deep contraction); fp32 partial sums go through `workspace` (>= splitk * M * N * 4 bytes, 16-byte aligned)
-// and a second kernel adds them up (+ bias, + C).  One segment, no transposed copy; with a contraction-contiguous operand
-// the number of 64-deep stages must be a multiple of splitk (else -22).
+// The same product with the contraction cut into `splitk` parts that run as independent units; fp32 partial sums go through
+// `workspace` (whole 256 x 256 tile slabs: >= splitk * tiles_split * 262144 bytes, 16-byte aligned) and a second kernel
+// adds them up (+ bias, + C).  tail_only = 0: every tile is split (outputs of few tiles with a deep contraction);
+// tail_only = 1: the whole rounds of tiles (floor(tiles / CUs) * CUs) run unsplit, only the last partial round is split
+// (tiles_split = tiles mod CUs; -22 when there is no whole round or no remainder).  One segment, no transposed copy; with a
+// contraction-contiguous operand the number of 64-deep stages must be a multiple of splitk (else -22).
 int tn_gemm_bf16_splitk(const void* A, const void* B, long long lda, long long ldb, int K, int a_kmaj, int b_kmaj,
-                        void* C, const void* bias, int M, int N, long long ldc, int accumulate, int splitk,
+                        void* C, const void* bias, int M, int N, long long ldc, int accumulate, int splitk, int tail_only,
                         void* workspace, long long workspace_bytes, void* stream) {
   if (splitk < 2) return TN_EINVAL;
   return gemm_launch(&A, &B, &lda, &ldb, &K, 1, a_kmaj, b_kmaj, C, nullptr, bias, M, N, ldc, 0, accumulate, splitk,
-                     workspace, workspace_bytes, stream);
+                     tail_only, workspace, workspace_bytes, stream);
 }
 
 // C[M,N] = A[M,K] · B[N,K]^T (+ bias) (+ C if accumulate); optional transposed copy Ct[N,M]: the round-2 entry point,
