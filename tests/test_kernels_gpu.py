@@ -1042,6 +1042,23 @@ def test_gemm_split_k_matches_fp64_reference(mode, M, N, K, monkeypatch):
     assert torch.equal(F.gemm([(a, b)], ak, bk), got)                      # deterministic
 
 
+@pytest.mark.parametrize("mode,M,N,K", [("fwd", 4360, 4104, 128), ("dgrad", 1000, 776, 1088), ("wgrad", 1280, 1280, 30000),
+                                        ("wgrad", 1280, 520, 3000)])
+def test_gemm_one_workgroup_per_tile_launch(mode, M, N, K, monkeypatch):
+    """TN_GEMM_PERSIST=0 (what the Trainer selects when collectives run beside the compute): grid = tiles (x split-K parts),
+    every workgroup handles exactly one unit — same results as the persistent launch, bit for bit."""
+    F = _f()
+    g = torch.Generator().manual_seed(M + N + K)
+    r = lambda *sh: (torch.rand(*sh, generator=g) * 2 - 1).to(torch.bfloat16).to(DEV)
+    a, b = (r(M, K), r(N, K)) if mode == "fwd" else (r(M, K), r(K, N)) if mode == "dgrad" else (r(K, M), r(K, N))
+    ak, bk = mode == "wgrad", mode != "fwd"
+    monkeypatch.delenv("TN_GEMM_PERSIST", raising=False)
+    persistent = F.gemm([(a, b)], ak, bk)
+    monkeypatch.setenv("TN_GEMM_PERSIST", "0")
+    per_tile = F.gemm([(a, b)], ak, bk)
+    assert torch.equal(persistent, per_tile)
+
+
 def test_gemm_segments_accumulate_in_fp32_and_reject_bad_shapes():
     """dX = dQ Wq + dK Wk + dV Wv as ONE launch (three segments of different depth and row pitch) and dW over two token
     ranges: equal to the fp64 sum rounded once — better than three bf16 round trips through C."""

@@ -272,3 +272,83 @@ def test_vocabulary_parallel_fused_lm_head_ce_on_the_hip_kernels_two_processes_o
         for compact, (e_loss, e_stats, e_dh, e_dw) in results[r][1].items():
             assert e_loss < 1e-5 and e_stats < 1e-4, (r, compact, results[r][1])
             assert e_dh < 2e-2 and e_dw < 2e-2, (r, compact, results[r][1])      # bf16 GEMMs of different shapes
+
+
+def _flat2_worker(rank, world, port, ref_losses, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0")
+    try:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import touchnet_amd.specs  # noqa: F401
+        from touchnet_amd.bin.train import TrainConfig, Trainer
+        from touchnet_amd.data.synthetic import text_batch
+        from touchnet_amd.models.llama import DecoderConfig
+        torch.cuda.set_device(0)
+
+        class mesh:                  # (a cuda DeviceMesh would create an RCCL group: two ranks cannot share one GPU there)
+            get_group = staticmethod(lambda: dist.group.WORLD)
+            size = staticmethod(lambda: world)
+        cfg = DecoderConfig.from_dict(dict(CFG, model_type="llama"))
+        job = TrainConfig(training_model_name="llama_mi355", training_enable_fused_ce=True, lr_scheduler_warmup_steps=0,
+                          lr_scheduler_lr=1e-3, training_dp_engine="flat", training_max_norm=1e9)
+        tr = Trainer(job, cfg, torch.device(DEV, 0), dp_mesh=mesh)
+        eng = tr.dp_engine
+        assert eng is not None and eng.world == 2 and not eng.identity and os.environ.get("TN_GEMM_PERSIST") == "0"
+        losses = []
+        for s in range(3):
+            b = text_batch(1024, 2, 512, seed=10 * s + rank, max_len=90)          # each rank its own rows
+            losses.append(float(tr.train_step(tr.next_batch(b))["loss_per_sample"]))
+        torch.cuda.synchronize()
+        # the replicas stay identical (every rank gathered the same updated slices)
+        flat = torch.cat([b.flat_p.float().reshape(-1)[:4096] for b in eng.buckets])
+        both = [torch.empty_like(flat) for _ in range(world)]
+        dist.all_gather(both, flat)
+        ret[rank] = ("ok", losses, bool(torch.equal(both[0], both[1])), len(eng._pool))
+    except Exception as e:
+        import traceback
+        ret[rank] = ("fail", traceback.format_exc(), repr(e))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_flat_engine_two_ranks_on_one_gpu_trains_like_one_process_on_the_joined_batch():
+    """World size 2 on the device (two processes share the GPU, gloo moves the device buffers): staging pool, side-stream
+    reduce-scatter (AVG) and in-place all-gather with REAL peers around the HIP kernels.  The per-rank losses equal those of
+    one unsharded process that sees both ranks' rows (B = 4 instead of 2 x 2): the same global num_sentence normalisation, the
+    dp-averaged gradient equals the joined batch's gradient / 2 — AdamW is invariant to that factor, the clip is not reached."""
+    import socket
+
+    import torch.multiprocessing as mp
+    import touchnet_amd.specs  # noqa: F401
+    from touchnet_amd.bin.train import TrainConfig, Trainer
+    from touchnet_amd.data.synthetic import text_batch
+    from touchnet_amd.models.llama import DecoderConfig
+    cfg = DecoderConfig.from_dict(dict(CFG, model_type="llama"))
+    job = TrainConfig(training_model_name="llama_mi355", training_enable_fused_ce=True, lr_scheduler_warmup_steps=0,
+                      lr_scheduler_lr=1e-3, training_max_norm=1e9)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        ret = mgr.dict()
+        procs = [ctx.Process(target=_flat2_worker, args=(r, 2, port, None, ret)) for r in range(2)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(900)
+        results = dict(ret)
+    for r in range(2):
+        assert r in results and results[r][0] == "ok", results.get(r)
+        assert results[r][2], "replicas diverged"
+        assert results[r][3] <= 3
+    # one process on the joined rows: its loss (sum over all sentences / global count) = sum of the ranks' loss parts
+    plain = Trainer(job, cfg, torch.device(DEV))
+    for s in range(3):
+        parts = [text_batch(1024, 2, 512, seed=10 * s + r, max_len=90) for r in range(2)]
+        joined = {k: (torch.cat([p[k] for p in parts]) if isinstance(parts[0][k], torch.Tensor)
+                      else sum(p[k] for p in parts) if isinstance(parts[0][k], int) else parts[0][k]) for k in parts[0]}
+        ref = float(plain.train_step(plain.next_batch(joined))["loss_per_sample"])
+        got = results[0][1][s] + results[1][1][s]
+        assert abs(got - ref) / abs(ref) < 3e-3, (s, got, ref)
