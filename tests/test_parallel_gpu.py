@@ -352,3 +352,144 @@ def test_flat_engine_two_ranks_on_one_gpu_trains_like_one_process_on_the_joined_
         ref = float(plain.train_step(plain.next_batch(joined))["loss_per_sample"])
         got = results[0][1][s] + results[1][1][s]
         assert abs(got - ref) / abs(ref) < 3e-3, (s, got, ref)
+
+
+def _cp2_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0")
+    try:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import touchnet_amd.specs  # noqa: F401
+        from touchnet_amd.bin.train import TrainConfig, Trainer
+        from touchnet_amd.data.synthetic import text_batch
+        from touchnet_amd.models.llama import DecoderConfig
+        torch.cuda.set_device(0)
+
+        class mesh:                  # (see _flat2_worker)
+            get_group = staticmethod(lambda: dist.group.WORLD)
+            size = staticmethod(lambda: world)
+        solo = [dist.new_group([r]) for r in range(world)][rank]      # dp = 1: `num_sentence` is summed over THIS group
+
+        class dp_mesh:
+            get_group = staticmethod(lambda: solo)
+            size = staticmethod(lambda: 1)
+        cfg = DecoderConfig.from_dict(dict(CFG, model_type="llama"))
+        job = TrainConfig(training_model_name="llama_mi355", training_enable_fused_ce=True, lr_scheduler_warmup_steps=0,
+                          lr_scheduler_lr=1e-3, training_dp_engine="flat", training_max_norm=1e9)
+        tr = Trainer(job, cfg, torch.device(DEV, 0), dp_mesh=dp_mesh, cp_mesh=mesh, fsdp_mesh=mesh)
+        losses, halo = [], 0
+        for s in range(3):
+            b = text_batch(1024, 1, 2048, seed=50 + s, min_len=200, max_len=700)      # the SAME rows on both cp ranks
+            data = tr.next_batch(b)
+            assert data["input_ids"].shape == (1, 1024) and data["attention_mask"].shape == (1, 2048)
+            losses.append(float(tr.train_step(data)["loss_per_sample"]))
+            halo = max(halo, tr.cp.halo_bytes)
+        torch.cuda.synchronize()
+        ret[rank] = ("ok", losses, halo)
+    except Exception as e:
+        import traceback
+        ret[rank] = ("fail", traceback.format_exc(), repr(e))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_context_parallel_two_ranks_on_one_gpu_trains_like_one_process():
+    """cp = 2 on the device with a REAL peer (two processes share the GPU; gloo carries the K/V chunks and the returned
+    dK/dV): zig-zag sequence shards, halo exchange issued before the query path, own-chunk attention, wait, received-chunk
+    attention, fp32 LSE merge, single segment backward, halo return, gradients reduced by the flat engine over the cp group.
+    The loss parts of the two ranks add up to the loss of ONE process on the whole sequence, three optimizer steps in a row."""
+    import socket
+
+    import torch.multiprocessing as mp
+    import touchnet_amd.specs  # noqa: F401
+    from touchnet_amd.bin.train import TrainConfig, Trainer
+    from touchnet_amd.data.synthetic import text_batch
+    from touchnet_amd.models.llama import DecoderConfig
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        ret = mgr.dict()
+        procs = [ctx.Process(target=_cp2_worker, args=(r, 2, port, ret)) for r in range(2)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(900)
+        results = dict(ret)
+    for r in range(2):
+        assert r in results and results[r][0] == "ok", results.get(r)
+    assert results[0][2] > 0 or results[1][2] > 0                      # documents cross the chunk boundaries: K/V really moved
+    cfg = DecoderConfig.from_dict(dict(CFG, model_type="llama"))
+    job = TrainConfig(training_model_name="llama_mi355", training_enable_fused_ce=True, lr_scheduler_warmup_steps=0,
+                      lr_scheduler_lr=1e-3, training_max_norm=1e9)
+    plain = Trainer(job, cfg, torch.device(DEV))
+    for s in range(3):
+        b = text_batch(1024, 1, 2048, seed=50 + s, min_len=200, max_len=700)
+        ref = float(plain.train_step(plain.next_batch(b))["loss_per_sample"])
+        got = results[0][1][s] + results[1][1][s]
+        assert abs(got - ref) / abs(ref) < 3e-3, (s, got, ref)
+
+
+def _tp2_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    try:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from touchnet_amd.models.tensor_parallel import apply_tp, reduce_sequence_partial_grads
+        torch.cuda.set_device(0)
+
+        class mesh:
+            get_group = staticmethod(lambda: dist.group.WORLD)
+            size = staticmethod(lambda: world)
+            get_local_rank = staticmethod(lambda: rank)
+        batch = _packed_batch(2, 1024, 1024, seed=8)
+        full = _model(seed=9)
+        loss0, g0 = _loss_and_grads(full, batch)
+        out = {}
+        for name, kw in (("plain", {}), ("sp", dict(sequence_parallel=True)),
+                         ("sp+lp", dict(sequence_parallel=True, loss_parallel=True))):
+            part = apply_tp(_model(seed=9), mesh, **kw)
+            loss1, _ = _loss_and_grads(part, batch)
+            reduce_sequence_partial_grads(part)
+            worst = 0.0
+            for n, p in part.named_parameters():
+                want = g0[n]
+                if p.shape != want.shape:
+                    want = want.chunk(world, dim=1 if ("o_proj" in n or "down_proj" in n) else 0)[rank]
+                worst = max(worst, _rel(p.grad, want))
+            out[name] = (abs(loss1 - loss0) / abs(loss0), worst, len(part._tn_tp["sharded_names"]))
+        ret[rank] = ("ok", out)
+    except Exception as e:
+        import traceback
+        ret[rank] = ("fail", traceback.format_exc(), repr(e))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_tensor_parallel_two_ranks_on_one_gpu_through_the_hip_kernels():
+    """tp = 2 with a REAL peer on the device (two processes share the GPU, gloo carries the all-reduces / sequence gathers /
+    reduce-scatters): replicated residual stream, sequence parallel, and sequence + loss parallel (vocabulary-sharded head in
+    the fused lm_head + CE) — loss and every gradient (shards against the matching slices) equal the unsharded model run by
+    the same process on the same kernels."""
+    import socket
+
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        ret = mgr.dict()
+        procs = [ctx.Process(target=_tp2_worker, args=(r, 2, port, ret)) for r in range(2)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(900)
+        results = dict(ret)
+    for r in range(2):
+        assert r in results and results[r][0] == "ok", results.get(r)
+        for name, (e_loss, e_grad, n_sharded) in results[r][1].items():
+            assert e_loss < 2e-3 and e_grad < 5e-2, (r, name, results[r][1])
+            assert n_sharded == 2 * 10 + (1 if name == "sp+lp" else 0)

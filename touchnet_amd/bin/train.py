@@ -194,7 +194,9 @@ class Trainer:
         ns = out["num_sentence"]
         ns = ns.to(self.device, torch.float32) if isinstance(ns, torch.Tensor) else torch.tensor(
             float(ns), dtype=torch.float32, device=self.device)
-        out["num_sentence"] = dist_sum(ns.reshape(1), self.dp_group)   # global over dp (train.py:339-343)
+        # global over the DATA-parallel ranks (train.py:339-343) — and over those only: the cp / tp peers of a rank hold the
+        # same rows (without a dp mesh there is nothing to sum, whatever other groups the process belongs to)
+        out["num_sentence"] = dist_sum(ns.reshape(1), self.dp_group) if self.dp_world > 1 else ns.reshape(1)
         if self.cp_group is not None or self.cp_emulate is not None:    # train.py:354-389: shard buffers on dim 1
             from touchnet_amd.utils.context_parallel import ContextParallel
             T = out["labels"].shape[1]
