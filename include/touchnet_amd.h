@@ -238,6 +238,14 @@ int tn_gemm_bf16(const void* const* A, const void* const* B, const long long* ld
 int tn_gemm_bf16_splitk(const void* A, const void* B, long long lda, long long ldb, int K, int a_kmaj, int b_kmaj,
                         void* C, const void* bias, int M, int N, long long ldc, int accumulate, int splitk, int tail_only,
                         void* workspace, long long workspace_bytes, void* stream);
+/*      Weight gradient with FP32 output — for a data-parallel engine that reduces gradients in fp32 (the reference's
+ *      MixedPrecisionPolicy(reduce_dtype=float32), touchnet/models/helper_func.py:165) and wants dW written straight into its
+ *      reduce-scatter input instead of cast-copied there: C[M,N] (float, ldc in floats) = (+= when accumulate)
+ *      A[K,M]^T . B[K,N], both operands contraction-major as stored (dY [tokens, M], x [tokens, N]).  splitk <= 1: one
+ *      launch; >= 2: split-K through `workspace` (>= splitk * tiles * 262144 bytes).  Same -22 rules as tn_gemm_bf16. */
+int tn_gemm_bf16_wgrad_f32(const void* A, const void* B, long long lda, long long ldb, int K, float* C, int M, int N,
+                           long long ldc, int accumulate, int splitk, void* workspace, long long workspace_bytes,
+                           void* stream);
 /*      Single segment, both operands contraction-contiguous (the round-2 entry point): */
 int tn_gemm_bf16_tn(const void* A, const void* B, void* C, void* Ct, const void* bias, int M, int N, int K,
                     long long lda, long long ldb, long long ldc, long long ldct, int accumulate, void* stream);

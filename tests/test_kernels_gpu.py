@@ -1059,6 +1059,31 @@ def test_gemm_one_workgroup_per_tile_launch(mode, M, N, K, monkeypatch):
     assert torch.equal(persistent, per_tile)
 
 
+@pytest.mark.parametrize("M,N,K", [(4096, 4104, 2048), (1280, 1280, 30000), (520, 264, 2500)])
+def test_gemm_weight_gradient_with_fp32_output(M, N, K):
+    """tn_gemm_bf16_wgrad_f32: dW = dY^T x written as fp32 (plain launch and split-K), overwrite and accumulate — the
+    accumulators unrounded: equal to the fp64 product to fp32 accuracy, far below a bf16 ulp."""
+    F = _f()
+    g = torch.Generator().manual_seed(M + N + K)
+    r = lambda *sh: (torch.rand(*sh, generator=g) * 2 - 1).to(torch.bfloat16)
+    a, b = r(K, M), r(K, N)
+    ref = a.double().t() @ b.double()
+    out = torch.full((M, N), 7.0, dtype=torch.float32, device=DEV)
+    F.gemm([(a.to(DEV), b.to(DEV))], True, True, out=out)
+    scale = float(ref.abs().max())
+    assert float((out.double().cpu() - ref).abs().max()) < scale * 2e-6 * (K ** 0.5), "fp32 weight gradient"
+    F.gemm([(a.to(DEV), b.to(DEV))], True, True, out=out, accumulate=True)
+    assert float((out.double().cpu() - 2 * ref).abs().max()) < scale * 4e-6 * (K ** 0.5), "fp32 accumulate"
+    # into a view of a larger flat buffer (what the data-parallel engine hands out)
+    flat = torch.zeros(128 + M * N + 64, dtype=torch.float32, device=DEV)
+    view = flat[128:128 + M * N].view(M, N)
+    F.gemm([(a.to(DEV), b.to(DEV))], True, True, out=view)
+    assert torch.equal(view, (out - view)) or float((view.double().cpu() - ref).abs().max()) < scale * 2e-6 * (K ** 0.5)
+    assert float(flat[:128].abs().max()) == 0.0 and float(flat[128 + M * N:].abs().max()) == 0.0
+    with pytest.raises(Exception):
+        F.gemm([(a.t().contiguous().to(DEV), b.t().contiguous().to(DEV))], False, False, out=out)     # fp32: wgrad mode only
+
+
 def test_gemm_segments_accumulate_in_fp32_and_reject_bad_shapes():
     """dX = dQ Wq + dK Wk + dV Wv as ONE launch (three segments of different depth and row pitch) and dW over two token
     ranges: equal to the fp64 sum rounded once — better than three bf16 round trips through C."""

@@ -195,6 +195,7 @@ def test_flat_data_parallel_engine_over_a_single_rank_rccl_group_trains_like_the
     got = [float(tr.train_step(tr.next_batch(b))["loss_per_sample"]) for b in batches]
     norm = float(tr.train_step(tr.next_batch(batches[0]))["grad_norm"])
     assert eng.buckets[0].shard.grad.dtype == getattr(torch, reduce)
+    assert eng.sunk == 2 * 7              # (registered; at these widths the products are too small for the own GEMM)
     assert all(p.grad is None for p in tr.model.parameters())
     tol = 1e-5 if reduce == "float32" else 2e-3            # same init, same kernels: only the gradient dtype differs
     for a, b in zip(got, ref):
@@ -493,3 +494,33 @@ def test_tensor_parallel_two_ranks_on_one_gpu_through_the_hip_kernels():
         for name, (e_loss, e_grad, n_sharded) in results[r][1].items():
             assert e_loss < 2e-3 and e_grad < 5e-2, (r, name, results[r][1])
             assert n_sharded == 2 * 10 + (1 if name == "sp+lp" else 0)
+
+
+def test_flat_engine_weight_gradients_written_by_the_gemm_into_fp32_staging(rccl_single_rank, monkeypatch):
+    """At widths the hand-written GEMM takes (2560-wide layers: 100 tiles, split-K in 2), the blocks' weight-gradient GEMMs
+    write the engine's fp32 reduce-scatter input themselves (`functional.GRAD_SINKS`, tn_gemm_bf16_wgrad_f32) — no bf16
+    gradient tensor, no cast-copy; the steps equal the plain trainer's."""
+    import touchnet_amd.specs  # noqa: F401
+    from touchnet_amd.bin.train import TrainConfig, Trainer
+    from touchnet_amd.data.synthetic import text_batch
+    from touchnet_amd.models.llama import DecoderConfig
+    from touchnet_amd.utils.distributed import build_dp_mesh
+    wide = dict(CFG, model_type="llama", hidden_size=2560, intermediate_size=2560, num_attention_heads=20,
+                num_key_value_heads=20, head_dim=128, num_hidden_layers=2)
+    cfg = DecoderConfig.from_dict(wide)
+    job = dict(training_model_name="llama_mi355", training_enable_fused_ce=True, lr_scheduler_warmup_steps=0,
+               lr_scheduler_lr=1e-3)
+    batches = [text_batch(1024, 4, 512, seed=s, max_len=90) for s in range(3)]
+    plain = Trainer(TrainConfig(**job), cfg, torch.device(DEV))
+    ref = [float(plain.train_step(plain.next_batch(b))["loss_per_sample"]) for b in batches]
+    del plain
+    monkeypatch.setenv("TN_FORCE_FSDP", "1")
+    monkeypatch.setenv("TN_DP_FORCE_COLLECTIVES", "1")
+    tr = Trainer(TrainConfig(**job, training_dp_engine="flat"), cfg, torch.device(DEV, 0), dp_mesh=build_dp_mesh("cuda", 1))
+    got = [float(tr.train_step(tr.next_batch(b))["loss_per_sample"]) for b in batches]
+    eng = tr.dp_engine
+    linear = sum(p.numel() for blk in tr.model.model.layers for n, p in blk.named_parameters() if p.dim() == 2)
+    total = sum(p.numel() for p in tr.model.parameters())
+    assert eng.sunk == 14 and eng.staged_bytes == (total - linear) * 6          # only norms / embeddings / head were cast-copied
+    for a, b in zip(got, ref):
+        assert abs(a - b) / abs(b) < 2e-4, (got, ref)

@@ -67,6 +67,7 @@ PROTOTYPES = {
                      _vp, _vp, _vp, _vp, _vp],
     "tn_gemm_bf16_tn": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _ll, _ll, _ll, _ll, _i, _vp],
     "tn_gemm_bf16_splitk": [_vp, _vp, _ll, _ll, _i, _i, _i, _vp, _vp, _i, _i, _ll, _i, _i, _i, _vp, _ll, _vp],
+    "tn_gemm_bf16_wgrad_f32": [_vp, _vp, _ll, _ll, _i, _vp, _i, _i, _ll, _i, _i, _vp, _ll, _vp],
     "tn_gemm_bf16": [C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_ll), C.POINTER(_ll), C.POINTER(_i), _i, _i, _i, _vp, _vp,
                      _vp, _i, _i, _ll, _ll, _i, _vp],
 }

@@ -83,6 +83,9 @@ struct Params {
   // rounds [0, main) unsplit in one launch and the last partial round [main, tiles) split-K in a second one (688 tiles on
   // 256 CUs are 2 rounds + 176 tiles: whole, the 176 take a third round at 69 % occupancy; cut in 4 they take 0.75)
   int tile0, ntiles;
+  // fp32 output (weight gradients written straight into the data-parallel engine's fp32 staging buffers, utils/zero_dp.py):
+  // C is a float matrix (ldc in floats), no bias, no transposed copy; accumulate adds to what is there
+  int c_f32;
 };
 
 // XCD-aware, bijective workgroup -> tile map
@@ -210,7 +213,7 @@ __device__ __forceinline__ u32x4_t ds_b128(uint32_t addr) {
   return r;
 }
 
-template <bool AK, bool BK, int PLACE, int ASYM, int ILV, bool HAS_CT, bool SPLITK = false>
+template <bool AK, bool BK, int PLACE, int ASYM, int ILV, bool HAS_CT, bool SPLITK = false, bool OUT_F32 = false>
 struct Kernel {
   // ---- per-lane LDS read offsets ------------------------------------------------------------------------------------------
   //  ROW : xr[q] = (row0 + l31) * 128 + (((2 q + hi) ^ ((l31 >> 1) & 7)) << 4); block b at + b * 4096
@@ -540,6 +543,8 @@ struct Kernel {
       if constexpr (SPLITK) {
         const int u = bid + kc * G, sp = u / tiles;
         epilogue_ws(p, acc, sp * tiles + (u - sp * tiles), wr * 128, wc * 64, lane);
+      } else if constexpr (OUT_F32) {
+        epilogue_f32(p, acc, m0 + wr * 128, n0 + wc * 64, lane);
       }
       else if constexpr (TN_GEMM_ABLATE != 4)
         epilogue(p, acc, smem + (wave < 4 ? pb : pa) * SLOT + (wave & 3) * 8192, m0 + wr * 128, n0 + wc * 64, lane);
@@ -563,6 +568,29 @@ struct Kernel {
       else body<1>(p, smem);
     } else {
       body<0>(p, smem);
+    }
+  }
+
+  // fp32 output: the accumulators as they are, 16 bytes per lane and register quad (see epilogue_ws), clipped to M x N
+  static __device__ __forceinline__ void epilogue_f32(const Params& p, Acc& acc, int wm0, int wn0, int lane) {
+    const int l31 = lane & 31, hi = lane >> 5;
+    float* C = reinterpret_cast<float*>(p.C);
+    const bool add = p.accumulate != 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = wm0 + i * 32 + l31;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n = wn0 + j * 32 + 8 * g + 4 * hi;
+          if (m < p.M && n < p.N) {                          // N is a multiple of 8: the quad is inside or outside
+            f32x4_t* dst = reinterpret_cast<f32x4_t*>(C + (long long)m * p.ldc + n);
+            f32x4_t v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+            if (add) v += *dst;
+            *dst = v;
+          }
+        }
     }
   }
 
@@ -681,10 +709,10 @@ struct Kernel {
   }
 };
 
-template <bool AK, bool BK, int PLACE, int ASYM, int ILV, bool HAS_CT, bool SPLITK = false>
+template <bool AK, bool BK, int PLACE, int ASYM, int ILV, bool HAS_CT, bool SPLITK = false, bool OUT_F32 = false>
 __global__ __launch_bounds__(NT, 2) void gemm_kernel(const Params p) {
   __shared__ __attribute__((aligned(1024))) char smem[LDS_BYTES];
-  Kernel<AK, BK, PLACE, ASYM, ILV, HAS_CT, SPLITK>::run(p, smem);
+  Kernel<AK, BK, PLACE, ASYM, ILV, HAS_CT, SPLITK, OUT_F32>::run(p, smem);
 }
 
 // ws[S][ntiles][256 x 256] fp32 partial sums -> C = bf16(sum_s ws[s] (+ bias) (+ C)) on the tiles [tile0, tile0 + ntiles);
@@ -692,7 +720,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const Params p) {
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int S, int M, int N, int nbm,
                                                             int nbn, int tile0, int ntiles, bf16_t* __restrict__ C,
                                                             long long ldc, const bf16_t* __restrict__ bias,
-                                                            int accumulate) {
+                                                            int accumulate, int out_f32) {
   const int t = blockIdx.x >> 5, part = blockIdx.x & 31;
   int tm, tn;
   tile_of_block(tile0 + t, nbm, nbn, tm, tn);
@@ -708,6 +736,18 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     const float4 y = *reinterpret_cast<const float4*>(src + sp * slab + 4);
     a[0] += x.x; a[1] += x.y; a[2] += x.z; a[3] += x.w;
     a[4] += y.x; a[5] += y.y; a[6] += y.z; a[7] += y.w;
+  }
+  if (out_f32) {                                           // (weight gradients into fp32 staging: no bias)
+    float* d = reinterpret_cast<float*>(C) + (long long)m * ldc + n;
+    float4 x = make_float4(a[0], a[1], a[2], a[3]), y = make_float4(a[4], a[5], a[6], a[7]);
+    if (accumulate) {
+      const float4 ox = *reinterpret_cast<const float4*>(d), oy = *reinterpret_cast<const float4*>(d + 4);
+      x.x += ox.x; x.y += ox.y; x.z += ox.z; x.w += ox.w;
+      y.x += oy.x; y.y += oy.y; y.z += oy.z; y.w += oy.w;
+    }
+    *reinterpret_cast<float4*>(d) = x;
+    *reinterpret_cast<float4*>(d + 4) = y;
+    return;
   }
   bf16_t* dst = C + (long long)m * ldc + n;
   if (bias != nullptr) {
@@ -1761,7 +1801,13 @@ static int launch_variant(int variant, dim3 grid, hipStream_t st, Params p) {
       if constexpr (!HAS_CT) {
         hipLaunchKernelGGL((gemm_kernel<AK, BK, DPL, DAS, DIL, false, true>), grid, dim3(NT), 0, st, p);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)p.ntiles * 32u), dim3(256), 0, st, p.ws, p.splitk, p.M,
-                           p.N, p.nbm, p.nbn, p.tile0, p.ntiles, p.C, p.ldc, p.bias, p.accumulate);
+                           p.N, p.nbm, p.nbn, p.tile0, p.ntiles, p.C, p.ldc, p.bias, p.accumulate, p.c_f32);
+      } else {
+        return -1;
+      }
+    } else if (p.c_f32) {
+      if constexpr (AK && BK && !HAS_CT) {         // (weight-gradient mode only: the one caller)
+        hipLaunchKernelGGL((gemm_kernel<true, true, DPL, DAS, DIL, false, false, true>), grid, dim3(NT), 0, st, p);
       } else {
         return -1;
       }
@@ -1788,10 +1834,13 @@ extern "C" {
 static int gemm_launch(const void* const* A, const void* const* B, const long long* lda, const long long* ldb,
                        const int* K, int nseg, int a_kmaj, int b_kmaj, void* C, void* Ct, const void* bias, int M, int N,
                        long long ldc, long long ldct, int accumulate, int splitk, int tail_only, void* workspace,
-                       long long workspace_bytes, void* stream) {
+                       long long workspace_bytes, void* stream, int c_f32 = 0) {
   using namespace tn::gemm;
   if (M <= 0 || N <= 0 || nseg < 1 || nseg > MAXSEG || (N % 8) != 0) return TN_EINVAL;
   if ((ldc % 8) || ldc < N || ((uintptr_t)C & 15)) return TN_EINVAL;
+  if (c_f32 && (!(a_kmaj && b_kmaj) || nseg != 1 || Ct != nullptr || bias != nullptr || tail_only ||
+                TN_GEMM_DEFAULT_VARIANT >= 1000 || getenv("TN_GEMM_VARIANT") != nullptr))
+    return TN_EINVAL;
   if (a_kmaj && (M % 8)) return TN_EINVAL;
   Params p;
   p.stages = 0;
@@ -1839,6 +1888,7 @@ static int gemm_launch(const void* const* A, const void* const* B, const long lo
   p.ws = nullptr;
   p.tile0 = 0;
   p.ntiles = p.nbm * p.nbn;
+  p.c_f32 = c_f32;
   // persistent: one workgroup per CU walks its tiles (TN_GEMM_PERSIST=0: one workgroup per tile, kernel-development A/B)
   static const int ncu = [] {
     int dev = 0, n = 256;
@@ -1916,6 +1966,15 @@ int tn_gemm_bf16_splitk(const void* A, const void* B, long long lda, long long l
   if (splitk < 2) return TN_EINVAL;
   return gemm_launch(&A, &B, &lda, &ldb, &K, 1, a_kmaj, b_kmaj, C, nullptr, bias, M, N, ldc, 0, accumulate, splitk,
                      tail_only, workspace, workspace_bytes, stream);
+}
+
+// Weight gradient with fp32 output: C[M,N] (float, ldc in floats) = (+=) A[K,M]^T · B[K,N], both operands contraction-major
+// (dW = dY^T x read as stored).  splitk <= 1: plain; >= 2: split-K through `workspace` as in tn_gemm_bf16_splitk.
+int tn_gemm_bf16_wgrad_f32(const void* A, const void* B, long long lda, long long ldb, int K, float* C, int M, int N,
+                           long long ldc, int accumulate, int splitk, void* workspace, long long workspace_bytes,
+                           void* stream) {
+  return gemm_launch(&A, &B, &lda, &ldb, &K, 1, 1, 1, C, nullptr, nullptr, M, N, ldc, 0, accumulate,
+                     splitk > 1 ? splitk : 1, 0, workspace, workspace_bytes, stream, 1);
 }
 
 // C[M,N] = A[M,K] · B[N,K]^T (+ bias) (+ C if accumulate); optional transposed copy Ct[N,M]: the round-2 entry point,

@@ -423,6 +423,20 @@ def gemm(segs, a_kmaj: bool = False, b_kmaj: bool = False, bias: Optional[torch.
         if accumulate:
             raise _C.KernelError("gemm: accumulate needs `out`")
         out = torch.empty(M, N, dtype=torch.bfloat16, device=a0.device)
+    if out.dtype == torch.float32:
+        # weight gradient straight into an fp32 buffer (the data-parallel engine's reduce-scatter input)
+        if not (a_kmaj and b_kmaj and len(segs) == 1 and bias is None and out_t is None):
+            raise _C.KernelError("gemm: fp32 output exists for the single-segment weight-gradient mode only")
+        if out.stride(1) != 1 or tuple(out.shape) != (M, N) or not a0.is_cuda:
+            raise _C.KernelError("gemm: bad fp32 `out`")
+        split = split_k(M, N, Ks[0], True, True) if SPLIT_K else 1
+        ws = None
+        if split > 1:
+            ws = torch.empty(split * ((M + 255) // 256) * ((N + 255) // 256) * 65536, dtype=torch.float32, device=a0.device)
+        _C.check(_C.lib().tn_gemm_bf16_wgrad_f32(_p(a0), _p(b0), a0.stride(0), b0.stride(0), Ks[0], _p(out), M, N,
+                                                 out.stride(0), int(accumulate), split, _p(ws),
+                                                 ws.numel() * 4 if ws is not None else 0, _cur()), "tn_gemm_bf16_wgrad_f32")
+        return out
     if out.stride(1) != 1 or tuple(out.shape) != (M, N) or out.dtype != torch.bfloat16:
         raise _C.KernelError("gemm: bad `out`")
     if bias is not None:
@@ -581,6 +595,27 @@ def _wgrad(dy, x2) -> Optional[torch.Tensor]:
     return gemm([(dy, x2)], True, True)
 
 
+# Gradient sinks: a data-parallel engine (utils/zero_dp.py) registers, per weight (by id), an object with
+#   take(w) -> (view [N, K] in its reduce-scatter input — fp32 or bf16 —, accumulate?)   and   done(w)
+# and the weight-gradient GEMM of that weight writes straight into the view instead of returning a tensor that would have
+# to be cast-copied there (autograd then sees no gradient for the weight: the engine counts the arrival itself).
+GRAD_SINKS = {}          # id(weight) -> weakref to the engine (a dead engine's entries are ignored)
+
+
+def _sink_wgrad(w, dy, x2) -> bool:
+    ref = GRAD_SINKS.get(id(w))
+    sink = ref() if ref is not None else None
+    if sink is None or not sink.owns(w):
+        return False
+    M, N = dy.shape
+    if not (_own(N, x2.shape[1], (M,), True, True) and _bf16_rows(dy, x2)):
+        return False
+    view, acc = sink.take(w)
+    gemm([(dy, x2)], True, True, out=view, accumulate=acc)
+    sink.done(w)
+    return True
+
+
 def _stacked_view(ts):
     """[n, M, N] view over `ts` if they are equally shaped contiguous [M, N] matrices lying back to back in one storage
     (in order), else None."""
@@ -654,10 +689,15 @@ class _LinearGroup(torch.autograd.Function):
             dx = dx.view(x.shape)
         dws = [None] * n
         if any(need_w):
+            sunk = set()
             if own:
                 x2c = _c(x2)
-                dws = [_wgrad(d, x2c) if nw else None for d, nw in zip(dys, need_w)]
-            todo = [i for i in range(n) if need_w[i] and dws[i] is None]
+                for i, (d, nw) in enumerate(zip(dys, need_w)):
+                    if nw and _sink_wgrad(ws[i], d, x2c):
+                        sunk.add(i)
+                    elif nw:
+                        dws[i] = _wgrad(d, x2c)
+            todo = [i for i in range(n) if need_w[i] and dws[i] is None and i not in sunk]
             if not todo:
                 pass
             elif len(todo) < n:                           # (some layers of the group went to the hand-written kernel)
@@ -731,13 +771,13 @@ class _SwiGLUMLP(torch.autograd.Function):
         dy2 = _c(dy).reshape(M, H)
         nx, ng, nu, nd = ctx.needs_input_grad
         if ctx.own and LINEAR_GEMM == "own":
-            dwd = gemm([(dy2, kept)], True, True) if nd else None                      # dY^T act  [H, I]
+            dwd = None if (not nd or _sink_wgrad(wd, dy2, kept)) else gemm([(dy2, kept)], True, True)    # dY^T act  [H, I]
             dact = gemm([(dy2, _c(wd))], b_kmaj=True)                                  # dY W_down [M, I]
             dgate, dup = L.swiglu_bwd(dact, gate, up)
             del dact
             dx = gemm([(dgate, _c(wg)), (dup, _c(wu))], b_kmaj=True).view(ctx.xshape) if nx else None
-            dwg = gemm([(dgate, x2)], True, True) if ng else None
-            dwu = gemm([(dup, x2)], True, True) if nu else None
+            dwg = None if (not ng or _sink_wgrad(wg, dgate, x2)) else gemm([(dgate, x2)], True, True)
+            dwu = None if (not nu or _sink_wgrad(wu, dup, x2)) else gemm([(dup, x2)], True, True)
             return dx, dwg, dwu, dwd
         act_t = kept if not ctx.own else transpose_2d(kept)
         dwd = _mm_tn(transpose_2d(dy2), act_t) if nd else None                      # [H, I], forward layout

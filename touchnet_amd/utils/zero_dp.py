@@ -27,6 +27,8 @@ skip-on-nonfinite semantics are FSDP2's / the reference's; `reduce_dtype=bfloat1
 """
 from __future__ import annotations
 
+import os
+import weakref
 from typing import List, Optional
 
 import torch
@@ -107,7 +109,6 @@ class FlatShardedDataParallel:
         # straight into the persistent gradient shard and no collective is issued — RCCL would run its generic one-rank
         # kernel instead (oneRankReduce<PreMulSum>, measured 48.5 ms per step for 34 GB: 1.4 TB/s), which says nothing
         # about what a rank pays at N > 1.  TN_DP_FORCE_COLLECTIVES=1 issues them anyway (the 1-rank RCCL test).
-        import os
         self.identity = self.world == 1 and os.environ.get("TN_DP_FORCE_COLLECTIVES") != "1"
         params = [p for p in model.parameters() if p.requires_grad]
         self.device = params[0].device
@@ -151,6 +152,17 @@ class FlatShardedDataParallel:
         model.register_forward_pre_hook(wait_rest)
         self.avg = dist.ReduceOp.AVG
         self.staged_bytes = 0                            # diagnostics (tests): bytes moved into staging this step
+        # the blocks' linear weights (used once per step, by our own GEMM nodes): their weight-gradient GEMMs write the
+        # staging views themselves
+        self.sunk = 0
+        if self.cuda and os.environ.get("TN_DP_GRAD_SINKS", "1") != "0":
+            from touchnet_amd import functional as F
+            for blk, b in self._hooked_modules:
+                for m in blk.modules():
+                    w = getattr(m, "weight", None)
+                    if isinstance(m, nn.Linear) and w is not None and id(w) in self._of and w.dim() == 2:
+                        F.GRAD_SINKS[id(w)] = weakref.ref(self)
+                        self.sunk += 1
 
     # ------------------------------------------------------------------ optimizer view
     def named_shards(self):
@@ -180,25 +192,44 @@ class FlatShardedDataParallel:
         b._slot = len(self._pool) - 1
         return self._pool[-1][:b.total]
 
-    def _on_grad(self, p: nn.Parameter) -> None:
+    def take(self, p):
+        """-> (this parameter's [shape] view in its bucket's staging buffer, already holds a partial gradient?).  Called by
+        the post-accumulate hook below and — for the linear layers' weights of the blocks (`functional.GRAD_SINKS`) — by
+        the weight-gradient GEMM itself, which then writes the view directly (no cast-copy)."""
         b, i = self._of[id(p)]
         if b.launched:
             raise RuntimeError(f"gradient of a parameter of bucket {b.name} arrived after its reduce-scatter was issued "
                                "(gradient accumulation over several backward passes is not supported by this engine)")
-        first = b.pending == len(b.params) and not any(b.arrived)
-        if first:
+        if b.pending == len(b.params) and not any(b.arrived):
             b.stage = self._acquire(b)
             for a, e in b.gaps:                          # (stale numbers of the buffer's previous user)
                 b.stage[a:e].zero_()
         o = b.offsets[i]
-        b.stage[o:o + p.numel()].view(p.shape).copy_(p.grad)          # the one cast-copy of this gradient
-        self.staged_bytes += p.numel() * (p.grad.element_size() + b.stage.element_size())
-        p.grad = None
+        return b.stage[o:o + p.numel()].view(p.shape), b.arrived[i]
+
+    def owns(self, p) -> bool:
+        e = self._of.get(id(p))
+        return e is not None and e[0].params[e[1]] is p      # (ids can be recycled by later objects)
+
+    def done(self, p) -> None:
+        b, i = self._of[id(p)]
         if not b.arrived[i]:
             b.arrived[i] = True
             b.pending -= 1
         if b.pending == 0:
             self._launch(b)
+
+    def _on_grad(self, p: nn.Parameter) -> None:
+        if p.grad is None:        # (autograd also runs the hook for a weight whose GEMM wrote the staging view itself and
+            return                #  returned no gradient)
+        view, partial = self.take(p)
+        if partial:
+            view.add_(p.grad)
+        else:
+            view.copy_(p.grad)                           # the one cast-copy of this gradient
+        self.staged_bytes += p.numel() * (p.grad.element_size() + view.element_size())
+        p.grad = None
+        self.done(p)
 
     def _launch(self, b: _Bucket) -> None:
         if self.identity:
