@@ -273,6 +273,8 @@ class FlatShardedDataParallel:
 
     def zero_grad(self) -> None:
         for b in self.buckets:
+            if any(b.arrived) and not b.launched and not self.identity and b not in self.rest:
+                self._pool_free_at[b._slot] = None        # (a step that died inside its backward: give the buffer back)
             b.arrived = [False] * len(b.params)
             b.pending, b.launched = len(b.params), False
             b.shard.grad = None
