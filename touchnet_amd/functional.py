@@ -279,7 +279,8 @@ class _FusedLinearCE(torch.autograd.Function):
             lab_k = torch.where(lab == ignore_index, lab, torch.where(mine, lab - v0, torch.full_like(lab, V)))
         for s in range(0, n, chunk):
             e = min(s + chunk, n)
-            logits = torch.nn.functional.linear(h2[s:e], weight)              # [c, V]: the only logits alive
+            logits = _mm_tn(h2[s:e], weight) if (h2.is_cuda and h2.dtype == torch.bfloat16 and _bf16_rows(h2[s:e], weight)) \
+                else torch.nn.functional.linear(h2[s:e], weight)             # [c, V]: the only logits alive
             nll_c, lse_c, hit_c = L.ce_fwd_rows(logits, lab_k[s:e], sl[s:e], ns, int(ignore_index))
             if tp is not None:
                 valid = lab[s:e] != ignore_index
@@ -304,11 +305,19 @@ class _FusedLinearCE(torch.autograd.Function):
                 hit_c = ((best[:, 1].to(torch.int64) == lab[s:e]) & valid).to(hit_c.dtype)
             L.ce_bwd_(logits, lab_k[s:e], sl[s:e], lse_c, ns, one, int(ignore_index))     # logits := dlogits
             parts.append((nll_c, hit_c))
-            torch.mm(logits, weight, out=dh[s:e])                             # dh = dlogits @ W
-            if dw is None:
-                dw = torch.mm(logits.t(), h2[s:e])                            # dW = dlogits^T @ h
+            hc = h2[s:e]
+            own_d = (logits.is_cuda and _own(e - s, H, (V,)) and _bf16_rows(logits, weight, dh[s:e]))
+            if own_d:
+                gemm([(logits, weight)], b_kmaj=True, out=dh[s:e])            # dh = dlogits @ W (W read contraction-major)
             else:
-                dw.addmm_(logits.t(), h2[s:e])                                # accumulate inside the GEMM epilogue
+                torch.mm(logits, weight, out=dh[s:e])
+            own_w = (logits.is_cuda and _own(V, H, (e - s,), True, True) and _bf16_rows(logits, hc))
+            if dw is None:
+                dw = gemm([(logits, hc)], True, True) if own_w else torch.mm(logits.t(), hc)     # dW = dlogits^T @ h
+            elif own_w:
+                gemm([(logits, hc)], True, True, out=dw, accumulate=True)     # accumulate inside the GEMM epilogue
+            else:
+                dw.addmm_(logits.t(), hc)
             del logits
         nll = torch.cat([a for a, _ in parts]) if len(parts) > 1 else parts[0][0]
         hit = torch.cat([b for _, b in parts]) if len(parts) > 1 else parts[0][1]
