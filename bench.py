@@ -438,6 +438,9 @@ def main():
     ap.add_argument("--emulate-rank", type=int, default=None,
                     help="with --gpus 1 and --cp N or --tp N: run rank r of the N-way group alone on one GPU")
     ap.add_argument("--ac", choices=("none", "full", "selective"), default="none", help="activation checkpointing mode")
+    ap.add_argument("--wgrad-stream", action="store_true",
+                    help="weight-gradient GEMMs on a side stream beside the input-gradient chain, one workgroup per tile "
+                         "(TN_WGRAD_STREAM=1): A/B switch, see functional.enable_wgrad_stream")
     ap.add_argument("--loss-parallel", action="store_true",
                     help="with --tp: vocabulary-parallel lm_head + CE (the reference's enable_loss_parallel)")
     ap.add_argument("--no-sequence-parallel", action="store_true",
@@ -451,6 +454,8 @@ def main():
         import touchnet_amd.functional as _F
         _F.LINEAR_GEMM = args.linear_gemm
 
+    if args.wgrad_stream or os.environ.get("TN_WGRAD_STREAM") == "1":
+        os.environ.setdefault("TN_GEMM_PERSIST", "0")
     from touchnet_amd.utils import gemm_tuning
     tuned = (not args.no_gemm_tuning) and gemm_tuning.enable()
 
@@ -490,6 +495,9 @@ def main():
         dp_mesh = build_dp_mesh("cuda", world) if (world > 1 or forced) else None
     mesh = dp_mesh
 
+    if args.wgrad_stream or os.environ.get("TN_WGRAD_STREAM") == "1":
+        import touchnet_amd.functional as _F2
+        _F2.enable_wgrad_stream()
     wl = Workload(args.workload, device, dp_rank, args.batch, args.seqlen, cp=cp_view)
     wl.job.training_enable_fused_ce = not args.unfused_ce
     wl.job.training_ce_compact_rows = args.compact_lm_head

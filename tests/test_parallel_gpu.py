@@ -524,3 +524,42 @@ def test_flat_engine_weight_gradients_written_by_the_gemm_into_fp32_staging(rccl
     assert eng.sunk == 14 and eng.staged_bytes == (total - linear) * 6          # only norms / embeddings / head were cast-copied
     for a, b in zip(got, ref):
         assert abs(a - b) / abs(b) < 2e-4, (got, ref)
+
+
+@pytest.mark.parametrize("engine", ["plain", "flat"])
+def test_weight_gradients_on_a_side_stream_train_identically(rccl_single_rank, engine, monkeypatch):
+    """functional.enable_wgrad_stream(): the weight-gradient GEMMs (own kernel, 2560-wide layers) run on a second stream
+    beside the input-gradient chain, inputs kept alive by record_stream, consumers (optimizer, the flat engine's
+    reduce-scatter) waiting for that stream — the same numbers as the single-stream run, step for step."""
+    import touchnet_amd.functional as F
+    import touchnet_amd.specs  # noqa: F401
+    from touchnet_amd.bin.train import TrainConfig, Trainer
+    from touchnet_amd.data.synthetic import text_batch
+    from touchnet_amd.models.llama import DecoderConfig
+    from touchnet_amd.utils.distributed import build_dp_mesh
+    wide = dict(CFG, model_type="llama", hidden_size=2560, intermediate_size=2560, num_attention_heads=20,
+                num_key_value_heads=20, head_dim=128, num_hidden_layers=2)
+    cfg = DecoderConfig.from_dict(wide)
+    job = dict(training_model_name="llama_mi355", training_enable_fused_ce=True, lr_scheduler_warmup_steps=0,
+               lr_scheduler_lr=1e-3)
+    batches = [text_batch(1024, 4, 512, seed=s, max_len=90) for s in range(4)]
+    if engine == "flat":
+        monkeypatch.setenv("TN_FORCE_FSDP", "1")
+        monkeypatch.setenv("TN_DP_FORCE_COLLECTIVES", "1")
+        job["training_dp_engine"] = "flat"
+    make = lambda: Trainer(TrainConfig(**job), cfg, torch.device(DEV, 0),
+                           dp_mesh=build_dp_mesh("cuda", 1) if engine == "flat" else None)
+
+    def run():
+        tr = make()
+        out = [float(tr.train_step(tr.next_batch(b))["loss_per_sample"]) for b in batches]
+        norm = float(tr.train_step(tr.next_batch(batches[0]))["grad_norm"])
+        return out, norm
+    ref = run()
+    monkeypatch.setenv("TN_GEMM_PERSIST", "0")
+    F.enable_wgrad_stream(True)
+    try:
+        got = run()
+    finally:
+        F.enable_wgrad_stream(False)
+    assert got == ref, (got, ref)

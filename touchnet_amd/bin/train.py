@@ -266,6 +266,9 @@ class Trainer:
         # FSDP2's reduce-scatter then AVERAGES over dp, i.e. gradients are 1/dp of the global-batch mean
         # gradient.  We keep that scale for parity (AdamW is invariant to it, the clip threshold is not).
         loss.backward()
+        from touchnet_amd.models.backend import ops as _ops
+        if hasattr(_ops(), "sync_wgrad_stream"):
+            _ops().sync_wgrad_stream()                   # (weight-gradient GEMMs issued beside the input-gradient chain)
         if self.tp_mesh is not None:
             from touchnet_amd.models.tensor_parallel import reduce_sequence_partial_grads
             reduce_sequence_partial_grads(self.model)    # norm weights saw T/tp rows: sum their gradients over tp

@@ -604,6 +604,41 @@ def _wgrad(dy, x2) -> Optional[torch.Tensor]:
     return gemm([(dy, x2)], True, True)
 
 
+# Weight-gradient GEMMs on a side stream.  Nothing in the backward consumes a weight gradient, so these products can
+# run beside the input-gradient chain: with one workgroup per tile (TN_GEMM_PERSIST=0) the tiles of two launches interleave
+# and the last, partly filled round of one kernel (the MLP weight gradients are 688 tiles for 256 CUs: 2.69 rounds) is
+# filled by the other's.  `enable_wgrad_stream()` switches it on (bench.py --wgrad-stream / TN_WGRAD_STREAM=1);
+# `sync_wgrad_stream()` makes the current stream wait for everything issued there (before the optimizer, before a
+# reduce-scatter).  Inputs are `record_stream`ed so the caching allocator does not recycle them under the side stream.
+WGRAD_STREAM = None
+
+
+def enable_wgrad_stream(on: bool = True) -> None:
+    global WGRAD_STREAM
+    WGRAD_STREAM = torch.cuda.Stream() if on else None
+
+
+def sync_wgrad_stream() -> None:
+    if WGRAD_STREAM is not None:
+        torch.cuda.current_stream().wait_stream(WGRAD_STREAM)
+
+
+def _beside(inputs, fn):
+    """run `fn` (a weight-gradient product over `inputs`) on the side stream, if there is one"""
+    side = WGRAD_STREAM
+    if side is None:
+        return fn()
+    main = torch.cuda.current_stream()
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        out = fn()
+    for t in inputs:
+        t.record_stream(side)
+    if isinstance(out, torch.Tensor):
+        out.record_stream(main)
+    return out
+
+
 # Gradient sinks: a data-parallel engine (utils/zero_dp.py) registers, per weight (by id), an object with
 #   take(w) -> (view [N, K] in its reduce-scatter input — fp32 or bf16 —, accumulate?)   and   done(w)
 # and the weight-gradient GEMM of that weight writes straight into the view instead of returning a tensor that would have
@@ -702,10 +737,10 @@ class _LinearGroup(torch.autograd.Function):
             if own:
                 x2c = _c(x2)
                 for i, (d, nw) in enumerate(zip(dys, need_w)):
-                    if nw and _sink_wgrad(ws[i], d, x2c):
+                    if nw and _beside((d, x2c), lambda: _sink_wgrad(ws[i], d, x2c)):
                         sunk.add(i)
                     elif nw:
-                        dws[i] = _wgrad(d, x2c)
+                        dws[i] = _beside((d, x2c), lambda: _wgrad(d, x2c))
             todo = [i for i in range(n) if need_w[i] and dws[i] is None and i not in sunk]
             if not todo:
                 pass
@@ -780,13 +815,16 @@ class _SwiGLUMLP(torch.autograd.Function):
         dy2 = _c(dy).reshape(M, H)
         nx, ng, nu, nd = ctx.needs_input_grad
         if ctx.own and LINEAR_GEMM == "own":
-            dwd = None if (not nd or _sink_wgrad(wd, dy2, kept)) else gemm([(dy2, kept)], True, True)    # dY^T act  [H, I]
+            dwd = None if (not nd or _beside((dy2, kept), lambda: _sink_wgrad(wd, dy2, kept))) \
+                else _beside((dy2, kept), lambda: gemm([(dy2, kept)], True, True))                       # dY^T act  [H, I]
             dact = gemm([(dy2, _c(wd))], b_kmaj=True)                                  # dY W_down [M, I]
             dgate, dup = L.swiglu_bwd(dact, gate, up)
             del dact
             dx = gemm([(dgate, _c(wg)), (dup, _c(wu))], b_kmaj=True).view(ctx.xshape) if nx else None
-            dwg = None if (not ng or _sink_wgrad(wg, dgate, x2)) else gemm([(dgate, x2)], True, True)
-            dwu = None if (not nu or _sink_wgrad(wu, dup, x2)) else gemm([(dup, x2)], True, True)
+            dwg = None if (not ng or _beside((dgate, x2), lambda: _sink_wgrad(wg, dgate, x2))) \
+                else _beside((dgate, x2), lambda: gemm([(dgate, x2)], True, True))
+            dwu = None if (not nu or _beside((dup, x2), lambda: _sink_wgrad(wu, dup, x2))) \
+                else _beside((dup, x2), lambda: gemm([(dup, x2)], True, True))
             return dx, dwg, dwu, dwd
         act_t = kept if not ctx.own else transpose_2d(kept)
         dwd = _mm_tn(transpose_2d(dy2), act_t) if nd else None                      # [H, I], forward layout

@@ -241,6 +241,9 @@ class FlatShardedDataParallel:
             ready = torch.cuda.Event()
             ready.record()
             self.comm.wait_event(ready)
+            from touchnet_amd import functional as F
+            if F.WGRAD_STREAM is not None:               # the GEMMs that wrote this bucket's views may run there
+                self.comm.wait_stream(F.WGRAD_STREAM)
             with torch.cuda.stream(self.comm):
                 dist.reduce_scatter_tensor(b.gshard, b.stage, op=self.avg, group=self.group)
                 b.reduced = torch.cuda.Event()
