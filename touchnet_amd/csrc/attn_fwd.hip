@@ -349,13 +349,16 @@ int tn_attn_fwd_pp_launch(const void* q, const void* k, const void* v, void* o, 
 
 // Schedule selection: 0 = 4 waves x 32 rows, independent workgroups (default: fastest on packed batches of short
 // documents, where a workgroup meets only a handful of KV tiles); 1 = ping-pong (attn_fwd_pp.hip: 256-row
-// workgroups, ~15 % faster on long documents / plain causal, slower on short ones).  TN_ATTN_FWD_SCHEDULE selects.
-static int fwd_schedule() {
+// workgroups, ~15 % faster on long documents / plain causal, slower on short ones).  TN_ATTN_FWD_SCHEDULE = 0 / 1 forces
+// one; unset = by shape: the long-sequence recipes (T >= 32768, D = 128: config D's 20-minute recordings; measured at
+// T = 65536 plain causal 35.1 vs 38.3 ms) take the ping-pong kernel, everything else — the 8192-token packed batches, the
+// audio tower's 1500-frame clips (0.27 vs 0.35 ms) — schedule 0.
+static int fwd_schedule(int T, int D) {
   static int mode = [] {
     const char* e = getenv("TN_ATTN_FWD_SCHEDULE");
-    return e ? atoi(e) : 0;
+    return e ? atoi(e) : -1;
   }();
-  return mode;
+  return mode >= 0 ? mode : (T >= 32768 && D == 128 ? 1 : 0);
 }
 
 template <int ABL, int NW = 4>
@@ -396,7 +399,7 @@ static int attn_fwd_launch(const void* q, const void* k, const void* v, void* o,
   AttnMeta m = {meta, meta + n, meta + 2 * n, meta + 3 * n, meta + 4 * n, nt};
   const float sl2 = scale * 1.4426950408889634f;
   hipStream_t st = (hipStream_t)stream;
-  if (fwd_schedule() == 1 && (D == 64 || D == 128) && nt <= 1024 && qv.kv_tpc == 0)   // (the ping-pong kernel's LDS tile list)
+  if (fwd_schedule(T, D) == 1 && (D == 64 || D == 128) && nt <= 1024)   // (the ping-pong kernel's LDS tile list)
     return tn_attn_fwd_pp_launch(q, k, v, o, lse2, doc, m, qv, B, T, Nh, Nkv, D, sl2, st);
   dim3 grid(Nh, qv.tiles(0, 128) + qv.tiles(1, 128), B), block(256);
   if (D == 128)

@@ -138,7 +138,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(const bf16_t* __res
       mn = m_min[j];
       mx = m_max[j];
       mp = m_minpos[j];
-      ok = tile_may_interact(bminpos, bmax, mp, mx);
+      ok = tile_may_interact(bminpos, bmax, mp, mx) && qv.kv_tile_on(j);    // (context parallel: own / received chunks only)
     }
     const unsigned long long bal = __ballot(ok);
     if (lane == 0) wcount[wave] = __popcll(bal);
