@@ -522,8 +522,11 @@ def test_flat_engine_weight_gradients_written_by_the_gemm_into_fp32_staging(rccl
     linear = sum(p.numel() for blk in tr.model.model.layers for n, p in blk.named_parameters() if p.dim() == 2)
     total = sum(p.numel() for p in tr.model.parameters())
     assert eng.sunk == 14 and eng.staged_bytes == (total - linear) * 6          # only norms / embeddings / head were cast-copied
+    # (the engine's weight gradients are the UNROUNDED fp32 accumulators, the plain trainer's are rounded to bf16 first: the
+    #  first step is identical, AdamW then amplifies the last-bit differences — 3e-5 at step 2, 5e-4 at step 3 observed)
+    assert got[0] == pytest.approx(ref[0], rel=1e-6)
     for a, b in zip(got, ref):
-        assert abs(a - b) / abs(b) < 2e-4, (got, ref)
+        assert abs(a - b) / abs(b) < 3e-3, (got, ref)
 
 
 @pytest.mark.parametrize("engine", ["plain", "flat"])
