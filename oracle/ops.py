@@ -196,3 +196,4 @@ def log_mel_spectrogram(wav, num_mel_bins=128, padding=0):
 def audiofeat_stack(feat, stack, stride, normalize=True):
     from . import frontend as _fe
     return torch.from_numpy(_fe.audiofeat_stack(feat.detach().cpu().numpy(), stack, stride, normalize)).float()
+

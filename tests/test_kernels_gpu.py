@@ -1287,3 +1287,34 @@ def test_rope_on_one_tensor_alone():
     k1, e = F.apply_rope(k, k.new_empty(B, T, 0, D), cos, sin)
     q1, _ = F.apply_rope(q, q.new_empty(B, T, 0, D), cos, sin)
     assert torch.equal(k1, kj) and torch.equal(q1, qj) and e.numel() == 0
+
+
+@pytest.mark.parametrize("n,T,C,O,stride", [(3, 160, 16, 128, 1), (3, 160, 128, 128, 2), (2, 3000, 128, 1280, 1),
+                                            (2, 3000, 1280, 1280, 2), (1, 77, 64, 192, 2)])
+def test_conv1d_k3_as_gemm_over_strided_im2col_views(n, T, C, O, stride):
+    """functional.conv1d_k3 (the audio tower's conv stem on the hand-written GEMM: overlapping-row im2col views, zero-separated
+    clip slots, overlap-add input gradient) against torch's conv1d in fp32 on the same bf16 values: output, d(input),
+    d(weight), d(bias)."""
+    F = _f()
+    g = torch.Generator().manual_seed(n + T + C + O)
+    x = (torch.randn(n, T, C, generator=g) * 0.5).bfloat16()
+    w = (torch.randn(O, C, 3, generator=g) * (3 * C) ** -0.5).bfloat16()
+    b = (torch.randn(O, generator=g) * 0.1).bfloat16()
+    xr, wr, br = (t.float().requires_grad_() for t in (x, w, b))
+    ref = torch.nn.functional.conv1d(xr.transpose(1, 2), wr, br, stride=stride, padding=1).transpose(1, 2)
+    dyr = torch.randn(ref.shape, generator=g) * 0.3
+    ref.backward(dyr)
+    xd, wd, bd = (t.to(DEV).requires_grad_() for t in (x, w, b))
+    full, t_out = F.conv1d_k3(xd, wd, bd, stride)
+    assert t_out == ref.shape[1] and full.shape[1] >= t_out
+    y = full[:, :t_out]
+    y.backward(dyr.bfloat16().to(DEV))
+    _close(y, ref.detach(), atol=float(ref.abs().max()) * 2 ** -7, rtol=2 ** -6, what="conv1d_k3 forward")
+    for name, got, want in (("dx", xd.grad, xr.grad), ("dw", wd.grad, wr.grad), ("db", bd.grad, br.grad)):
+        _close(got, want, atol=float(want.abs().max()) * 2 ** -6, rtol=2 ** -5, what=f"conv1d_k3 {name}")
+    xd2 = x.to(DEV).requires_grad_()
+    F.conv1d_k3(xd2, wd, bd, stride, need_dx=False)[0][:, :t_out].sum().backward()
+    assert xd2.grad is None
+    from touchnet_amd import _C
+    with pytest.raises(_C.KernelError):
+        F.conv1d_k3(xd, wd[:72], bd[:72], stride)                          # the input gradient contracts over 72 channels

@@ -1853,13 +1853,14 @@ static int gemm_launch(const void* const* A, const void* const* B, const long lo
     if (a_kmaj) {
       if (lda[s] < M || ((long long)(k - 1) * lda[s] + M) * 2 >= 0x7fffffffLL) return TN_EINVAL;
     } else {
-      // per-tile DMA offsets are 32-bit: 288 rows of the operand must stay below 2 GB
-      if (lda[s] < k || (long long)288 * lda[s] * 2 >= 0x7fffffffLL) return TN_EINVAL;
+      // per-tile DMA offsets are 32-bit: 288 rows of the operand must stay below 2 GB.  (lda < K is allowed: OVERLAPPING rows,
+      // the im2col view of a k = 3 convolution over a channels-last sequence — row r = 3 C elements from r * stride * C on)
+      if (lda[s] <= 0 || (long long)288 * lda[s] * 2 >= 0x7fffffffLL) return TN_EINVAL;
     }
     if (b_kmaj) {
-      if (ldb[s] < N || ((long long)(k - 1) * ldb[s] + N) * 2 >= 0x7fffffffLL) return TN_EINVAL;
+      if (ldb[s] <= 0 || ((long long)(k - 1) * ldb[s] + N) * 2 >= 0x7fffffffLL) return TN_EINVAL;   // (ldb < N: overlapping rows)
     } else {
-      if (ldb[s] < k || (long long)288 * ldb[s] * 2 >= 0x7fffffffLL) return TN_EINVAL;
+      if (ldb[s] <= 0 || (long long)288 * ldb[s] * 2 >= 0x7fffffffLL) return TN_EINVAL;
     }
     p.seg[s].A = (const tn::bf16_t*)A[s];
     p.seg[s].B = (const tn::bf16_t*)B[s];

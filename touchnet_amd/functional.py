@@ -842,6 +842,68 @@ class _SwiGLUMLP(torch.autograd.Function):
         return dx, dwg if ng else None, dwu if nu else None, dwd
 
 
+class _Conv1dK3(torch.autograd.Function):
+    """``conv1d(kernel 3, padding 1, stride s)`` over channels-last sequences as GEMMs of the hand-written kernel — the
+    Whisper / Qwen2-Audio conv stem (transformers' WhisperEncoder.conv1 / conv2 behind touchnet/models/qwen2_audio/
+    __init__.py:52-73), which the reference runs through cuDNN/MIOpen.
+
+    x [n, T, C] is copied once into zero-separated slots of P = T + 2 rows ([0, x_0 .. x_{T-1}, 0]; P a multiple of s) of
+    ONE long [n P + s, C] sequence.  The im2col matrix then needs no copy: row r = the 3 C contiguous elements from row
+    r s on — a strided VIEW with overlapping rows (pitch s C < 3 C), which the GEMM's DMA descriptors read as they are:
+        forward      Y [n P / s, O] = A W2^T + b          W2[o, k C + c] = w[o, c, k]
+        dW2          = dY^T A        (both contraction-major: the contraction runs over the output rows)
+        dX           = overlap-add of dA = dY W2 over the three taps (fp32 accumulation, one rounding)
+    Of the P / s output rows of a slot the first T_out are the convolution, the last one(s) mix two clips: the result is
+    returned WHOLE ([n, P / s, O]; the caller slices behind its activation) so that nothing is copied here."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, stride, need_dx):
+        n, T, C0 = x.shape
+        O, s = w.shape[0], int(stride)
+        C = (C0 + 63) // 64 * 64                 # channels padded with zeros: 3 C is then a multiple of the 64-deep stage
+        P = (T + 2 + s - 1) // s * s
+        R = n * P // s
+        xp = x.new_zeros(n * P + s + 2, C)                                 # (+ tail rows: the last window stays inside)
+        xp[:n * P].view(n, P, C)[:, 1:T + 1, :C0] = x
+        A = xp.as_strided((R, 3 * C), (s * C, 1))
+        w2 = w.new_zeros(O, 3, C)
+        w2[:, :, :C0] = w.permute(0, 2, 1)
+        w2 = w2.view(O, 3 * C)
+        y = gemm([(A, w2)], bias=b)
+        ctx.save_for_backward(xp, w2)
+        ctx.geom = (n, T, C0, C, O, s, P, R, bool(need_dx), b is not None, w.dtype)
+        return y.view(n, P // s, O)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xp, w2 = ctx.saved_tensors
+        n, T, C0, C, O, s, P, R, need_dx, has_b, wdtype = ctx.geom
+        dyf = _c(dy).reshape(R, O)
+        A = xp.as_strided((R, 3 * C), (s * C, 1))
+        dw2 = gemm([(dyf, A)], True, True)                                 # [O, 3 C]
+        dw = dw2.view(O, 3, C)[:, :, :C0].permute(0, 2, 1).contiguous().to(wdtype)
+        db = column_sum(dyf) if has_b else None
+        dx = None
+        if need_dx:
+            dA = gemm([(dyf, w2)], b_kmaj=True)                            # [R, 3 C]
+            acc = torch.zeros(n * P + s + 2, C, dtype=torch.float32, device=dy.device)
+            for k in range(3):                                             # tap k of output row r lands on row r s + k
+                acc[k:k + R * s:s] += dA[:, k * C:(k + 1) * C]
+            dx = acc[:n * P].view(n, P, C)[:, 1:T + 1, :C0].to(dy.dtype)
+        return dx, dw, db, None, None
+
+
+def conv1d_k3(x, weight, bias, stride: int = 1, need_dx: bool = True):
+    """x [n, T, C] (channels last) -> (y [n, P / stride, O] with the convolution in rows [0, T_out), T_out); see
+    _Conv1dK3.  bf16 device tensors, output channels a multiple of 8."""
+    n, T, C = x.shape
+    if not (x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16
+            and weight.shape[2] == 3 and weight.shape[1] == C and weight.shape[0] % (64 if need_dx else 8) == 0):
+        raise _C.KernelError("conv1d_k3: bf16 device tensors, kernel size 3, output channels a multiple of 8 (of 64 when the "
+                             "input gradient is wanted: it contracts over them)")
+    return _Conv1dK3.apply(_c(x), weight, bias, stride, need_dx), (T + 2 - 3) // stride + 1
+
+
 _MLP_FUSED = os.environ.get("TN_MLP_FUSED", "1") != "0"       # (A/B switch for measurements)
 
 

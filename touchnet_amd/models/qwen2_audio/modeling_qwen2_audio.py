@@ -119,6 +119,8 @@ class EncoderLayer(nn.Module):
 
 # TN_TOWER_VALID_FRAMES=0 restores the reference's schedule (all 1500 frames of every padded clip through the tower).
 TOWER_VALID_FRAMES_ONLY = os.environ.get("TN_TOWER_VALID_FRAMES", "1") != "0"
+# TN_TOWER_CONV=miopen: the conv stem through torch's conv1d (MIOpen) instead of the hand-written GEMM (A/B switch)
+TOWER_CONV_GEMM = os.environ.get("TN_TOWER_CONV", "own") != "miopen"
 
 
 class Qwen2AudioEncoder(nn.Module):
@@ -144,6 +146,13 @@ class Qwen2AudioEncoder(nn.Module):
     def stem(self, input_features):
         """mel [n, num_mel_bins, Tm] -> conv stem + positions [n, (Tm - 1) // 2 + 1, d_model]"""
         x = input_features.to(self.conv1.weight.dtype)
+        if TOWER_CONV_GEMM and x.is_cuda and x.dtype == torch.bfloat16 and self.conv1.weight.shape[0] % 64 == 0:
+            # both convolutions as GEMMs of the hand-written kernel over channels-last im2col VIEWS (functional._Conv1dK3);
+            # a loader that keeps the mel as [n, Tm, bins] (the frontend's own layout) pays no transpose here
+            h, t1 = ops().conv1d_k3(x.transpose(1, 2), self.conv1.weight, self.conv1.bias, 1, need_dx=False)
+            h, t2 = ops().conv1d_k3(ops().gelu(h)[:, :t1], self.conv2.weight, self.conv2.bias, 2)
+            h = ops().gelu(h)[:, :t2]
+            return h + self.positions(t2)[None].to(h.dtype)
         x = ops().gelu(self.conv1(x))
         x = ops().gelu(self.conv2(x))
         h = x.permute(0, 2, 1).contiguous()
