@@ -550,3 +550,33 @@ def test_split_k_plan_of_the_hand_written_gemm():
     assert F.tail_split(16384, 4096, 4096, False, False) == 0        # 1024 tiles: whole rounds
     assert F.tail_split(30000, 1280, 1280, False, False) == 2        # tower: 590 = 2 rounds + 78; 20 stages: 10 per part
     assert F.tail_split(1280, 1280, 30000, True, True) == 0          # (fewer tiles than CUs: split_k's business)
+
+
+@pytest.mark.parametrize("n,T,C,O,stride", [(2, 20, 8, 16, 1), (3, 20, 8, 64, 2), (1, 7, 5, 8, 2)])
+def test_conv_stem_im2col_view_scheme_on_cpu(n, T, C, O, stride, monkeypatch):
+    """The HOST logic of functional._Conv1dK3 (zero-separated clip slots, overlapping-row im2col views, tap order of the
+    reshaped weight, overlap-add input gradient) with the GEMM replaced by torch matmuls: equals torch's conv1d, forward and
+    all gradients.  (The kernel itself is held to torch on the device, tests/test_kernels_gpu.py.)"""
+    import touchnet_amd.functional as F
+
+    def gemm(segs, a_kmaj=False, b_kmaj=False, bias=None, out=None, accumulate=False, out_t=None):
+        (a, b), = segs
+        a2 = a.t() if a_kmaj else a
+        b2 = b if b_kmaj else b.t()
+        r = a2.double() @ b2.double()
+        return (r + bias.double() if bias is not None else r).to(a.dtype)
+    monkeypatch.setattr(F, "gemm", gemm)
+    monkeypatch.setattr(F, "column_sum", lambda t: t.sum(0))
+    g = torch.Generator().manual_seed(n + T + C)
+    x = torch.randn(n, T, C, generator=g, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(O, C, 3, generator=g, dtype=torch.float64, requires_grad=True)
+    b = torch.randn(O, generator=g, dtype=torch.float64, requires_grad=True)
+    ref = torch.nn.functional.conv1d(x.transpose(1, 2), w, b, stride=stride, padding=1).transpose(1, 2)
+    dy = torch.randn(ref.shape, generator=g, dtype=torch.float64)
+    gx, gw, gb = torch.autograd.grad(ref, (x, w, b), dy)
+    full = F._Conv1dK3.apply(x, w, b, stride, True)
+    t_out = (T + 2 - 3) // stride + 1
+    got = full[:, :t_out]
+    assert got.shape == ref.shape and torch.allclose(got, ref, atol=1e-10)
+    hx, hw, hb = torch.autograd.grad(got, (x, w, b), dy)
+    assert torch.allclose(hx, gx, atol=1e-5) and torch.allclose(hw, gw, atol=1e-10) and torch.allclose(hb, gb, atol=1e-10)
