@@ -90,6 +90,7 @@ def _rmsnorm_setup(ctx, inputs, output):
     _, h, rstd = output
     ctx.has_res = residual is not None
     ctx.wdtype = weight.dtype
+    ctx.set_materialize_grads(False)     # (no zero tensors for the statistics outputs' gradients: 2-3 tiny fills per norm)
     ctx.save_for_backward(h if ctx.has_res else x, weight, rstd)
 
 
@@ -161,6 +162,7 @@ def _layernorm_setup(ctx, inputs, output):
     _, h, mean, rstd = output
     ctx.has_res = residual is not None
     ctx.wdtype = weight.dtype
+    ctx.set_materialize_grads(False)
     ctx.save_for_backward(h if ctx.has_res else x, weight, mean, rstd)
 
 
@@ -346,10 +348,13 @@ def _attn_setup(ctx, inputs, output):
     o, lse2 = output
     ctx.save_for_backward(_c(q), _c(k), _c(v), o, lse2, doc, meta)
     ctx.scale = scale
+    ctx.set_materialize_grads(False)     # (the LSE output has no gradient: no [B, Nh, T] zero fill per layer)
 
 
 def _attn_backward(ctx, do, _dlse):
     q, k, v, o, lse2, doc, meta = ctx.saved_tensors
+    if do is None:
+        do = torch.zeros_like(o)
     if q.shape == k.shape and _STACKED_BWD:                  # multi-head attention: one buffer, three slices
         dq, dk, dv = attn_bwd_stacked(q, k, v, o, do, lse2, doc, meta, ctx.scale).unbind(0)
     else:
@@ -477,10 +482,13 @@ def _attn_seg_setup(ctx, inputs, output):
     o, lse2 = output
     ctx.save_for_backward(_c(q), _c(k), _c(v), o, lse2, doc, meta)
     ctx.scale, ctx.segs, ctx.rpb = scale, list(segs), rpb
+    ctx.set_materialize_grads(False)
 
 
 def _attn_seg_backward(ctx, do, _dlse):
     q, k, v, o, lse2, doc, meta = ctx.saved_tensors
+    if do is None:
+        do = torch.zeros_like(o)
     dq, dk, dv = attn_bwd_seg(q, k, v, o, do, lse2, doc, meta, ctx.scale, ctx.segs, ctx.rpb)
     return dq, dk, dv, None, None, None, None, None
 
