@@ -70,3 +70,66 @@ def test_gemm_accumulators_stay_out_of_the_compilers_hands(tmp_path):
                     waits = sorted(x for x in seg if x.startswith("s_waitcnt"))
                     assert waits == ["s_waitcnt lgkmcnt(0)"] * 4 + ["s_waitcnt vmcnt(8)"], (name, waits)
         assert found == 4, (name, found)            # one stage loop per wave
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not on PATH")
+def test_fused_dkdv_accumulators_and_stage_ring(tmp_path):
+    """csrc/attn_bwd_fused.hip keeps dK^T / dV^T in the LITERAL registers a[0:127] at one wave per SIMD and runs every
+    MFMA as inline asm.  Sound only while hipcc never touches the accumulator file (no spill, no scratch, every
+    v_accvgpr_* and v_mfma inside an asm region, < 256 VGPRs of its own), and fast only while the stage loop keeps the
+    counted vmcnt(5) wait of the four-slot LDS-DMA ring and no compiler-inserted vmcnt(0)."""
+    import re
+    out = tmp_path / "fused.s"
+    r = subprocess.run(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-result", "-S",
+                        "--cuda-device-only", os.path.join(ROOT, "touchnet_amd", "csrc", "attn_bwd_fused.hip"),
+                        "-o", str(out)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr
+    text = out.read_text()
+    m = re.search(r"^(_ZN2tn24attn_bwd_kv_fused_kernel\S*):(.*?)s_endpgm", text, re.S | re.M)
+    assert m
+    body = m.group(2)
+    in_asm, mine, theirs, mfma_in, mfma_out = False, 0, [], 0, 0
+    for line in body.split("\n"):
+        t = line.strip()
+        if t.startswith(";;#ASMSTART") or t.startswith(";#ASMSTART"):
+            in_asm = True
+        elif t.startswith(";;#ASMEND") or t.startswith(";#ASMEND"):
+            in_asm = False
+        elif t.startswith("v_accvgpr"):
+            if in_asm:
+                mine += 1
+            else:
+                theirs.append(t)
+        elif t.startswith("v_mfma"):
+            mfma_in, mfma_out = mfma_in + in_asm, mfma_out + (not in_asm)
+        assert not t.startswith("scratch_"), t
+    # 128 zeroing writes + 128 epilogue reads; five loop-trip variants with MFMAs (32 + 32 + 16 + 16 + 16)
+    assert mfma_out == 0 and mine == 256 and mfma_in == 112, (mine, mfma_in, mfma_out)
+    # hipcc may park a few of its own values in accumulator registers ABOVE the literal block a[0:127] (outside the stage
+    # loop: checked below), never inside it
+    for t in theirs:
+        idx = [int(x) for x in re.findall(r"\ba(\d+)\b", t)]
+        assert idx and all(i >= 128 for i in idx), t
+    meta = re.search(r"\.agpr_count:\s+(\d+).*?\.private_segment_fixed_size:\s+(\d+).*?\.vgpr_count:\s+(\d+)"
+                     r".*?\.vgpr_spill_count:\s+(\d+)", text, re.S)
+    assert meta, "kernel metadata not found"
+    agpr, priv, vgpr, spill = map(int, meta.groups())
+    assert 128 <= agpr <= 136 and priv == 0 and spill == 0 and vgpr - agpr <= 256, (agpr, priv, vgpr, spill)
+    # the stage loop = the innermost loop holding the barriers of the loop trips
+    ins = [l.strip() for l in body.split("\n") if l.strip() and not l.strip().startswith(";")]
+    labels = {mm.group(1): i for i, l in enumerate(ins) for mm in [re.match(r"(\.LBB\d+_\d+):", l)] if mm}
+    loops = []
+    for i, l in enumerate(ins):
+        mm = re.match(r"s_c?branch\S*\s+(\.LBB\d+_\d+)", l)
+        if mm and labels.get(mm.group(1), len(ins)) < i:
+            seg = ins[labels[mm.group(1)]:i + 1]
+            if sum(x.startswith("v_mfma") for x in seg) == 112:
+                loops.append(seg)
+    assert loops, "stage loop not found"
+    seg = min(loops, key=len)
+    vm = [x for x in seg if x.startswith("s_waitcnt") and "vmcnt" in x]
+    assert vm == ["s_waitcnt vmcnt(5)"] * 6, vm          # one counted wait per trip variant, nothing else
+    # no SGPR spill traffic and none of hipcc's parked accumulator values inside the loop
+    assert not any(x.startswith(("v_readlane", "v_writelane")) for x in seg)
+    assert sum(x.startswith("v_accvgpr") for x in seg) == 0
+    assert sum(x.startswith("v_pk_") for x in seg) == 0, "packed f32 VALU beside the MFMAs (see the kernel's ds_elem)"

@@ -633,9 +633,23 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(
 
 }  // namespace tn
 
+namespace tn {
+// attn_bwd_fused.hip: dK and dV in ONE pass (D = 128)
+void launch_attn_bwd_kv_fused128(const bf16_t* Q, const bf16_t* K, const bf16_t* V, const bf16_t* dO,
+                                 const float* lse2, const float* delta, bf16_t* dK, bf16_t* dV, const int* doc,
+                                 AttnMeta m, QView qv, int B, int T, int Nh, int Nkv, float scale, float sl2,
+                                 hipStream_t st);
+}  // namespace tn
+
 using namespace tn;
 
 extern "C" {
+
+// TN_ATTN_BWD_KV=split restores the two-launch dV / dK scheme for D = 128 (kernel-development A/B switch, read per call)
+static bool bwd_kv_split() {
+  const char* e = getenv("TN_ATTN_BWD_KV");
+  return e != nullptr && e[0] == 's';
+}
 
 static int attn_bwd_launch(const void* q, const void* k, const void* v, const void* o, const void* dout,
                            const float* lse2, float* delta, void* dq, void* dk, void* dv, const int* doc,
@@ -655,10 +669,15 @@ static int attn_bwd_launch(const void* q, const void* k, const void* v, const vo
   if (D == 128) {
     hipLaunchKernelGGL((attn_delta_kernel<128>), dim3((rows * 16 + 255) / 256), block, 0, st, (const bf16_t*)o, dO,
                        delta, B, qv.rpb, Nh);
-    hipLaunchKernelGGL((attn_bwd_kv_kernel<128, 0>), gk, block, 0, st, Q, K, V, dO, lse2, delta, (bf16_t*)dk,
-                       (bf16_t*)dv, doc, m, qv, T, Nh, Nkv, scale, sl2);
-    hipLaunchKernelGGL((attn_bwd_kv_kernel<128, 1>), gk, block, 0, st, Q, K, V, dO, lse2, delta, (bf16_t*)dk,
-                       (bf16_t*)dv, doc, m, qv, T, Nh, Nkv, scale, sl2);
+    if (bwd_kv_split()) {
+      hipLaunchKernelGGL((attn_bwd_kv_kernel<128, 0>), gk, block, 0, st, Q, K, V, dO, lse2, delta, (bf16_t*)dk,
+                         (bf16_t*)dv, doc, m, qv, T, Nh, Nkv, scale, sl2);
+      hipLaunchKernelGGL((attn_bwd_kv_kernel<128, 1>), gk, block, 0, st, Q, K, V, dO, lse2, delta, (bf16_t*)dk,
+                         (bf16_t*)dv, doc, m, qv, T, Nh, Nkv, scale, sl2);
+    } else {
+      launch_attn_bwd_kv_fused128(Q, K, V, dO, lse2, delta, (bf16_t*)dk, (bf16_t*)dv, doc, m, qv, B, T, Nh, Nkv, scale,
+                                  sl2, st);
+    }
     hipLaunchKernelGGL((attn_bwd_dq_kernel<128>), gq, block, 0, st, Q, K, V, dO, lse2, delta, (bf16_t*)dq, doc, m,
                        qv, T, Nh, Nkv, scale, sl2);
   } else {
