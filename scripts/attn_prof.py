@@ -36,7 +36,9 @@ def run(B, T, Nh, Nkv, D, doc, iters=3):
     torch.cuda.synchronize()
 
 
-which = sys.argv[1] if len(sys.argv) > 1 else "all"      # docs | causal | tower | all
+which = sys.argv[1] if len(sys.argv) > 1 else "all"      # docs | causal | tower | all | long (config-D-like length)
+if which == "long":
+    run(1, 32768, 32, 32, 128, torch.ones(1, 32768, dtype=torch.int64), iters=2)
 if which in ("docs", "all"):
     run(2, 8192, 32, 32, 128, docs(2, 8192, 790))
 if which in ("causal", "all"):

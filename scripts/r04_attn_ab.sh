@@ -3,7 +3,7 @@
 # fused dK+dV pass (default) — parity tests first, then the schedule and long-sequence benches.  Output: gpurun_out/$1/
 out=gpurun_out/${1:-r04a}; mkdir -p $out
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_kernels_gpu.py -m gpu -k "attention" -x -q > $out/pytest_attention_fused.log 2>&1
+timeout 600 python -m pytest tests/test_kernels_gpu.py -m gpu -k "attention" -x -q > $out/pytest_attention_fused.log 2>&1
 echo "pytest fused rc=$?" | tee -a $out/summary.log
 tail -3 $out/pytest_attention_fused.log | tee -a $out/summary.log
 for mode in split fused; do

@@ -1,3 +1,8 @@
+// MEASURED VARIANT, not built into the library (round 4): the S / dP chain MFMAs alternate with the dV / dK MFMAs so that no two
+// consecutive MFMAs write one accumulator.  Correct (18 attention GPU tests), NOT faster than the grouped order of
+// csrc/attn_bwd_fused.hip: 112.3 vs 113.0 ms backward at T = 65536 (profiles/r04a_*): the same-accumulator cliff is not what
+// limits this kernel (its non-MFMA instruction stream is: scripts/r04_fkv_ablate.sh).
+
 // Packed (document-masked, causal) flash attention BACKWARD for gfx950, D = 128: ONE pass for dK and dV.
 //
 // The two-launch dV / dK scheme of attn_bwd.hip recomputes S = Q K^T in both launches: 16 + 24 MFMAs per
@@ -26,12 +31,6 @@
 #include <utility>
 
 #include "attn_common.h"
-
-// Timing experiments only (scripts/r04_fkv_ablate.sh builds variants with -DTN_FKV_ABL=<bits>; results are wrong):
-// 1 no LDS-DMA in the trips, 2 no barrier, 4 no softmax arithmetic, 8 no LDS reads, 16 no MFMAs, 32 no lgkmcnt waits
-#ifndef TN_FKV_ABL
-#define TN_FKV_ABL 0
-#endif
 
 namespace tn {
 
@@ -68,9 +67,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 template <int BLK, bool FIRST>
 __device__ __forceinline__ void acc_mfma(bf16x8_t a, bf16x8_t b) {
 #define TN_M(...)                                                                                                     \
-  if constexpr ((TN_FKV_ABL & 16) != 0)                                                                               \
-    asm volatile("" ::"v"(a), "v"(b));                                                                                \
-  else if constexpr (FIRST)                                                                                           \
+  if constexpr (FIRST)                                                                                                \
     asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(a), "v"(b),             \
                  "n"(16 * BLK), "n"(16 * BLK + 15) : __VA_ARGS__);                                                    \
   else                                                                                                                \
@@ -104,19 +101,11 @@ __device__ __forceinline__ float acc_read() {
 // behind that read; one statement, so hipcc has no boundary to pad between the wait and the MFMA).
 template <int K>
 __device__ __forceinline__ void mfma_first(f32x16_t& d, u32x4_t a, bf16x8_t b) {
-  constexpr int W = (TN_FKV_ABL & 32) ? 15 : K;
-  if constexpr ((TN_FKV_ABL & 16) != 0)
-    asm volatile("s_waitcnt lgkmcnt(%3)" : "=&v"(d) : "v"(a), "v"(b), "n"(W));
-  else
-    asm volatile("s_waitcnt lgkmcnt(%3)\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b), "n"(W));
+  asm volatile("s_waitcnt lgkmcnt(%3)\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b), "n"(K));
 }
 template <int K>
 __device__ __forceinline__ void mfma_acc(f32x16_t& d, u32x4_t a, bf16x8_t b) {
-  constexpr int W = (TN_FKV_ABL & 32) ? 15 : K;
-  if constexpr ((TN_FKV_ABL & 16) != 0)
-    asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(d) : "v"(a), "v"(b), "n"(W));
-  else
-    asm volatile("s_waitcnt lgkmcnt(%3)\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b), "n"(W));
+  asm volatile("s_waitcnt lgkmcnt(%3)\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b), "n"(K));
 }
 // >= 13 wait states between the last MFMA of a chain and the first VALU read of its result
 __device__ __forceinline__ void mfma_result_pad(f32x16_t& d) { asm volatile("s_nop 7\n\ts_nop 4" : "+v"(d)); }
@@ -124,35 +113,57 @@ __device__ __forceinline__ void mfma_result_pad(f32x16_t& d) { asm volatile("s_n
 template <int OFF>
 __device__ __forceinline__ u32x2_t ds_tr16(uint32_t addr) {
   u32x2_t r;
-  if constexpr ((TN_FKV_ABL & 8) != 0) asm volatile("" : "=v"(r) : "v"(addr));
-  else asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
   return r;
 }
 
 template <class V, int OFF>
 __device__ __forceinline__ V ds_b128(uint32_t addr) {
   V r;
-  if constexpr ((TN_FKV_ABL & 8) != 0) asm volatile("" : "=v"(r) : "v"(addr));
-  else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
   return r;
 }
 
-// LDS operations issued in gap g of group 2 of a trip with a current AND a next stage (see the table in the kernel)
-constexpr int g2_ops(int g, bool mask) { return g < 4 ? 4 : g < 6 ? 3 + (mask ? 1 : 0) : 1 + (mask ? 1 : 0); }
-// ... and how many of the trip's LDS operations are younger than Q row operand s when S MFMA s is issued
-constexpr int g2_wait(int s, bool mask) {
-  int y = 0;
-  if (s < 4) {                         // loaded in gap 4 + s of group 1, operands s + 1 .. 3 right behind it
-    y = 3 - s;
-    for (int g = 0; g < s; ++g) y += g2_ops(g, mask);
-  } else {                             // loaded first thing in gap s - 4 of group 2
-    y = g2_ops(s - 4, mask) - 1;
-    for (int g = s - 3; g < s; ++g) y += g2_ops(g, mask);
-  }
-  return y;
+// ---- The MFMA order of a loop trip and the LDS operations in the gaps behind its MFMAs (see the kernel) -------------
+// Part A, 18 MFMAs: the 8 of dV^T(c) += dO^T(c) P(c) [kind 0], the S(n) = Q(n) K^T chain [1] and the first two of the
+// dP(n) = dO(n) V^T chain [2];  part B, 14 MFMAs: the 8 of dK^T(c) += Q^T(c) dS(c) [3] and the rest of the dP chain.
+// No two consecutive MFMAs write the same accumulator: a filler instruction between two MFMAs of ONE chain costs ~43
+// cycles of matrix-pipe idle each (MI355X_MICROARCH, per-instruction constants; the first version of this kernel ran
+// the S and dP chains back to back: 27 % of its wave cycles were issue stalls).
+constexpr int a_kind(int j) { return j < 3 ? 0 : j < 14 ? (j & 1) : j == 14 || j == 16 ? 2 : 1; }
+constexpr int a_idx(int j) { return j < 3 ? j : j < 14 ? ((j & 1) ? (j - 3) / 2 : j / 2 + 1) : j == 14 ? 0 : j == 16 ? 1 : j == 15 ? 6 : 7; }
+constexpr int b_kind(int j) { return j == 13 ? 3 : (j & 1) ? 2 : 3; }
+constexpr int b_idx(int j) { return j == 13 ? 7 : (j & 1) ? (j + 3) / 2 : j / 2; }
+// LDS operations issued in the gap behind MFMA g of part A (trip with a current AND a next stage), in issue order:
+//   g 0: RQ0   1: RQ1   2: DE2   3: RQ2   4: DE3   5: RQ3 T T   6: T T   7: RQ4 T T   8: T T   9: RQ5 T T   10: RDO0 T T
+//   11: RQ6 T T   12: RDO1 T T   13: RQ7 LE0 (QD0)   14: LE1 (QD1)   15: LE2 (QD2) RDO2   16: LE3 (QD3)   17: RDO3
+// (RQ / RDO = ds_read_b128 row operands of Q(n) / dO(n), T = ds_read_b64_tr_b16 halves of the Q^T(c) operands, DE / LE /
+// QD = delta(c) / LSE(n) / document-id(n) rows)
+constexpr int a_cnt(int g, bool mask) {
+  const int m = mask ? 1 : 0;
+  return g <= 4 ? 1 : g <= 12 ? ((g & 1) || g == 10 || g == 12 ? 3 : 2) : g == 13 ? 2 + m : g == 14 ? 1 + m : g == 15 ? 2 + m
+                                                                                  : g == 16 ? 1 + m : 1;
 }
-static_assert(g2_wait(0, false) == 3 && g2_wait(3, false) == 12 && g2_wait(4, false) == 15 && g2_wait(7, false) == 10 &&
-              g2_wait(5, true) == 15 && g2_wait(6, true) == 15 && g2_wait(7, true) == 13, "LDS wait table");
+constexpr int a_prefix(int g, bool mask) {
+  int n = 0;
+  for (int h = 0; h < g; ++h) n += a_cnt(h, mask);
+  return n;
+}
+// lgkmcnt in front of MFMA `slot` of part A for an operand that was the FIRST operation of gap `gap`
+constexpr int a_wait(int slot, int gap, bool mask) { return a_prefix(slot, mask) - a_prefix(gap, mask) - 1; }
+constexpr int rq_gap(int s) { return s < 2 ? s : 2 * s - 1; }           // gap that loads Q row operand s (S MFMA: 3 + 2 s)
+// part B loads RDO4..7 behind its MFMAs 0, 2, 4, 6; RDO2 / RDO3 come from part A's gaps 15 / 17 (RDO3 = its last LDS
+// operation: lgkmcnt(1) in front of part B retires everything else).  In front of dP MFMA s = 2..7:
+constexpr int b_wait(int s) { return s <= 5 ? 2 : 7 - s; }
+static_assert(a_kind(3) == 1 && a_idx(3) == 0 && a_kind(4) == 0 && a_idx(4) == 3 && a_idx(13) == 5 && a_kind(13) == 1 &&
+              a_idx(12) == 7 && a_kind(15) == 1 && a_idx(15) == 6 && a_idx(17) == 7 && a_kind(17) == 1, "part A order");
+static_assert(b_kind(1) == 2 && b_idx(1) == 2 && b_idx(11) == 7 && b_idx(12) == 6 && b_kind(12) == 3 && b_idx(13) == 7,
+              "part B order");
+static_assert(a_prefix(18, false) == 34 && a_prefix(18, true) == 38 && a_wait(3, rq_gap(0), false) == 2 &&
+              a_wait(5, rq_gap(1), false) == 3 && a_wait(7, rq_gap(2), false) == 6 && a_wait(9, rq_gap(3), false) == 9 &&
+              a_wait(11, rq_gap(4), false) == 10 && a_wait(13, rq_gap(5), false) == 11 && a_wait(14, 10, false) == 10 &&
+              a_wait(15, rq_gap(6), false) == 8 && a_wait(16, 12, false) == 7 && a_wait(17, rq_gap(7), false) == 5 &&
+              a_wait(17, rq_gap(7), true) == 9 && a_wait(16, 12, true) == 10, "LDS wait table");
 
 // One stage of the stream as the list holds it (16 bytes) — every field is wave-uniform once read (SGPRs):
 //   qsb   global position of the stage's first query row
@@ -345,18 +356,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kv_fused_kernel(
   // One loop trip.  CUR: the wave has a stage c to finish (dV, dS, dK); NEXT: it starts stage n (S, dP, P); MASK: stage n
   // needs the element-wise predicate.  sb_c / sb_n: byte offsets of the two slots; the stage three ahead goes to sb_a.
   //
-  // EVERY LDS read of the trip is inline asm and is retired by a hand-counted `s_waitcnt lgkmcnt(k)` that names the
-  // registers it releases (LDS operations retire in order, so k = the number of LDS operations issued behind the one
-  // needed).  Compiler-visible loads next to asm loads get waits computed from hipcc's own count, which ignores the asm
-  // ones: correct but far too strong (lgkmcnt(3) in front of every S MFMA drained the transpose reads issued one gap
-  // earlier).  LDS operations of the trip, in issue order (T = ds_read_b64_tr_b16, everything else ds_read_b128):
-  //   head      16 T (dO^T operands of group 1), DE0, DE1                      retired by lgkmcnt(0) behind the barrier
-  //   group 1   gap 2: DE2   gap 3: DE3   gaps 4..7: RQ0..RQ3
-  //   group 2   gap s < 4: RQ[s + 4], T, T, T    gaps 4, 5: T, T, LE[s - 4] (, QD)    gaps 6, 7: LE[s - 4] (, QD)
-  //             in front of S MFMA s: lgkmcnt(g2_wait(s))                      lgkmcnt(0) in front of group 3
-  //   group 3   gap i: RDO[i]
-  //   group 4   in front of dP MFMA s: lgkmcnt(7 - s)
-  // The counts hold for CUR && NEXT; any other variant waits with lgkmcnt(0) (those trips are the rare ones).
+  // EVERY LDS read of the trip is inline asm and is retired by a hand-counted `s_waitcnt lgkmcnt(k)` inside the statement
+  // of the MFMA that consumes it (LDS operations retire in order, so k = the number of LDS operations issued behind the
+  // one needed: the tables above).  Compiler-visible loads next to asm loads get waits computed from hipcc's own count,
+  // which ignores the asm ones: correct but far too strong.  The counts hold for CUR && NEXT; any other variant waits
+  // with lgkmcnt(0) (those trips are the rare ones).
   auto trip = [&](auto cur_t, auto next_t, auto mask_t, int qsb_n, const QStage& ahead, int sb_c, int sb_n,
                   int sb_a) {
     constexpr bool CUR = decltype(cur_t)::value, NEXT = decltype(next_t)::value, MASK = decltype(mask_t)::value;
@@ -395,18 +399,18 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kv_fused_kernel(
     // my pieces of stage n have landed (stage n + 1 may stay in flight) ...
     wait_vmcnt<IPS>();
     // ... everybody's have, and everybody has left stage c - 1: its slot takes the stage three ahead
-    if constexpr ((TN_FKV_ABL & 2) == 0) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if constexpr ((TN_FKV_ABL & 1) == 0) issue(ahead, sb_a);
+    issue(ahead, sb_a);
     auto ds_elem = [&](auto R) {               // dS = P o (dP - delta), element R of stage c
       constexpr int r = decltype(R)::value;
-      float v = (TN_FKV_ABL & 4) ? dPc[r] : pf[r] * (dPc[r] - de4[r >> 2][r & 3]);
+      float v = pf[r] * (dPc[r] - de4[r >> 2][r & 3]);
       asm volatile("" : "+v"(v));              // (one element per statement: no v_pk_*_f32 packing beside the MFMAs)
       dsf[r] = v;
     };
     auto p_elem = [&](auto R) {                // P = exp2(S c - LSE2), element R of stage n
       constexpr int r = decltype(R)::value;
-      float pv = (TN_FKV_ABL & 4) ? S[r] : fast_exp2(S[r] * scale_log2 - le4[r >> 2][r & 3]);
+      float pv = fast_exp2(S[r] * scale_log2 - le4[r >> 2][r & 3]);
       if constexpr (MASK) {
         const int o = 8 * (r >> 2) + 4 * hi + (r & 3);
         pv = ((kvrow <= qsb_n + o) & (qd4[r >> 2][r & 3] == dkdoc) & (dkdoc > 0)) ? pv : 0.f;
@@ -421,7 +425,27 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kv_fused_kernel(
                          pack2bf(p[8 * sp + 4], p[8 * sp + 5]), pack2bf(p[8 * sp + 6], p[8 * sp + 7])};
       return __builtin_bit_cast(bf16x8_t, t);
     };
-    // ---- group 1: dV^T(c) += dO^T(c) P(c)      gaps: first half of dS(c); delta rows 2, 3; Q(n) row operands 0..3
+    auto rq_load = [&](auto S_) {               // Q(n) row operand s
+      constexpr int s = decltype(S_)::value;
+      rq_[s] = ds_b128<u32x4_t, 2 * ((s >> 1) * Tile::PSTRIDE)>((s & 1) ? rn1 : rn0);
+    };
+    auto rdo_load = [&](auto S_) {              // dO(n) row operand s
+      constexpr int s = decltype(S_)::value;
+      rdo_[s] = ds_b128<u32x4_t, 2 * (Tile::SIZE + (s >> 1) * Tile::PSTRIDE)>((s & 1) ? rn1 : rn0);
+    };
+    auto t2_pair = [&](auto X_) {               // transpose-read halves 2 X, 2 X + 1 = operand X of the Q^T(c) image
+      constexpr int i = decltype(X_)::value;
+      constexpr int off = 2 * ((i & 3) * Tile::PSTRIDE + 16 * (i >> 2) * 32);
+      th[i][0] = ds_tr16<off>(ta0);
+      th[i][1] = ds_tr16<off + 512>(ta1);
+    };
+    auto ln_load = [&](auto R4_) {              // LSE (and document-id) row quad r4 of stage n
+      constexpr int r4 = decltype(R4_)::value;
+      le4[r4] = ds_b128<f32x4_t, 2 * IMGB + 32 * r4>(axn);
+      if constexpr (MASK) qd4[r4] = ds_b128<i32x4_t, 2 * IMGB + 512 + 32 * r4>(axn);
+    };
+    using std::integral_constant;
+    // ---- part A
     if constexpr (CUR) {
       asm volatile("s_waitcnt lgkmcnt(0)"
                    : "+v"(th[0][0]), "+v"(th[0][1]), "+v"(th[1][0]), "+v"(th[1][1]), "+v"(th[2][0]), "+v"(th[2][1]),
@@ -429,60 +453,51 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kv_fused_kernel(
                      "+v"(th[6][0]), "+v"(th[6][1]), "+v"(th[7][0]), "+v"(th[7][1]), "+v"(de4[0]), "+v"(de4[1]));
       tr_retire();
     }
-    static_for<8>([&](auto I) {
-      constexpr int i = decltype(I)::value, sp = i >> 2, db = i & 3;
-      if constexpr (CUR) {
-        acc_mfma<db, i == 0>(tf[i], Pc[sp]);
-        ds_elem(std::integral_constant<int, i>{});
-        if constexpr (i == 2 || i == 3) de4[i] = ds_b128<f32x4_t, 2 * IMGB + 256 + 32 * i>(axc);
-      }
-      if constexpr (NEXT && i >= 4) {
-        constexpr int s = i - 4;
-        rq_[s] = ds_b128<u32x4_t, 2 * ((s >> 1) * Tile::PSTRIDE)>((s & 1) ? rn1 : rn0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    });
-    // ---- group 2: S(n) = Q(n) K^T               gaps: second half of dS(c); Q row operands 4..7; the Q^T(c) operands
-    //                                                   of group 3; LSE / document-id rows of stage n
-    if constexpr (CUR) dSc[0] = pack8(dsf, 0);
-    if constexpr (CUR && !NEXT) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(de4[2]), "+v"(de4[3]));
-    static_for<8>([&](auto I) {
-      constexpr int s = decltype(I)::value;
-      if constexpr (NEXT) {
-        constexpr int k = BOTH ? g2_wait(s, MASK) : 0;
-        if constexpr (s == 0 && CUR)            // (the delta rows 2, 3 are older than Q row operand 0)
-          asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(de4[2]), "+v"(de4[3]) : "n"(k));
-        if constexpr (s == 0) mfma_first<k>(S, rq_[0], kreg[0]);
-        else mfma_acc<k>(S, rq_[s], kreg[s]);
-        if constexpr (s < 4) rq_[s + 4] = ds_b128<u32x4_t, 2 * (((s + 4) >> 1) * Tile::PSTRIDE)>((s & 1) ? rn1 : rn0);
-      }
-      if constexpr (CUR) {
-        ds_elem(std::integral_constant<int, 8 + s>{});
-        if constexpr (s < 6) {                  // 16 transpose reads in the first six gaps (3, 3, 3, 3, 2, 2)
-          constexpr int first = s < 4 ? 3 * s : 12 + 2 * (s - 4), cnt = s < 4 ? 3 : 2;
-          static_for<cnt>([&](auto J) {
-            constexpr int x = first + decltype(J)::value, i = x >> 1, half = x & 1;
-            constexpr int off = 2 * ((i & 3) * Tile::PSTRIDE + 16 * (i >> 2) * 32) + 512 * half;
-            th[i][half] = ds_tr16<off>(half ? ta1 : ta0);
-          });
+    static_for<18>([&](auto J) {
+      constexpr int j = decltype(J)::value, kind = a_kind(j), idx = a_idx(j);
+      // the delta rows 2 / 3 are older than the Q row operands 2 / 3 that S MFMAs 2 / 3 (j = 7, 9) wait for
+      if constexpr (CUR && j == 7) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(de4[2]) : "n"(BOTH ? a_wait(7, 3, MASK) : 0));
+      if constexpr (CUR && j == 9) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(de4[3]) : "n"(BOTH ? a_wait(9, 5, MASK) : 0));
+      if constexpr (kind == 0) {
+        if constexpr (CUR) acc_mfma<(idx & 3), j == 0>(tf[idx], Pc[idx >> 2]);
+      } else if constexpr (kind == 1) {
+        if constexpr (NEXT) {
+          constexpr int k = BOTH ? a_wait(j, rq_gap(idx), MASK) : 0;
+          if constexpr (idx == 0) mfma_first<k>(S, rq_[0], kreg[0]);
+          else mfma_acc<k>(S, rq_[idx], kreg[idx]);
+        }
+      } else {
+        if constexpr (NEXT) {
+          constexpr int k = BOTH ? a_wait(j, idx == 0 ? 10 : 12, MASK) : 0;
+          if constexpr (idx == 0) mfma_first<k>(dPn, rdo_[0], vreg[0]);
+          else mfma_acc<k>(dPn, rdo_[idx], vreg[idx]);
         }
       }
-      if constexpr (NEXT && s >= 4) {
-        le4[s - 4] = ds_b128<f32x4_t, 2 * IMGB + 32 * (s - 4)>(axn);
-        if constexpr (MASK) qd4[s - 4] = ds_b128<i32x4_t, 2 * IMGB + 512 + 32 * (s - 4)>(axn);
-      }
+      // ---- the gap behind MFMA j
+      if constexpr (CUR && j < 16) ds_elem(integral_constant<int, (j < 16 ? j : 0)>{});
+      if constexpr (CUR && j == 7) dSc[0] = pack8(dsf, 0);
+      if constexpr (CUR && j == 15) dSc[1] = pack8(dsf, 1);
+      if constexpr (NEXT && (j == 0 || j == 1)) rq_load(integral_constant<int, (j < 2 ? j : 0)>{});
+      if constexpr (CUR && (j == 2 || j == 4)) de4[j / 2 + 1] = ds_b128<f32x4_t, 2 * IMGB + 256 + 32 * (j / 2 + 1)>(axc);
+      if constexpr (NEXT && (j == 3 || j == 5 || j == 7 || j == 9 || j == 11 || j == 13))
+        rq_load(integral_constant<int, ((j & 1) && j >= 3 && j <= 13 ? (j + 1) / 2 : 0)>{});
+      if constexpr (NEXT && j == 10) rdo_load(integral_constant<int, 0>{});
+      if constexpr (NEXT && j == 12) rdo_load(integral_constant<int, 1>{});
+      if constexpr (CUR && j >= 5 && j <= 12) t2_pair(integral_constant<int, (j >= 5 && j <= 12 ? j - 5 : 0)>{});
+      if constexpr (NEXT && j >= 13 && j <= 16) ln_load(integral_constant<int, (j >= 13 && j <= 16 ? j - 13 : 0)>{});
+      if constexpr (NEXT && j == 15) rdo_load(integral_constant<int, 2>{});
+      if constexpr (NEXT && j == 17) rdo_load(integral_constant<int, 3>{});
       __builtin_amdgcn_sched_barrier(0);
     });
-    // ---- group 3: dK^T(c) += Q^T(c) dS(c)       gaps: first half of P(n); the dO(n) row operands
-    if constexpr (CUR) dSc[1] = pack8(dsf, 1);
+    // ---- part B: everything but the last LDS operation of part A (RDO3) is retired here
     if constexpr (CUR && NEXT && MASK) {
-      asm volatile("s_waitcnt lgkmcnt(0)"
+      asm volatile("s_waitcnt lgkmcnt(1)"
                    : "+v"(th[0][0]), "+v"(th[0][1]), "+v"(th[1][0]), "+v"(th[1][1]), "+v"(th[2][0]), "+v"(th[2][1]),
                      "+v"(th[3][0]), "+v"(th[3][1]), "+v"(th[4][0]), "+v"(th[4][1]), "+v"(th[5][0]), "+v"(th[5][1]),
                      "+v"(th[6][0]), "+v"(th[6][1]), "+v"(th[7][0]), "+v"(th[7][1]), "+v"(le4[0]), "+v"(le4[1]),
                      "+v"(le4[2]), "+v"(le4[3]), "+v"(qd4[0]), "+v"(qd4[1]), "+v"(qd4[2]), "+v"(qd4[3]));
     } else if constexpr (CUR && NEXT) {
-      asm volatile("s_waitcnt lgkmcnt(0)"
+      asm volatile("s_waitcnt lgkmcnt(1)"
                    : "+v"(th[0][0]), "+v"(th[0][1]), "+v"(th[1][0]), "+v"(th[1][1]), "+v"(th[2][0]), "+v"(th[2][1]),
                      "+v"(th[3][0]), "+v"(th[3][1]), "+v"(th[4][0]), "+v"(th[4][1]), "+v"(th[5][0]), "+v"(th[5][1]),
                      "+v"(th[6][0]), "+v"(th[6][1]), "+v"(th[7][0]), "+v"(th[7][1]), "+v"(le4[0]), "+v"(le4[1]),
@@ -499,35 +514,34 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kv_fused_kernel(
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(le4[0]), "+v"(le4[1]), "+v"(le4[2]), "+v"(le4[3]));
     }
     if constexpr (CUR) tr_retire();
-    if constexpr (NEXT && !CUR) mfma_result_pad(S);      // (with CUR the first MFMAs of this group are the distance)
-    static_for<8>([&](auto I) {
-      constexpr int i = decltype(I)::value, sp = i >> 2, db = i & 3;
-      if constexpr (CUR) acc_mfma<DBLK + db, i == 0>(tf[i], dSc[sp]);
-      if constexpr (NEXT) {
-        if constexpr (i == 0 && CUR) asm volatile("s_nop 4" : "+v"(S));   // S chain -> first VALU read: >= 13 states
-        p_elem(std::integral_constant<int, i>{});
-        rdo_[i] = ds_b128<u32x4_t, 2 * (Tile::SIZE + (i >> 1) * Tile::PSTRIDE)>((i & 1) ? rn1 : rn0);
+    if constexpr (NEXT && !CUR) mfma_result_pad(S);      // (with CUR the first MFMA of part B is the distance)
+    static_for<14>([&](auto J) {
+      constexpr int j = decltype(J)::value, kind = b_kind(j), idx = b_idx(j);
+      if constexpr (kind == 3) {
+        if constexpr (CUR) acc_mfma<DBLK + (idx & 3), j == 0>(tf[idx], dSc[idx >> 2]);
+      } else {
+        if constexpr (NEXT) mfma_acc<(BOTH ? b_wait(idx) : 0)>(dPn, rdo_[idx], vreg[idx]);
       }
-      __builtin_amdgcn_sched_barrier(0);
-    });
-    // ---- group 4: dP(n) = dO(n) V^T             gaps: second half of P(n)
-    if constexpr (NEXT) {
-      Pn[0] = pack8(pn, 0);
-      asm volatile("" : "+v"(Pn[0]));
-    }
-    static_for<8>([&](auto I) {
-      constexpr int s = decltype(I)::value;
       if constexpr (NEXT) {
-        if constexpr (s == 0) mfma_first<7>(dPn, rdo_[0], vreg[0]);
-        else mfma_acc<7 - s>(dPn, rdo_[s], vreg[s]);
-        p_elem(std::integral_constant<int, 8 + s>{});
+        if constexpr (j == 0 && CUR) asm volatile("s_nop 4" : "+v"(S));   // S chain -> first VALU read: >= 13 states
+        if constexpr (j < 12) {
+          p_elem(integral_constant<int, (j < 12 ? j : 0)>{});
+        } else {                                // 16 elements over 14 gaps
+          p_elem(integral_constant<int, (j >= 12 ? 2 * j - 12 : 0)>{});
+          p_elem(integral_constant<int, (j >= 12 ? 2 * j - 11 : 0)>{});
+        }
+        if constexpr (j == 7) {
+          Pn[0] = pack8(pn, 0);
+          asm volatile("" : "+v"(Pn[0]));
+        }
+        if constexpr (j == 0 || j == 2 || j == 4 || j == 6) rdo_load(integral_constant<int, (j <= 6 ? 4 + j / 2 : 4)>{});
       }
       __builtin_amdgcn_sched_barrier(0);
     });
     if constexpr (NEXT) {
       Pn[1] = pack8(pn, 1);
       asm volatile("" : "+v"(Pn[1]));
-      mfma_result_pad(dPn);
+      if constexpr (!CUR) mfma_result_pad(dPn);          // (with CUR two dK MFMAs follow the chain's last MFMA)
       Pc[0] = Pn[0];
       Pc[1] = Pn[1];
       dPc = dPn;

@@ -277,6 +277,64 @@ def test_tp_shards_are_not_initialised_identically():
             assert same, n                                             # replicated parameters (and zero biases) agree
 
 
+def test_tp_shards_and_norm_index_survive_activation_checkpointing():
+    """`apply_ac` wraps the blocks AFTER `apply_tp` recorded its parameter names; root-level names then
+    carry `_checkpoint_wrapped_module.` and neither the shard re-initialisation nor the tp-aware gradient norm found
+    their parameters (identical shards on all tp ranks, clip coefficient without the tp sum)."""
+    from types import SimpleNamespace
+    from touchnet_amd.models.kimi_audio import KimiAudioConfig, KimiAudioPackedForCausalLM
+    from touchnet_amd.models.parallelize import apply_ac
+    from touchnet_amd.models.tensor_parallel import EmulatedTPMesh, apply_tp, reinit_tp_shards, tp_param_ids
+    job = SimpleNamespace(training_activation_checkpoint_mode="full", training_activation_checkpoint_selective_ac_option="2")
+    shards = []
+    for r in range(2):
+        torch.manual_seed(5)
+        m = apply_tp(KimiAudioPackedForCausalLM(KimiAudioConfig(**KIMI_TINY)), EmulatedTPMesh(2, r))
+        n_plain = len(tp_param_ids([m])[1])
+        apply_ac(m, job)
+        assert any("_checkpoint_wrapped_module." in n for n, _ in m.named_parameters())
+        m.post_init()
+        reinit_tp_shards(m, seed=5, std=0.02)
+        group, ids = tp_param_ids([m])
+        assert len(ids) == n_plain and n_plain > 0                       # the optimizer's tp index is complete
+        shards.append({n: p.detach().clone() for n, p in m.named_parameters()})
+    names = m._tn_tp["sharded_names"]
+    checked = 0
+    for n in shards[0]:
+        plain = n.replace("_checkpoint_wrapped_module.", "")
+        if plain in names and not n.endswith("bias"):
+            assert not torch.equal(shards[0][n], shards[1][n]), n        # the tp ranks hold DIFFERENT shards
+            checked += "_checkpoint_wrapped_module." in n
+    assert checked > 0
+
+
+def test_tp_shard_reinit_under_dim0_sharding_is_not_a_dp_copy():
+    """with FSDP2 on top (dp shards along dim 0) every dp rank drew its local rows from the same
+    generator state: each tp-local weight came out as dp copies of one row block.  The rows of a tp-local tensor must be
+    one draw of its FULL shape, whichever dp rank holds which rows."""
+    from torch.distributed.device_mesh import init_device_mesh
+    from torch.distributed.tensor import Shard, distribute_tensor
+    import torch.distributed as dist
+    from touchnet_amd.models.tensor_parallel import reinit_tp_shards
+    import os
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29631")
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        mesh = init_device_mesh("cpu", (1,), mesh_dim_names=("dp",))
+        lin = torch.nn.Linear(8, 12, bias=False)
+        plain = torch.nn.Linear(8, 12, bias=False)
+        lin.weight = torch.nn.Parameter(distribute_tensor(lin.weight.detach(), mesh, [Shard(0)]))
+        info = {"size": 2, "rank": 1, "sharded_names": {"weight"}, "group": None}
+        lin._tn_tp, plain._tn_tp = info, info
+        reinit_tp_shards(lin, seed=3, std=0.02)
+        reinit_tp_shards(plain, seed=3, std=0.02)
+        # one dp rank holds all rows here: the DTensor path (full draw + slice) must reproduce the plain draw
+        assert torch.equal(lin.weight._local_tensor, plain.weight)
+    finally:
+        dist.destroy_process_group()
+
+
 def test_row_parallel_bias_is_refused():
     from touchnet_amd.models.kimi_audio import KimiAudioConfig, KimiAudioPackedForCausalLM
     from touchnet_amd.models.tensor_parallel import EmulatedTPMesh, apply_tp

@@ -611,11 +611,25 @@ def _wgrad(dy, x2) -> Optional[torch.Tensor]:
 # `sync_wgrad_stream()` makes the current stream wait for everything issued there (before the optimizer, before a
 # reduce-scatter).  Inputs are `record_stream`ed so the caching allocator does not recycle them under the side stream.
 WGRAD_STREAM = None
+WGRAD_MAIN = None             # the stream the backward itself runs on (noted by `_beside`)
+# A sharding engine (utils/zero_dp.py, FSDP2) reads a returned weight gradient on the backward's own stream right away
+# (cast-copy into the reduce-scatter input); it sets this and `_beside` then lets that stream wait for the product.
+WGRAD_RETURNS_NEED_SYNC = False
 
 
 def enable_wgrad_stream(on: bool = True) -> None:
     global WGRAD_STREAM
     WGRAD_STREAM = torch.cuda.Stream() if on else None
+
+
+def wgrad_streams():
+    """Streams that may hold unfinished writes of gradients during a backward: the current one, and with the side stream
+    on also that one and the backward's own."""
+    out = [torch.cuda.current_stream()]
+    for st in (WGRAD_STREAM, WGRAD_MAIN if WGRAD_STREAM is not None else None):
+        if st is not None and all(st != o for o in out):
+            out.append(st)
+    return out
 
 
 def sync_wgrad_stream() -> None:
@@ -628,7 +642,9 @@ def _beside(inputs, fn):
     side = WGRAD_STREAM
     if side is None:
         return fn()
+    global WGRAD_MAIN
     main = torch.cuda.current_stream()
+    WGRAD_MAIN = main
     side.wait_stream(main)
     with torch.cuda.stream(side):
         out = fn()
@@ -636,6 +652,8 @@ def _beside(inputs, fn):
         t.record_stream(side)
     if isinstance(out, torch.Tensor):
         out.record_stream(main)
+        if WGRAD_RETURNS_NEED_SYNC:           # (record_stream only protects the allocator, not the reader)
+            main.wait_stream(side)
     return out
 
 

@@ -41,6 +41,11 @@ def apply_fsdp(model: nn.Module, dp_mesh, param_dtype=torch.bfloat16, reduce_dty
     if pp_enabled or cpu_offload:
         raise NotImplementedError("pipeline parallelism / CPU offload are outside the MI355X path")
     fully_shard, MixedPrecisionPolicy = _fully_shard()
+    if any(p.is_cuda for p in model.parameters()):
+        # FSDP2 copies a returned weight gradient into its reduce-scatter input behind the backward's own stream: a product
+        # computed on the optional weight-gradient side stream must be waited for there (functional._beside)
+        from touchnet_amd import functional as F
+        F.WGRAD_RETURNS_NEED_SYNC = True
     cfg = {"mesh": dp_mesh, "mp_policy": MixedPrecisionPolicy(param_dtype=param_dtype, reduce_dtype=reduce_dtype)}
     for blocks in block_groups(model):
         for i, blk in enumerate(blocks):

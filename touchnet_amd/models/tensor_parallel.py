@@ -278,7 +278,7 @@ def reduce_sequence_partial_grads(model: nn.Module) -> None:
         return
     grads = []
     for n, p in model.named_parameters():
-        if n.replace("_checkpoint_wrapped_module.", "") in info["seq_partial_names"] and p.grad is not None:
+        if _plain_name(n) in info["seq_partial_names"] and p.grad is not None:
             g = p.grad
             grads.append(g._local_tensor if hasattr(g, "_local_tensor") else g)
     if not grads:
@@ -301,14 +301,32 @@ def reinit_tp_shards(model: nn.Module, seed: int, std: float) -> None:
         return
     import zlib
     for name, p in model.named_parameters():
+        name = _plain_name(name)
         if name in info["sharded_names"] and not p.is_meta:
             local = p._local_tensor if hasattr(p, "_local_tensor") else p
-            g = torch.Generator(device=local.device)
-            g.manual_seed((int(seed) * 1000003 + zlib.crc32(name.encode()) * 31 + info["rank"]) % (2 ** 63 - 1))
             if name.endswith("bias"):
                 local.zero_()
+                continue
+            g = torch.Generator(device=local.device)
+            g.manual_seed((int(seed) * 1000003 + zlib.crc32(name.encode()) * 31 + info["rank"]) % (2 ** 63 - 1))
+            if hasattr(p, "_local_tensor"):
+                # FSDP2 on top (dim-0 shards over dp): every dp rank draws the WHOLE tp-local tensor from the same
+                # (seed, name, tp rank) stream and keeps its own rows — drawing `local` directly would give all dp
+                # ranks the same numbers, i.e. dp copies of one row block
+                from torch.distributed.tensor._utils import compute_local_shape_and_global_offset
+                shape, offset = compute_local_shape_and_global_offset(p.shape, p.device_mesh, p.placements)
+                full = torch.empty(tuple(p.shape), dtype=local.dtype, device=local.device)
+                full.normal_(mean=0.0, std=std, generator=g)
+                idx = tuple(slice(o, o + n) for o, n in zip(offset, shape))
+                local.copy_(full[idx].reshape(local.shape))
             else:
                 local.normal_(mean=0.0, std=std, generator=g)
+
+
+def _plain_name(name: str) -> str:
+    """Parameter name without the prefix activation checkpointing's wrapper inserts (`apply_ac` runs after `apply_tp`,
+    which recorded the names of the unwrapped blocks)."""
+    return name.replace("_checkpoint_wrapped_module.", "")
 
 
 def tp_param_ids(model_parts):
@@ -318,5 +336,5 @@ def tp_param_ids(model_parts):
         info = getattr(m, "_tn_tp", None)
         if info:
             group = info["group"]
-            ids |= {id(p) for n, p in m.named_parameters() if n in info["sharded_names"]}
+            ids |= {id(p) for n, p in m.named_parameters() if _plain_name(n) in info["sharded_names"]}
     return group, ids

@@ -150,11 +150,16 @@ class FlatShardedDataParallel:
             for b in self.rest:
                 self._wait_params(b)
         model.register_forward_pre_hook(wait_rest)
+        if hasattr(model, "register_state_dict_pre_hook"):
+            model.register_state_dict_pre_hook(lambda module, prefix, keep_vars: self.wait_params())
         self.avg = dist.ReduceOp.AVG
         self.staged_bytes = 0                            # diagnostics (tests): bytes moved into staging this step
         # the blocks' linear weights (used once per step, by our own GEMM nodes): their weight-gradient GEMMs write the
         # staging views themselves
         self.sunk = 0
+        if self.cuda:
+            from touchnet_amd import functional as F
+            F.WGRAD_RETURNS_NEED_SYNC = True             # (see functional._beside)
         if self.cuda and os.environ.get("TN_DP_GRAD_SINKS", "1") != "0":
             from touchnet_amd import functional as F
             for blk, b in self._hooked_modules:
@@ -178,12 +183,12 @@ class FlatShardedDataParallel:
             if b.stage is None:
                 b.stage = torch.zeros(b.total, dtype=self.reduce_dtype, device=self.device)
             if b.reduced is not None and self.cuda:
-                torch.cuda.current_stream().wait_event(b.reduced)
+                self._wait_writers(b.reduced)
             return b.stage
         for i, ev in enumerate(self._pool_free_at):
             if ev is not False:                          # False = in use by an open bucket
                 if ev is not None and self.cuda:
-                    torch.cuda.current_stream().wait_event(ev)
+                    self._wait_writers(ev)
                 self._pool_free_at[i] = False
                 b._slot = i
                 return self._pool[i][:b.total]
@@ -191,6 +196,14 @@ class FlatShardedDataParallel:
         self._pool_free_at.append(False)
         b._slot = len(self._pool) - 1
         return self._pool[-1][:b.total]
+
+    def _wait_writers(self, ev) -> None:
+        """Every stream that may write gradients into a staging buffer waits for its previous reduce-scatter: the caller's,
+        and — with weight-gradient GEMMs on a side stream — that stream AND the backward's own (a bucket may be opened
+        by a GEMM on the side stream while norm weights / biases are cast-copied on the main one)."""
+        from touchnet_amd import functional as F
+        for st in F.wgrad_streams():
+            st.wait_event(ev)
 
     def take(self, p):
         """-> (this parameter's [shape] view in its bucket's staging buffer, already holds a partial gradient?).  Called by
@@ -238,12 +251,9 @@ class FlatShardedDataParallel:
         if b.gshard is None:
             b.gshard = torch.empty(b.S, dtype=self.reduce_dtype, device=self.device)
         if self.cuda:
-            ready = torch.cuda.Event()
-            ready.record()
-            self.comm.wait_event(ready)
             from touchnet_amd import functional as F
-            if F.WGRAD_STREAM is not None:               # the GEMMs that wrote this bucket's views may run there
-                self.comm.wait_stream(F.WGRAD_STREAM)
+            for st in F.wgrad_streams():                 # everything that wrote this bucket's views, wherever it ran
+                self.comm.wait_stream(st)
             with torch.cuda.stream(self.comm):
                 dist.reduce_scatter_tensor(b.gshard, b.stage, op=self.avg, group=self.group)
                 b.reduced = torch.cuda.Event()
@@ -304,6 +314,14 @@ class FlatShardedDataParallel:
         else:
             for b in order:
                 dist.all_gather_into_tensor(b.flat_p, b.shard.data, group=self.group)
+
+    def wait_params(self) -> None:
+        """The current stream waits for every pending all-gather of updated slices.  The blocks' and the model's forward
+        pre-hooks do that per bucket; anything ELSE that reads parameters right behind a step (state_dict / checkpoint
+        save, evaluation through a submodule, an EMA) must call this first — a state_dict pre-hook does it for
+        `model.state_dict()`."""
+        for b in self.buckets:
+            self._wait_params(b)
 
     def _wait_params(self, b: _Bucket) -> None:
         if self.cuda and b.params_ready is not None:
