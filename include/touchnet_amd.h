@@ -250,6 +250,14 @@ int tn_gemm_bf16_wgrad_f32(const void* A, const void* B, long long lda, long lon
 int tn_gemm_bf16_tn(const void* A, const void* B, void* C, void* Ct, const void* bias, int M, int N, int K,
                     long long lda, long long ldb, long long ldc, long long ldct, int accumulate, void* stream);
 
+/*      Launch form of the GEMMs above: 1 (default) = persistent, one workgroup per CU walking a fixed tile list; 0 = one
+ *      workgroup per tile, for a host that runs collectives beside the compute (an RCCL kernel holding CUs would leave a
+ *      persistent workgroup's whole tile list waiting: the FSDP2 / context-parallel schedule of
+ *      touchnet/models/helper_func.py:134-202, touchnet/utils/distributed.py:292-346).  Process-wide, takes effect at the
+ *      next launch; TN_GEMM_PERSIST in the environment overrides it (kernel-development A/B).  Returns nothing / the value. */
+void tn_gemm_set_persistent(int on);
+int tn_gemm_get_persistent(void);
+
 #ifdef __cplusplus
 }
 #endif

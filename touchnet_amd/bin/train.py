@@ -106,13 +106,15 @@ class Trainer:
         # parameters, RCCL all-gather / reduce-scatter, the optimizer on local shards) can be exercised on one GPU
         sharded = fsdp_mesh is not None and (shard_world > 1 or os.environ.get("TN_FORCE_FSDP") == "1")
         if (shard_world > 1 or self.cp_group is not None or (self.tp_mesh is not None and not getattr(
-                self.tp_mesh, "emulated", False))) and "TN_GEMM_PERSIST" not in os.environ:
+                self.tp_mesh, "emulated", False))) and self.device.type == "cuda":
             # Collectives run beside the compute from here on.  The GEMM's persistent form (one workgroup per CU, each
             # walking a FIXED list of tiles) assumes it gets every CU: an RCCL kernel that holds some of them would leave
             # those workgroups — and their whole tile lists — waiting behind it.  One workgroup per tile lets the
             # dispatcher hand tiles to whatever CUs are free; it costs 0-2.5 % per kernel alone on the chip
-            # (profiles/r03b_gemm_persistent_asym_sweep.json: p0 vs p1 columns).  csrc/gemm.hip reads the switch per launch.
-            os.environ["TN_GEMM_PERSIST"] = "0"
+            # (profiles/r03b_gemm_persistent_asym_sweep.json: p0 vs p1 columns).  An explicit library call, not a change
+            # of the process environment (TN_GEMM_PERSIST in the environment still overrides it).
+            from touchnet_amd import _C
+            _C.lib().tn_gemm_set_persistent(0)
         if self.spec.additional_pre_init_fn:
             self.spec.additional_pre_init_fn(job)                      # train.py:121-122
         torch.manual_seed(job.training_seed)

@@ -771,987 +771,18 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   out.store(dst);
 }
 
-// =====================================================================================================================
-// Half-stage ring (variants 1000 + PLACE32): the same tile, operands and fragment maths, but K is consumed in 32-deep
-// HALF stages and the 160 KB of LDS are a ring of FIVE (A, B) pairs of 16 KB half-slots.  The barrier of half-stage h
-// frees pair h, which takes pair h + 5; pairs h+2 .. h+4 are under way meanwhile: every operand is issued 4 half-stages
-// = TWO full stages before it is due (the 64-deep ring gives B(t+2) one stage), and a wave issues one piece every 4
-// MFMAs without pause instead of 8 pieces per 32 MFMAs behind one barrier.
-//      wait at the barrier of half-stage h, in flight oldest first: pair h+1 | h+2, h+3, h+4 -> vmcnt(12)
-//   ROW   half image [256 r][64 B] : 16-byte chunk c of row r in slot c ^ ((r >> 2) & 3) (a 256-byte bank row holds 4
-//         tile rows; the 16 lanes of a ds_read_b128 service group see 16 different (row & 3, slot) pairs); a DMA piece is
-//         16 rows x 64 B (half lines: the L2 request granule is 64 B, TCC_REQ counts say so)
-//   KMAJ  half image [32 k][512 B] : as the 64-deep image
-// =====================================================================================================================
-constexpr int HSLOT = 16384;
-
-template <int PLACE32> struct Place32;     // positions 0..15 behind the barrier: two B pieces, then two A pieces
-template <> struct Place32<0> { static constexpr int B[2] = {0, 4}, A[2] = {8, 12}; };
-template <> struct Place32<1> { static constexpr int B[2] = {0, 2}, A[2] = {4, 6}; };
-template <> struct Place32<2> { static constexpr int B[2] = {1, 5}, A[2] = {9, 13}; };
-template <> struct Place32<3> { static constexpr int B[2] = {2, 6}, A[2] = {10, 14}; };
-
-template <int PLACE32, bool IS_A> constexpr int piece32_at(int pos) {
-  for (int i = 0; i < 2; ++i)
-    if ((IS_A ? Place32<PLACE32>::A[i] : Place32<PLACE32>::B[i]) == pos) return i;
-  return -1;
-}
-
-template <bool KMAJ>
-struct Stream32 {
-  __amdgpu_buffer_rsrc_t rs;
-  int soff, step, left, seg, ld2;
-  int voff[2];   // per-lane byte offsets of this wave's 2 pieces
-
-  __device__ __forceinline__ void set_voff(int wave, int lane) {
-    if constexpr (!KMAJ) {
-      // piece q = rows 32 wave + 16 q + (lane >> 2); the lane's slot lane & 3 holds chunk (lane & 3) ^ ((row >> 2) & 3)
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int row = wave * 32 + q * 16 + (lane >> 2);
-        voff[q] = (TN_GEMM_ABLATE == 6 ? (row & 7) : row) * ld2 + (((lane & 3) ^ ((row >> 2) & 3)) << 4);
-      }
-    } else {
-      // piece q = k-rows 4 wave + 2 q + (lane >> 5) of the half stage
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int k = wave * 4 + q * 2 + (lane >> 5);
-        const int u = lane & 31;
-        voff[q] = (TN_GEMM_ABLATE == 6 ? (k & 1) : k) * ld2 + ((((u >> 2) ^ (k & 3)) << 6) | ((u & 3) << 4));
-      }
-    }
-  }
-  __device__ __forceinline__ void open(const bf16_t* X, long long ld, int K, int R, int origin, int wave, int lane) {
-    ld2 = (int)(ld * 2);
-    if constexpr (!KMAJ) {
-      const long long bytes = (long long)(R - origin) * ld2;
-      rs = __builtin_amdgcn_make_buffer_rsrc((void*)(X + (long long)origin * ld), 0, (int)min(bytes, 0x7fffffffLL),
-                                             0x00020000);
-      step = 64;
-    } else {
-      const long long bytes = ((long long)(K - 1) * ld + (R - origin)) * 2;
-      rs = __builtin_amdgcn_make_buffer_rsrc((void*)(X + origin), 0, (int)min(bytes, 0x7fffffffLL), 0x00020000);
-      step = 32 * ld2;
-    }
-    set_voff(wave, lane);
-    soff = 0;
-    left = (K + 31) >> 5;
-  }
-  __device__ __forceinline__ void kill(const void* any) {
-    rs = __builtin_amdgcn_make_buffer_rsrc((void*)any, 0, 0, 0x00020000);
-    soff = 0;
-    step = 0;
-    left = 0x7fffffff;
-  }
-};
-
-template <bool AK, bool BK, int PLACE32, bool HAS_CT>
-struct Kernel32 {
-  static constexpr bool SPLITK = false;      // (split-K exists in the 64-deep-ring kernel only)
-  template <bool KMAJ, int NB>
-  struct Reader {
-    int x[4];
-    __device__ __forceinline__ Reader(int lane, int row0) {
-      const int l31 = lane & 31, hi = lane >> 5;
-      if constexpr (!KMAJ) {
-        const int f = (l31 >> 2) & 3;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) x[q] = (row0 + l31) * 64 + (((2 * q + hi) ^ f) << 4);
-        x[2] = x[3] = 0;
-      } else {
-        const int s4 = lane & 15, j = s4 >> 2, w = s4 & 3, half = (lane >> 4) & 1;
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-          x[b] = (8 * hi + j) * 512 + half * 32 + w * 8 + ((((row0 >> 5) + (b < NB ? b : 0)) ^ j) << 6);
-      }
-    }
-    template <int Q, int B>
-    __device__ __forceinline__ void read(const char* smem, int sbase, Frags<KMAJ, NB>& f) const {
-      if constexpr (!KMAJ) {
-        f.v[B] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(smem + sbase + x[Q] + B * 2048));
-      } else {
-        const uint32_t a = (uint32_t)(size_t)(lds_ptr_t)smem + (uint32_t)(sbase + x[B]);
-        f.h[B][0] = ds_tr16<(16 * Q) * 512>(a);
-        f.h[B][1] = ds_tr16<(16 * Q + 4) * 512>(a);
-      }
-    }
-  };
-
-  using K64 = Kernel<AK, BK, 0, 0, 1, HAS_CT>;       // (wait_frags is shared)
-
-  static __device__ __forceinline__ void run(const Params& p, char* smem) {
-    const int tid = threadIdx.x;
-    int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 2, wc = wave & 3;
-
-    const int bid = blockIdx.x, G = gridDim.x;
-    const int tiles = p.ntiles;
-    const int mine = ((SPLITK ? tiles * p.splitk : tiles) - bid + G - 1) / G;
-    auto origin = [&](int k, int& m0, int& n0) {
-      int tm, tn, u = bid + k * G;
-      if constexpr (SPLITK) u -= (u / tiles) * tiles;
-      tile_of_block(p.tile0 + u, p.nbm, p.nbn, tm, tn);
-      m0 = tm * BM;
-      n0 = tn * BN;
-    };
-    auto split_of = [&](int k) { return (bid + k * G) / tiles; };
-
-    Stream32<AK> sA;
-    Stream32<BK> sB;
-    int ka = 0, kb = 0;
-    auto open_a = [&](int s) {
-      int m0, n0;
-      origin(ka, m0, n0);
-      if constexpr (SPLITK) {
-        // the unit's share of the contraction: `kchunk` stages from k0 on (a share that starts behind K reads nothing;
-        // one that crosses K is cut by the descriptor — contraction-major operands only, the host sees to that)
-        const int k0 = split_of(ka) * p.kchunk * 64, klen = min(p.seg[0].K - k0, p.kchunk * 64);
-        if (klen > 0) sA.open(p.seg[0].A + (AK ? (long long)k0 * p.seg[0].lda : (long long)k0), p.seg[0].lda, klen, p.M,
-                              m0, wave, lane);
-        else sA.kill(p.C);
-        sA.left = p.kchunk;
-      } else {
-        sA.open(p.seg[s].A, p.seg[s].lda, p.seg[s].K, p.M, m0, wave, lane);
-      }
-      sA.seg = s;
-    };
-    auto open_b = [&](int s) {
-      int m0, n0;
-      origin(kb, m0, n0);
-      if constexpr (SPLITK) {
-        const int k0 = split_of(kb) * p.kchunk * 64, klen = min(p.seg[0].K - k0, p.kchunk * 64);
-        if (klen > 0) sB.open(p.seg[0].B + (BK ? (long long)k0 * p.seg[0].ldb : (long long)k0), p.seg[0].ldb, klen, p.N,
-                              n0, wave, lane);
-        else sB.kill(p.C);
-        sB.left = p.kchunk;
-      } else {
-        sB.open(p.seg[s].B, p.seg[s].ldb, p.seg[s].K, p.N, n0, wave, lane);
-      }
-      sB.seg = s;
-    };
-    auto adv_a = [&]() {
-      sA.soff += sA.step;
-      if (--sA.left == 0) {
-        if (sA.seg + 1 < p.nseg) open_a(sA.seg + 1);
-        else if (++ka < mine) open_a(0);
-        else sA.kill(p.C);
-      }
-    };
-    auto adv_b = [&]() {
-      sB.soff += sB.step;
-      if (--sB.left == 0) {
-        if (sB.seg + 1 < p.nseg) open_b(sB.seg + 1);
-        else if (++kb < mine) open_b(0);
-        else sB.kill(p.C);
-      }
-    };
-    // pair slot `pr`: A half at pr * 32 KB, B half 16 KB behind it; this wave's pieces 2 wave, 2 wave + 1
-    auto piece_a = [&](int pr, int q) {
-      if constexpr (TN_GEMM_ABLATE != 1)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(sA.rs, (lds_ptr_t)(smem + pr * SLOT + wave * 2048 + q * 1024), 16,
-                                                 sA.voff[q], sA.soff, 0, 0);
-      if (q == 1) adv_a();
-    };
-    auto piece_b = [&](int pr, int q) {
-      if constexpr (TN_GEMM_ABLATE != 1)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(sB.rs, (lds_ptr_t)(smem + pr * SLOT + HSLOT + wave * 2048 + q * 1024),
-                                                 16, sB.voff[q], sB.soff, 0, 0);
-      if (q == 1) adv_b();
-    };
-    open_a(0);
-    open_b(0);
-
-    Reader<AK, 4> ra(lane, wr * 128);
-    Reader<BK, 2> rb(lane, wc * 64);
-
-    Acc acc;
-    auto zero_acc = [&]() {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    };
-    zero_acc();
-
-    Frags<AK, 4> ae, ao;
-    Frags<BK, 2> be, bo;
-
-    auto read_frag = [&](auto QC, auto FC, int pr, Frags<AK, 4>& a, Frags<BK, 2>& b) {
-      constexpr int Q = decltype(QC)::value, F = decltype(FC)::value;
-      if constexpr (F < 2) rb.template read<Q, F>(smem, pr * SLOT + HSLOT, b);
-      else ra.template read<Q, F - 2>(smem, pr * SLOT, a);
-    };
-    auto read_all = [&](auto QC, int pr, Frags<AK, 4>& a, Frags<BK, 2>& b) {
-      read_frag(QC, std::integral_constant<int, 0>{}, pr, a, b);
-      read_frag(QC, std::integral_constant<int, 1>{}, pr, a, b);
-      read_frag(QC, std::integral_constant<int, 2>{}, pr, a, b);
-      read_frag(QC, std::integral_constant<int, 3>{}, pr, a, b);
-      read_frag(QC, std::integral_constant<int, 4>{}, pr, a, b);
-      read_frag(QC, std::integral_constant<int, 5>{}, pr, a, b);
-    };
-    auto mma = [&](const Frags<AK, 4>& a, const Frags<BK, 2>& b, int i, int j) {
-#if TN_GEMM_ABLATE == 3
-      asm volatile("" ::"v"(a.v[i]), "v"(b.v[j]));
-#else
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b.v[j], a.v[i], acc[i][j], 0, 0, 0);
-#endif
-    };
-    // 8 MFMAs of (ca, cb); the fragments of 16-deep step NQ of pair `npr` are read one behind each of the first six
-    // MFMAs; the pieces the table puts at positions P0 .. P0 + 7 go behind their MFMA into pair `dst` (P0 < 0: none;
-    // NQ < 0: no reads)
-    auto quarter = [&](auto NQC, auto P0C, const Frags<AK, 4>& ca, const Frags<BK, 2>& cb, Frags<AK, 4>& na,
-                       Frags<BK, 2>& nb, int npr, int dst) {
-      constexpr int P0 = decltype(P0C)::value, NQ = decltype(NQC)::value;
-      auto step = [&](auto MC) {
-        constexpr int m = decltype(MC)::value;
-        mma(ca, cb, m >> 1, m & 1);
-        TN_PIN();
-        if constexpr (NQ >= 0 && m < 6 && TN_GEMM_ABLATE != 2) {
-          read_frag(std::integral_constant<int, (NQ < 0 ? 0 : NQ)>{}, std::integral_constant<int, m>{}, npr, na, nb);
-          TN_PIN();
-        }
-        constexpr int pb = P0 < 0 ? -1 : piece32_at<PLACE32, false>(P0 + m);
-        constexpr int pa = P0 < 0 ? -1 : piece32_at<PLACE32, true>(P0 + m);
-        if constexpr (pb >= 0) {
-          piece_b(dst, pb);
-          TN_PIN();
-        }
-        if constexpr (pa >= 0) {
-          piece_a(dst, pa);
-          TN_PIN();
-        }
-      };
-      step(std::integral_constant<int, 0>{});
-      step(std::integral_constant<int, 1>{});
-      step(std::integral_constant<int, 2>{});
-      step(std::integral_constant<int, 3>{});
-      step(std::integral_constant<int, 4>{});
-      step(std::integral_constant<int, 5>{});
-      step(std::integral_constant<int, 6>{});
-      step(std::integral_constant<int, 7>{});
-    };
-    auto early_pieces = [&](int dst) {
-      auto one = [&](auto MC) {
-        constexpr int m = decltype(MC)::value;
-        constexpr int pb = piece32_at<PLACE32, false>(m), pa = piece32_at<PLACE32, true>(m);
-        if constexpr (pb >= 0) piece_b(dst, pb);
-        if constexpr (pa >= 0) piece_a(dst, pa);
-      };
-      one(std::integral_constant<int, 0>{});
-      one(std::integral_constant<int, 1>{});
-      one(std::integral_constant<int, 2>{});
-      one(std::integral_constant<int, 3>{});
-      one(std::integral_constant<int, 4>{});
-      one(std::integral_constant<int, 5>{});
-      one(std::integral_constant<int, 6>{});
-      one(std::integral_constant<int, 7>{});
-    };
-    using I0 = std::integral_constant<int, 0>;
-    using I1 = std::integral_constant<int, 1>;
-    using NONE = std::integral_constant<int, -1>;
-
-    // prologue: pairs 0..3 whole, then the positions < 8 of the set "opened at the barrier of half-stage -1" = pair 4
-#pragma unroll
-    for (int pr = 0; pr < 4; ++pr) {
-      piece_a(pr, 0);
-      piece_a(pr, 1);
-      piece_b(pr, 0);
-      piece_b(pr, 1);
-    }
-    early_pieces(4);
-    constexpr int kEarly = (Place32<PLACE32>::B[0] < 8) + (Place32<PLACE32>::B[1] < 8) + (Place32<PLACE32>::A[0] < 8) +
-                           (Place32<PLACE32>::A[1] < 8);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(12 + kEarly) : "memory");     // pair 0 landed
-    __builtin_amdgcn_s_barrier();
-    int pr = 0;          // pair slot of the current half-stage
-    int pf = 4;          // pair slot the set opened at the previous barrier fills
-
-    auto trip = [&](auto LASTC) {
-      constexpr bool LAST = decltype(LASTC)::value;
-      const int pn = pr == 4 ? 0 : pr + 1;
-      __builtin_amdgcn_s_setprio(1);
-      quarter(I1{}, std::integral_constant<int, 8>{}, ae, be, ao, bo, pr, pf);       // 16-deep step 0
-      __builtin_amdgcn_s_setprio(0);
-      K64::wait_frags(ao, bo);
-      __builtin_amdgcn_s_waitcnt(0xc07f);                 // my reads of this half-stage are complete
-      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // pair h+1 landed; h+2 .. h+4 may be in flight
-      if constexpr (TN_GEMM_ABLATE != 5) __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_s_setprio(1);
-      if constexpr (!LAST) {
-        quarter(I0{}, I0{}, ao, bo, ae, be, pn, pr);      // 16-deep step 1; the freed pair takes pair h+5
-        __builtin_amdgcn_s_setprio(0);
-        K64::wait_frags(ae, be);
-        TN_PIN();
-      } else {
-        quarter(NONE{}, NONE{}, ao, bo, ae, be, pn, pr);
-        __builtin_amdgcn_s_setprio(0);
-      }
-      pf = pr;
-      pr = pn;
-    };
-
-    const int np = p.stages;                              // HALF stages here
-    for (int kc = 0; kc < mine; ++kc) {
-      read_all(I0{}, pr, ae, be);
-      K64::wait_frags(ae, be);
-      TN_PIN();
-      for (int t = 1; t < np; ++t) trip(std::false_type{});
-      trip(std::true_type{});
-      int m0, n0;
-      origin(kc, m0, n0);
-      if constexpr (TN_GEMM_ABLATE != 4)
-        epilogue32(p, acc, smem + pf * SLOT + wave * 4096, m0 + wr * 128, n0 + wc * 64, lane);
-      zero_acc();
-      __builtin_amdgcn_s_waitcnt(0xc07f);
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" : "+v"(lane));
-      ra = Reader<AK, 4>(lane, wr * 128);
-      rb = Reader<BK, 2>(lane, wc * 64);
-      sA.set_voff(wave, lane);
-      sB.set_voff(wave, lane);
-      early_pieces(pf);
-    }
-  }
-
-  // Epilogue through LDS, 32 rows at a time: the wave parks [32 rows][64 cols] bf16 (4 KB, chunk ^= row & 7) in its
-  // share of the pair the last barrier freed and writes full 128-byte lines.
-  static __device__ __forceinline__ void epilogue32(const Params& p, Acc& acc, char* park, int wm0, int wn0, int lane) {
-    const int l31 = lane & 31, hi = lane >> 5;
-    float bias_v[2][4][4];
-    if (p.bias != nullptr) {
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int n = min(wn0 + j * 32 + 8 * g + 4 * hi, p.N - 4);
-          const uint2 w = *reinterpret_cast<const uint2*>(p.bias + n);
-          bias_v[j][g][0] = __uint_as_float(w.x << 16);
-          bias_v[j][g][1] = __uint_as_float(w.x & 0xffff0000u);
-          bias_v[j][g][2] = __uint_as_float(w.y << 16);
-          bias_v[j][g][3] = __uint_as_float(w.y & 0xffff0000u);
-        }
-    }
-    const bool acc_c = p.accumulate != 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = l31;
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          float v[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] + (p.bias != nullptr ? bias_v[j][g][e] : 0.f);
-          const int chunk = (j * 4 + g) ^ (row & 7);
-          const u32x2_t pk = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-          *reinterpret_cast<u32x2_t*>(park + row * 128 + chunk * 16 + hi * 8) = pk;
-        }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int r = it * 8 + (lane >> 3), c = lane & 7;
-        const u32x4_t pv = *reinterpret_cast<const u32x4_t*>(park + r * 128 + ((c ^ (r & 7)) << 4));
-        uint4 v = make_uint4(pv.x, pv.y, pv.z, pv.w);
-        const int m = wm0 + i * 32 + r, n = wn0 + c * 8;
-        if (m < p.M && n < p.N) {
-          bf16_t* dst = p.C + (long long)m * p.ldc + n;
-          if (acc_c) {
-            Vec16<bf16_t> o, nw;
-            o.load(dst);
-            nw.raw = v;
-            float fo[8], fn[8];
-            o.unpack(fo);
-            nw.unpack(fn);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) fn[e] += fo[e];
-            nw.pack(fn);
-            v = nw.raw;
-          }
-          *reinterpret_cast<uint4*>(dst) = v;
-        }
-      }
-      if constexpr (HAS_CT) {
-        // transposed copy: Ct[n, m]: a lane gathers 8 consecutive m of one n (64 n x 4 groups of 8 m per pass)
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-          const int n_l = it * 16 + (lane >> 2), mg = lane & 3;
-          uint32_t w[4];
-#pragma unroll
-          for (int e2 = 0; e2 < 4; ++e2) {
-            const int r0 = mg * 8 + 2 * e2, r1 = r0 + 1;
-            const uint32_t lo =
-                *reinterpret_cast<const uint16_t*>(park + r0 * 128 + ((((n_l >> 3) ^ (r0 & 7))) << 4) + (n_l & 7) * 2);
-            const uint32_t hi16 =
-                *reinterpret_cast<const uint16_t*>(park + r1 * 128 + ((((n_l >> 3) ^ (r1 & 7))) << 4) + (n_l & 7) * 2);
-            w[e2] = lo | (hi16 << 16);
-          }
-          const int n = wn0 + n_l, m = wm0 + i * 32 + mg * 8;
-          if (n < p.N && m < p.M)
-            *reinterpret_cast<uint4*>(p.Ct + (long long)n * p.ldct + m) = make_uint4(w[0], w[1], w[2], w[3]);
-        }
-      }
-    }
-  }
-};
-
-template <bool AK, bool BK, int PLACE32, bool HAS_CT>
-__global__ __launch_bounds__(NT, 2) void gemm32_kernel(const Params p) {
-  __shared__ __attribute__((aligned(1024))) char smem[LDS_BYTES];
-  Kernel32<AK, BK, PLACE32, HAS_CT>::run(p, smem);
-}
-
-// =====================================================================================================================
-// Four-wave geometry (variants 2000 + DENS): the same 256 x 256 tile, operand modes, LDS images and five-slot ring, but
-// FOUR waves (2 x 2), one per SIMD, each owning a 128 x 128 wave tile = 4 x 4 MFMA blocks with 256 accumulator registers
-// (AGPRs) out of the SIMD's 512.  Per 16-deep step a wave reads 8 fragments for 16 MFMAs instead of 6 for 8: 2/3 of the
-// LDS read traffic of the eight-wave kernel — and this chip clocks by its power budget: with the LDS reads removed the
-// eight-wave kernel runs at 2.0 instead of 1.67 GHz (profiles/r03c_gemm_ablation_cycles_vs_clock.log), so LDS bytes
-// are frequency.  With one wave per SIMD nothing hides an instruction that issues for longer than an MFMA runs (32
-// cycles), and an LDS-DMA piece does when the CU's four waves hand their pieces to the texture-address unit at the
-// same moment (they leave every barrier together).  So each wave gets ITS OWN instruction stream (template parameter W,
-// switch on the wave id) in which its 16 pieces per stage sit behind MFMAs 4 p + W: the address unit sees one piece per
-// MFMA time, never two.
-// =====================================================================================================================
-template <class F, int... I>
-__device__ __forceinline__ void static_for_impl(F& f, std::integer_sequence<int, I...>) {
-  (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-  static_for_impl(f, std::make_integer_sequence<int, N>{});
-}
-
-// The 256 accumulators of the four-wave kernel are the LITERAL registers a[0:255]: MFMA block (i, j) = a[16 (4 i + j) ..
-// + 15].  hipcc does not allocate them (every statement that touches a block lists its registers as clobbers, which also
-// makes the kernel descriptor reserve the accumulator file), so it can neither permute them at control-flow joins nor
-// spill them; the rest of the kernel stays far below 256 VGPRs and never needs the AGPR file for its own use (audited in
-// tests/test_isa_checks.py: no spill, no compiler v_accvgpr_*).  cdna_hip_programming.md 5.7 item 4.
-template <int BLK>
-__device__ __forceinline__ void acc_mfma(bf16x8_t b, bf16x8_t a) {
-#define TN_ACC_ASM(...)                                                                                   \
-  asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(b), "v"(a), "n"(16 * BLK), \
-               "n"(16 * BLK + 15)                                                                         \
-               : __VA_ARGS__)
-    if constexpr (BLK == 0) { TN_ACC_ASM("a0","a1","a2","a3","a4","a5","a6","a7","a8","a9","a10","a11","a12","a13","a14","a15"); }
-    if constexpr (BLK == 1) { TN_ACC_ASM("a16","a17","a18","a19","a20","a21","a22","a23","a24","a25","a26","a27","a28","a29","a30","a31"); }
-    if constexpr (BLK == 2) { TN_ACC_ASM("a32","a33","a34","a35","a36","a37","a38","a39","a40","a41","a42","a43","a44","a45","a46","a47"); }
-    if constexpr (BLK == 3) { TN_ACC_ASM("a48","a49","a50","a51","a52","a53","a54","a55","a56","a57","a58","a59","a60","a61","a62","a63"); }
-    if constexpr (BLK == 4) { TN_ACC_ASM("a64","a65","a66","a67","a68","a69","a70","a71","a72","a73","a74","a75","a76","a77","a78","a79"); }
-    if constexpr (BLK == 5) { TN_ACC_ASM("a80","a81","a82","a83","a84","a85","a86","a87","a88","a89","a90","a91","a92","a93","a94","a95"); }
-    if constexpr (BLK == 6) { TN_ACC_ASM("a96","a97","a98","a99","a100","a101","a102","a103","a104","a105","a106","a107","a108","a109","a110","a111"); }
-    if constexpr (BLK == 7) { TN_ACC_ASM("a112","a113","a114","a115","a116","a117","a118","a119","a120","a121","a122","a123","a124","a125","a126","a127"); }
-    if constexpr (BLK == 8) { TN_ACC_ASM("a128","a129","a130","a131","a132","a133","a134","a135","a136","a137","a138","a139","a140","a141","a142","a143"); }
-    if constexpr (BLK == 9) { TN_ACC_ASM("a144","a145","a146","a147","a148","a149","a150","a151","a152","a153","a154","a155","a156","a157","a158","a159"); }
-    if constexpr (BLK == 10) { TN_ACC_ASM("a160","a161","a162","a163","a164","a165","a166","a167","a168","a169","a170","a171","a172","a173","a174","a175"); }
-    if constexpr (BLK == 11) { TN_ACC_ASM("a176","a177","a178","a179","a180","a181","a182","a183","a184","a185","a186","a187","a188","a189","a190","a191"); }
-    if constexpr (BLK == 12) { TN_ACC_ASM("a192","a193","a194","a195","a196","a197","a198","a199","a200","a201","a202","a203","a204","a205","a206","a207"); }
-    if constexpr (BLK == 13) { TN_ACC_ASM("a208","a209","a210","a211","a212","a213","a214","a215","a216","a217","a218","a219","a220","a221","a222","a223"); }
-    if constexpr (BLK == 14) { TN_ACC_ASM("a224","a225","a226","a227","a228","a229","a230","a231","a232","a233","a234","a235","a236","a237","a238","a239"); }
-    if constexpr (BLK == 15) { TN_ACC_ASM("a240","a241","a242","a243","a244","a245","a246","a247","a248","a249","a250","a251","a252","a253","a254","a255"); }
-#undef TN_ACC_ASM
-}
-template <int BLK>
-__device__ __forceinline__ void acc_zero() {
-#define TN_ACC_ASM(...)                                                                                              \
-  asm volatile("v_accvgpr_write_b32 a[%c0], 0\n\tv_accvgpr_write_b32 a[%c0+1], 0\n\tv_accvgpr_write_b32 a[%c0+2], 0\n\t"  \
-               "v_accvgpr_write_b32 a[%c0+3], 0\n\tv_accvgpr_write_b32 a[%c0+4], 0\n\tv_accvgpr_write_b32 a[%c0+5], 0\n\t" \
-               "v_accvgpr_write_b32 a[%c0+6], 0\n\tv_accvgpr_write_b32 a[%c0+7], 0\n\tv_accvgpr_write_b32 a[%c0+8], 0\n\t" \
-               "v_accvgpr_write_b32 a[%c0+9], 0\n\tv_accvgpr_write_b32 a[%c0+10], 0\n\tv_accvgpr_write_b32 a[%c0+11], 0\n\t" \
-               "v_accvgpr_write_b32 a[%c0+12], 0\n\tv_accvgpr_write_b32 a[%c0+13], 0\n\tv_accvgpr_write_b32 a[%c0+14], 0\n\t" \
-               "v_accvgpr_write_b32 a[%c0+15], 0" ::"n"(16 * BLK)                                                       \
-               : __VA_ARGS__)
-    if constexpr (BLK == 0) { TN_ACC_ASM("a0","a1","a2","a3","a4","a5","a6","a7","a8","a9","a10","a11","a12","a13","a14","a15"); }
-    if constexpr (BLK == 1) { TN_ACC_ASM("a16","a17","a18","a19","a20","a21","a22","a23","a24","a25","a26","a27","a28","a29","a30","a31"); }
-    if constexpr (BLK == 2) { TN_ACC_ASM("a32","a33","a34","a35","a36","a37","a38","a39","a40","a41","a42","a43","a44","a45","a46","a47"); }
-    if constexpr (BLK == 3) { TN_ACC_ASM("a48","a49","a50","a51","a52","a53","a54","a55","a56","a57","a58","a59","a60","a61","a62","a63"); }
-    if constexpr (BLK == 4) { TN_ACC_ASM("a64","a65","a66","a67","a68","a69","a70","a71","a72","a73","a74","a75","a76","a77","a78","a79"); }
-    if constexpr (BLK == 5) { TN_ACC_ASM("a80","a81","a82","a83","a84","a85","a86","a87","a88","a89","a90","a91","a92","a93","a94","a95"); }
-    if constexpr (BLK == 6) { TN_ACC_ASM("a96","a97","a98","a99","a100","a101","a102","a103","a104","a105","a106","a107","a108","a109","a110","a111"); }
-    if constexpr (BLK == 7) { TN_ACC_ASM("a112","a113","a114","a115","a116","a117","a118","a119","a120","a121","a122","a123","a124","a125","a126","a127"); }
-    if constexpr (BLK == 8) { TN_ACC_ASM("a128","a129","a130","a131","a132","a133","a134","a135","a136","a137","a138","a139","a140","a141","a142","a143"); }
-    if constexpr (BLK == 9) { TN_ACC_ASM("a144","a145","a146","a147","a148","a149","a150","a151","a152","a153","a154","a155","a156","a157","a158","a159"); }
-    if constexpr (BLK == 10) { TN_ACC_ASM("a160","a161","a162","a163","a164","a165","a166","a167","a168","a169","a170","a171","a172","a173","a174","a175"); }
-    if constexpr (BLK == 11) { TN_ACC_ASM("a176","a177","a178","a179","a180","a181","a182","a183","a184","a185","a186","a187","a188","a189","a190","a191"); }
-    if constexpr (BLK == 12) { TN_ACC_ASM("a192","a193","a194","a195","a196","a197","a198","a199","a200","a201","a202","a203","a204","a205","a206","a207"); }
-    if constexpr (BLK == 13) { TN_ACC_ASM("a208","a209","a210","a211","a212","a213","a214","a215","a216","a217","a218","a219","a220","a221","a222","a223"); }
-    if constexpr (BLK == 14) { TN_ACC_ASM("a224","a225","a226","a227","a228","a229","a230","a231","a232","a233","a234","a235","a236","a237","a238","a239"); }
-    if constexpr (BLK == 15) { TN_ACC_ASM("a240","a241","a242","a243","a244","a245","a246","a247","a248","a249","a250","a251","a252","a253","a254","a255"); }
-#undef TN_ACC_ASM
-}
-// one accumulator register into a VGPR (epilogue; the caller has let the matrix pipe drain first)
-template <int IDX>
-__device__ __forceinline__ float acc_read() {
-  float v;
-  asm volatile("v_accvgpr_read_b32 %0, a[%c1]" : "=v"(v) : "n"(IDX));
-  return v;
-}
-
-// timing experiments on this kernel (bit mask, results garbage): 1 no DMA, 2 no fragment reads, 4 no barrier, 8 no vmcnt
-// wait, 16 no epilogue stores
-#ifndef TN_GEMM_ABL4
-#define TN_GEMM_ABL4 0
-#endif
-
-template <bool KMAJ>
-struct Stream4 {
-  __amdgpu_buffer_rsrc_t rs;
-  int soff, step, left, seg, ld2;
-  int qstep;     // byte offset between pieces q and q + 2
-  int voff[2];   // per-lane byte offsets of pieces 0 and 1 (piece q = voff[q & 1] + (q >> 1) * qstep)
-
-  __device__ __forceinline__ void set_voff(int wave, int lane) {
-    if constexpr (!KMAJ) {
-      // piece q = rows 64 wave + 8 q + (lane >> 3); chunk (lane & 7) ^ ((row >> 1) & 7) depends on q & 1 only
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int row = wave * 64 + q * 8 + (lane >> 3);
-        voff[q] = row * ld2 + (((lane & 7) ^ ((row >> 1) & 7)) << 4);
-      }
-      qstep = 16 * ld2;
-    } else {
-      // piece q = k-rows 16 wave + 2 q + (lane >> 5); k & 3 depends on q & 1 only
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int k = wave * 16 + q * 2 + (lane >> 5);
-        const int u = lane & 31;
-        voff[q] = k * ld2 + ((((u >> 2) ^ (k & 3)) << 6) | ((u & 3) << 4));
-      }
-      qstep = 4 * ld2;
-    }
-  }
-  __device__ __forceinline__ void open(const bf16_t* X, long long ld, int K, int R, int origin, int wave, int lane) {
-    ld2 = (int)(ld * 2);
-    if constexpr (!KMAJ) {
-      const long long bytes = (long long)(R - origin) * ld2;
-      rs = __builtin_amdgcn_make_buffer_rsrc((void*)(X + (long long)origin * ld), 0, (int)min(bytes, 0x7fffffffLL),
-                                             0x00020000);
-      step = 128;
-    } else {
-      const long long bytes = ((long long)(K - 1) * ld + (R - origin)) * 2;
-      rs = __builtin_amdgcn_make_buffer_rsrc((void*)(X + origin), 0, (int)min(bytes, 0x7fffffffLL), 0x00020000);
-      step = 64 * ld2;
-    }
-    set_voff(wave, lane);
-    soff = 0;
-    left = (K + 63) >> 6;
-  }
-  __device__ __forceinline__ void kill(const void* any) {
-    rs = __builtin_amdgcn_make_buffer_rsrc((void*)any, 0, 0, 0x00020000);
-    soff = 0;
-    step = 0;
-    left = 0x7fffffff;
-  }
-};
-
-// DENS = pieces the CU issues per MFMA time: 1 -> wave W's piece p behind MFMA 4 p + W (B over the first half of the
-// stage, A over the second); 2 -> behind MFMA 2 p + (W >> 1) (waves 0/1 and 2/3 share a slot; everything in the first half)
-template <bool AK, bool BK, int DENS, bool HAS_CT>
-struct Kernel4 {
-  static constexpr bool SPLITK = false;
-  // Every LDS read of this kernel is inline asm: with plain loads hipcc's waitcnt pass cannot tell the ring's slots apart
-  // and puts `s_waitcnt vmcnt(5)` in front of some fragment reads ("a pending LDS-DMA may alias this load"), which
-  // drains the DMA queue twice per stage — and with one wave per SIMD nothing covers that.  The reads are retired by
-  // wait_frags() (form (ii) of cdna_hip_programming.md 5.7: the wait names every destination "+v").
-  template <bool KMAJ>
-  struct F4 {
-    u32x4_t r[4];          // ROW: one ds_read_b128 per fragment
-    u32x2_t h[4][2];       // KMAJ: two ds_read_b64_tr_b16 per fragment
-    bf16x8_t v[4];
-  };
-  template <bool KMAJ>
-  struct Reader {
-    int x[4];
-    __device__ __forceinline__ Reader(int lane, int row0) {
-      const int l31 = lane & 31, hi = lane >> 5;
-      if constexpr (!KMAJ) {
-        const int f = (l31 >> 1) & 7;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) x[q] = (row0 + l31) * 128 + (((2 * q + hi) ^ f) << 4);
-      } else {
-        const int s4 = lane & 15, j = s4 >> 2, w = s4 & 3, half = (lane >> 4) & 1;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) x[b] = (8 * hi + j) * 512 + half * 32 + w * 8 + ((((row0 >> 5) + b) ^ j) << 6);
-      }
-    }
-    template <int Q, int B>
-    __device__ __forceinline__ void read(const char* smem, int sbase, F4<KMAJ>& f) const {
-      const uint32_t base = (uint32_t)(size_t)(lds_ptr_t)smem + (uint32_t)sbase;
-      if constexpr (!KMAJ) {
-        f.r[B] = ds_b128<B * 4096>(base + x[Q]);
-      } else {
-        f.h[B][0] = ds_tr16<(16 * Q) * 512>(base + x[B]);
-        f.h[B][1] = ds_tr16<(16 * Q + 4) * 512>(base + x[B]);
-      }
-    }
-  };
-  template <bool KMAJ>
-  static __device__ __forceinline__ void retire(F4<KMAJ>& f) {      // (after the wait below)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      if constexpr (!KMAJ) {
-        f.v[i] = __builtin_bit_cast(bf16x8_t, f.r[i]);
-      } else {
-        const u32x4_t t = {f.h[i][0].x, f.h[i][0].y, f.h[i][1].x, f.h[i][1].y};
-        f.v[i] = __builtin_bit_cast(bf16x8_t, t);
-      }
-    }
-  }
-#define TN_F4_ROW(f) "+v"(f.r[0]), "+v"(f.r[1]), "+v"(f.r[2]), "+v"(f.r[3])
-#define TN_F4_KMAJ(f)                                                                                        \
-  "+v"(f.h[0][0]), "+v"(f.h[0][1]), "+v"(f.h[1][0]), "+v"(f.h[1][1]), "+v"(f.h[2][0]), "+v"(f.h[2][1]), \
-      "+v"(f.h[3][0]), "+v"(f.h[3][1])
-  static __device__ __forceinline__ void wait_frags(F4<AK>& a, F4<BK>& b) {
-    if constexpr (AK && BK) asm volatile("s_waitcnt lgkmcnt(0)" : TN_F4_KMAJ(a), TN_F4_KMAJ(b));
-    else if constexpr (!AK && BK) asm volatile("s_waitcnt lgkmcnt(0)" : TN_F4_ROW(a), TN_F4_KMAJ(b));
-    else if constexpr (AK && !BK) asm volatile("s_waitcnt lgkmcnt(0)" : TN_F4_KMAJ(a), TN_F4_ROW(b));
-    else asm volatile("s_waitcnt lgkmcnt(0)" : TN_F4_ROW(a), TN_F4_ROW(b));
-    retire(a);
-    retire(b);
-  }
-#undef TN_F4_ROW
-#undef TN_F4_KMAJ
-
-  // piece index (0..7 = B, 8..15 = A) wave W issues behind MFMA `pos` (0..63 counted from the barrier), or -1.
-  //   DENS 1: behind MFMA 4 p + W                    (one piece per MFMA time on the CU, spread over the whole stage)
-  //   DENS 2: behind MFMA 2 p + (W >> 1)             (two per MFMA time, all in the first half of the stage)
-  //   DENS 3: quarter p >> 2, MFMA 8 + 2 (p & 3) + (W >> 1): only in the second half of each quarter, where no
-  //           fragment read shares the gap
-  template <int W> static constexpr int piece_at4(int pos) {
-    if constexpr (DENS == 1) {
-      return (pos >= W && (pos - W) % 4 == 0 && (pos - W) / 4 < 16) ? (pos - W) / 4 : -1;
-    } else if constexpr (DENS == 2) {
-      const int o = W >> 1;
-      return (pos >= o && (pos - o) % 2 == 0 && (pos - o) / 2 < 16) ? (pos - o) / 2 : -1;
-    } else {
-      const int q = pos >> 4, m = (pos & 15) - 8 - (W >> 1);
-      return (m >= 0 && m < 8 && m % 2 == 0) ? 4 * q + m / 2 : -1;
-    }
-  }
-
-  static __device__ __forceinline__ void run(const Params& p, char* smem) {
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wr = wave >> 1, wc = wave & 1;
-    int lane = threadIdx.x & 63;
-    const unsigned long long t_start = (TN_GEMM_ABL4 & 32) ? __builtin_amdgcn_s_memtime() : 0ull;
-
-    const int bid = blockIdx.x, G = gridDim.x;
-    const int tiles = p.ntiles;
-    const int mine = ((SPLITK ? tiles * p.splitk : tiles) - bid + G - 1) / G;
-    auto origin = [&](int k, int& m0, int& n0) {
-      int tm, tn, u = bid + k * G;
-      if constexpr (SPLITK) u -= (u / tiles) * tiles;
-      tile_of_block(p.tile0 + u, p.nbm, p.nbn, tm, tn);
-      m0 = tm * BM;
-      n0 = tn * BN;
-    };
-    auto split_of = [&](int k) { return (bid + k * G) / tiles; };
-
-    Stream4<AK> sA;
-    Stream4<BK> sB;
-    int ka = 0, kb = 0;
-    auto open_a = [&](int s) {
-      int m0, n0;
-      origin(ka, m0, n0);
-      if constexpr (SPLITK) {
-        // the unit's share of the contraction: `kchunk` stages from k0 on (a share that starts behind K reads nothing;
-        // one that crosses K is cut by the descriptor — contraction-major operands only, the host sees to that)
-        const int k0 = split_of(ka) * p.kchunk * 64, klen = min(p.seg[0].K - k0, p.kchunk * 64);
-        if (klen > 0) sA.open(p.seg[0].A + (AK ? (long long)k0 * p.seg[0].lda : (long long)k0), p.seg[0].lda, klen, p.M,
-                              m0, wave, lane);
-        else sA.kill(p.C);
-        sA.left = p.kchunk;
-      } else {
-        sA.open(p.seg[s].A, p.seg[s].lda, p.seg[s].K, p.M, m0, wave, lane);
-      }
-      sA.seg = s;
-    };
-    auto open_b = [&](int s) {
-      int m0, n0;
-      origin(kb, m0, n0);
-      if constexpr (SPLITK) {
-        const int k0 = split_of(kb) * p.kchunk * 64, klen = min(p.seg[0].K - k0, p.kchunk * 64);
-        if (klen > 0) sB.open(p.seg[0].B + (BK ? (long long)k0 * p.seg[0].ldb : (long long)k0), p.seg[0].ldb, klen, p.N,
-                              n0, wave, lane);
-        else sB.kill(p.C);
-        sB.left = p.kchunk;
-      } else {
-        sB.open(p.seg[s].B, p.seg[s].ldb, p.seg[s].K, p.N, n0, wave, lane);
-      }
-      sB.seg = s;
-    };
-    auto adv_a = [&]() {
-      sA.soff += sA.step;
-      if (__builtin_expect(--sA.left == 0, 0)) {
-        if (sA.seg + 1 < p.nseg) open_a(sA.seg + 1);
-        else if (++ka < mine) open_a(0);
-        else sA.kill(p.C);
-      }
-    };
-    auto adv_b = [&]() {
-      sB.soff += sB.step;
-      if (__builtin_expect(--sB.left == 0, 0)) {
-        if (sB.seg + 1 < p.nseg) open_b(sB.seg + 1);
-        else if (++kb < mine) open_b(0);
-        else sB.kill(p.C);
-      }
-    };
-    // this wave's piece q (0..7) of an operand stage: 8 KB per wave, 1 KB per piece
-    auto piece_a = [&](int slot, int q) {
-      if constexpr (!(TN_GEMM_ABL4 & 1))
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(sA.rs, (lds_ptr_t)(smem + slot * SLOT + wave * 8192 + q * 1024), 16,
-                                                 sA.voff[q & 1], sA.soff + (q >> 1) * sA.qstep, 0, 0);
-      if (q == 7) adv_a();
-    };
-    auto piece_b = [&](int slot, int q) {
-      if constexpr (!(TN_GEMM_ABL4 & 1))
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(sB.rs, (lds_ptr_t)(smem + slot * SLOT + wave * 8192 + q * 1024), 16,
-                                                 sB.voff[q & 1], sB.soff + (q >> 1) * sB.qstep, 0, 0);
-      if (q == 7) adv_b();
-    };
-    open_a(0);
-    open_b(0);
-
-    Reader<AK> ra(lane, wr * 128);
-    Reader<BK> rb(lane, wc * 128);
-
-    auto zero_acc = [&]() {
-      static_for<16>([&](auto BC) { acc_zero<decltype(BC)::value>(); });
-      asm volatile("s_nop 3");
-    };
-    zero_acc();
-
-    F4<AK> ae, ao;
-    F4<BK> be, bo;
-
-    // fragment f (0..3 = B blocks, 4..7 = A blocks) of quarter Q
-    auto read_frag = [&](auto QC, auto FC, int sa, int sb, F4<AK>& a, F4<BK>& b) {
-      constexpr int Q = decltype(QC)::value, F = decltype(FC)::value;
-      if constexpr (F < 4) rb.template read<Q, F>(smem, sb * SLOT, b);
-      else ra.template read<Q, F - 4>(smem, sa * SLOT, a);
-    };
-    auto read_all = [&](auto QC, int sa, int sb, F4<AK>& a, F4<BK>& b) {
-      read_frag(QC, std::integral_constant<int, 0>{}, sa, sb, a, b);
-      read_frag(QC, std::integral_constant<int, 1>{}, sa, sb, a, b);
-      read_frag(QC, std::integral_constant<int, 2>{}, sa, sb, a, b);
-      read_frag(QC, std::integral_constant<int, 3>{}, sa, sb, a, b);
-      read_frag(QC, std::integral_constant<int, 4>{}, sa, sb, a, b);
-      read_frag(QC, std::integral_constant<int, 5>{}, sa, sb, a, b);
-      read_frag(QC, std::integral_constant<int, 6>{}, sa, sb, a, b);
-      read_frag(QC, std::integral_constant<int, 7>{}, sa, sb, a, b);
-    };
-    auto mma = [&](const F4<AK>& a, const F4<BK>& b, auto MC) {      // MFMA m of a quarter: block (m >> 2, m & 3)
-      constexpr int m = decltype(MC)::value;
-      acc_mfma<m>(b.v[m & 3], a.v[m >> 2]);
-    };
-    // One quarter = the 16 MFMAs of (ca, cb), positions P0 .. P0 + 15 behind the barrier; the 8 fragments of quarter NQ
-    // of slots (nsa, nsb) are read behind the first eight MFMAs (NQ < 0: none); the wave's pieces go behind their MFMAs.
-    // (A single stream with a scalar branch per gap on the wave's parity was tried for DENS 3: 1.32 vs 1.39-1.45 PF —
-    //  with one wave per SIMD a taken branch is an exposed instruction-buffer refill.)
-    auto quarter = [&](auto WC, auto NQC, auto P0C, const F4<AK>& ca, const F4<BK>& cb, F4<AK>& na, F4<BK>& nb, int nsa,
-                       int nsb, int dst_b, int dst_a) {
-      constexpr int W = decltype(WC)::value, P0 = decltype(P0C)::value, NQ = decltype(NQC)::value;
-      auto step = [&](auto MC) {
-        constexpr int m = decltype(MC)::value;
-        mma(ca, cb, MC);
-        TN_PIN();
-        if constexpr (NQ >= 0 && m < 8 && !(TN_GEMM_ABL4 & 2)) {
-          read_frag(std::integral_constant<int, (NQ < 0 ? 0 : NQ)>{}, std::integral_constant<int, m>{}, nsa, nsb, na, nb);
-          TN_PIN();
-        }
-        constexpr int pc = P0 < 0 ? -1 : piece_at4<W>(P0 + m);
-        if constexpr (pc >= 0 && pc < 8) {
-          piece_b(dst_b, pc);
-          TN_PIN();
-        }
-        if constexpr (pc >= 8) {
-          piece_a(dst_a, pc - 8);
-          TN_PIN();
-        }
-      };
-      static_for<16>(step);
-    };
-    // The pieces of positions 0..15 (the quarter behind the barrier) in one burst: prologue / behind a tile's epilogue.
-    // They are the same pieces for every wave (B pieces 0..3 for DENS = 1, 0..7 for DENS = 2).
-    constexpr int kEarly = DENS == 2 ? 8 : 4;
-    static_assert(piece_at4<0>(15) < kEarly && piece_at4<3>(15) == kEarly - 1, "pieces 0 .. kEarly - 1 sit in the first quarter");
-    auto early_pieces = [&](int dst_b) {
-#pragma unroll
-      for (int q = 0; q < kEarly; ++q) piece_b(dst_b, q);
-    };
-    auto next = [](int s, int d) { s += d; return s >= 5 ? s - 5 : s; };
-    using I0 = std::integral_constant<int, 0>;
-    using I1 = std::integral_constant<int, 1>;
-    using I2 = std::integral_constant<int, 2>;
-    using I3 = std::integral_constant<int, 3>;
-    using NONE = std::integral_constant<int, -1>;
-
-    // prologue: A0 B0 A1 -> slots 0..2, then the early part of the set {B(1) -> slot 3, A(2) -> slot 4}
-#pragma unroll
-    for (int q = 0; q < 8; ++q) piece_a(0, q);
-#pragma unroll
-    for (int q = 0; q < 8; ++q) piece_b(1, q);
-#pragma unroll
-    for (int q = 0; q < 8; ++q) piece_a(2, q);
-    early_pieces(3);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + kEarly) : "memory");     // A(0), B(0) landed
-    __builtin_amdgcn_s_barrier();
-    int sa = 0, sb = 1;
-    int pa = 4, pb = 3;
-
-    // One stage in wave W's instruction stream.  LAST = last stage of a tile: its final quarter neither opens the next
-    // piece set (the two slots it frees first serve as the epilogue's park) nor reads ahead.
-    auto trip = [&](auto WC, auto LASTC) {
-      constexpr bool LAST = decltype(LASTC)::value;
-      const int sa1 = next(sa, 2), sb1 = next(sb, 2);
-      quarter(WC, I1{}, std::integral_constant<int, 16>{}, ae, be, ao, bo, sa, sb, pb, pa);
-      wait_frags(ao, bo);
-      TN_PIN();
-      quarter(WC, I2{}, std::integral_constant<int, 32>{}, ao, bo, ae, be, sa, sb, pb, pa);
-      wait_frags(ae, be);
-      TN_PIN();
-      quarter(WC, I3{}, std::integral_constant<int, 48>{}, ae, be, ao, bo, sa, sb, pb, pa);
-      wait_frags(ao, bo);
-      if constexpr (!(TN_GEMM_ABL4 & 8))
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // A(t+1), B(t+1) landed; A(t+2) may still be in flight
-      if constexpr (!(TN_GEMM_ABL4 & 4)) __builtin_amdgcn_s_barrier();
-      if constexpr (!LAST) {
-        quarter(WC, I0{}, I0{}, ao, bo, ae, be, sa1, sb1, sa, sb);
-        wait_frags(ae, be);
-        TN_PIN();
-      } else {
-        quarter(WC, NONE{}, NONE{}, ao, bo, ae, be, sa1, sb1, sa, sb);
-      }
-      pb = sa;
-      pa = sb;
-      sa = sa1;
-      sb = sb1;
-    };
-    const int np = p.stages;
-    // all stages of one tile in wave W's instruction stream (the accumulators are literal AGPRs the compiler does not
-    // manage, so the four streams join without any register shuffling)
-    auto stages = [&](auto WC) {
-      for (int t = 1; t < np; ++t) trip(WC, std::false_type{});
-      trip(WC, std::true_type{});
-    };
-
-    for (int kc = 0; kc < mine; ++kc) {
-      read_all(I0{}, sa, sb, ae, be);
-      wait_frags(ae, be);
-      TN_PIN();
-      switch (wave) {
-        case 0: stages(std::integral_constant<int, 0>{}); break;
-        case 1: stages(std::integral_constant<int, 1>{}); break;
-        case 2: stages(std::integral_constant<int, 2>{}); break;
-        default: stages(std::integral_constant<int, 3>{}); break;
-      }
-      int m0, n0;
-      origin(kc, m0, n0);
-      if constexpr (TN_GEMM_ABLATE != 4)
-        epilogue4(p, smem + (wave < 2 ? pb : pa) * SLOT + (wave & 1) * 16384, m0 + wr * 128, n0 + wc * 128, lane);
-      zero_acc();
-      __builtin_amdgcn_s_waitcnt(0xc07f);
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" : "+v"(lane));
-      ra = Reader<AK>(lane, wr * 128);
-      rb = Reader<BK>(lane, wc * 128);
-      sA.set_voff(wave, lane);
-      sB.set_voff(wave, lane);
-      early_pieces(pb);
-    }
-    if constexpr ((TN_GEMM_ABL4 & 32) != 0) {      // shader cycles this wave lived, per workgroup and wave
-      const unsigned long long t_end = __builtin_amdgcn_s_memtime();
-      if (lane == 0) reinterpret_cast<unsigned long long*>(p.C)[blockIdx.x * 4 + wave] = t_end - t_start;
-    }
-  }
-
-  // Epilogue through LDS, 64 rows at a time: the wave parks [64 rows][128 cols] bf16 (16 KB, 256-byte rows, 16-byte
-  // chunk ^= row & 15) in its share of the two slots the last barrier freed and writes two full 128-byte lines per row.
-  static __device__ __forceinline__ void epilogue4(const Params& p, char* park, int wm0, int wn0, int lane) {
-    const int l31 = lane & 31, hi = lane >> 5;
-    const bool acc_c = p.accumulate != 0;
-    asm volatile("s_nop 15\n\ts_nop 15");                  // the last MFMAs have written their accumulators
-    static_for<2>([&](auto HC) {
-      constexpr int half = decltype(HC)::value;
-      static_for<32>([&](auto IC) {
-        constexpr int idx = decltype(IC)::value;
-        constexpr int ii = idx >> 4, j = (idx >> 2) & 3, g = idx & 3;
-        constexpr int i = half * 2 + ii;
-        constexpr int base = 16 * (4 * i + j) + 4 * g;
-        const int row = ii * 32 + l31;
-        float v[4] = {acc_read<base>(), acc_read<base + 1>(), acc_read<base + 2>(), acc_read<base + 3>()};
-        if (p.bias != nullptr) {
-          const int n = min(wn0 + j * 32 + 8 * g + 4 * hi, p.N - 4);    // (columns >= N are never stored)
-          const uint2 w = *reinterpret_cast<const uint2*>(p.bias + n);
-          v[0] += __uint_as_float(w.x << 16);
-          v[1] += __uint_as_float(w.x & 0xffff0000u);
-          v[2] += __uint_as_float(w.y << 16);
-          v[3] += __uint_as_float(w.y & 0xffff0000u);
-        }
-        const int chunk = (j * 4 + g) ^ (row & 15);
-        const u32x2_t pk = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-        *reinterpret_cast<u32x2_t*>(park + row * 256 + chunk * 16 + hi * 8) = pk;
-      });
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll 4
-      for (int it = 0; it < 16; ++it) {
-        const int r = it * 4 + (lane >> 4), c = lane & 15;
-        const u32x4_t pv = *reinterpret_cast<const u32x4_t*>(park + r * 256 + ((c ^ (r & 15)) << 4));
-        uint4 v = make_uint4(pv.x, pv.y, pv.z, pv.w);
-        const int m = wm0 + half * 64 + r, n = wn0 + c * 8;
-        if (m < p.M && n < p.N && !(TN_GEMM_ABL4 & 16)) {
-          bf16_t* dst = p.C + (long long)m * p.ldc + n;
-          if (acc_c) {
-            Vec16<bf16_t> o, nw;
-            o.load(dst);
-            nw.raw = v;
-            float fo[8], fn[8];
-            o.unpack(fo);
-            nw.unpack(fn);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) fn[e] += fo[e];
-            nw.pack(fn);
-            v = nw.raw;
-          }
-          *reinterpret_cast<uint4*>(dst) = v;
-        }
-      }
-      if constexpr (HAS_CT) {
-        // transposed copy: Ct[n, m]: a lane gathers 8 consecutive m of one n (128 n x 8 groups of 8 m per half)
-#pragma unroll 2
-        for (int it = 0; it < 16; ++it) {
-          const int n_l = it * 8 + (lane >> 3), mg = lane & 7;
-          uint32_t w[4];
-#pragma unroll
-          for (int e2 = 0; e2 < 4; ++e2) {
-            const int r0 = mg * 8 + 2 * e2, r1 = r0 + 1;
-            const uint32_t lo =
-                *reinterpret_cast<const uint16_t*>(park + r0 * 256 + ((((n_l >> 3) ^ (r0 & 15))) << 4) + (n_l & 7) * 2);
-            const uint32_t hi16 =
-                *reinterpret_cast<const uint16_t*>(park + r1 * 256 + ((((n_l >> 3) ^ (r1 & 15))) << 4) + (n_l & 7) * 2);
-            w[e2] = lo | (hi16 << 16);
-          }
-          const int n = wn0 + n_l, m = wm0 + half * 64 + mg * 8;
-          if (n < p.N && m < p.M)
-            *reinterpret_cast<uint4*>(p.Ct + (long long)n * p.ldct + m) = make_uint4(w[0], w[1], w[2], w[3]);
-        }
-      }
-    });
-  }
-};
-
-template <bool AK, bool BK, int DENS, bool HAS_CT>
-__global__ __launch_bounds__(256, 1) void gemm4_kernel(const Params p) {
-  __shared__ __attribute__((aligned(1024))) char smem[LDS_BYTES];
-  Kernel4<AK, BK, DENS, HAS_CT>::run(p, smem);
-}
-
 // kernel-development switch: TN_GEMM_VARIANT = 100 * PLACE + 10 * ASYM + ILV (scripts/gemm_sweep.py sweeps it)
 #ifndef TN_GEMM_DEFAULT_VARIANT
 #define TN_GEMM_DEFAULT_VARIANT 601
 #endif
+
+// The half-stage ring (Kernel32) and the four-wave / AGPR-accumulator geometry (Kernel4) are measured variants, not product:
+// scripts/variants/gemm_kernel32_kernel4.inc, compiled in only by variant builds.
+#if defined(TN_GEMM_ALL_VARIANTS) || TN_GEMM_DEFAULT_VARIANT >= 1000
+#define TN_GEMM_HAVE_VARIANT_KERNELS 1
+#include "../../scripts/variants/gemm_kernel32_kernel4.inc"
+#endif
+
 
 template <bool AK, bool BK, bool HAS_CT>
 static int launch_variant(int variant, dim3 grid, hipStream_t st, Params p) {
@@ -1790,12 +821,13 @@ static int launch_variant(int variant, dim3 grid, hipStream_t st, Params p) {
   }
 #endif
   (void)variant;
-  if constexpr (TN_GEMM_DEFAULT_VARIANT >= 2000) {
-    p.stages = stages64;
-    hipLaunchKernelGGL((gemm4_kernel<AK, BK, TN_GEMM_DEFAULT_VARIANT - 2000, HAS_CT>), grid, dim3(256), 0, st, p);
-  } else if constexpr (TN_GEMM_DEFAULT_VARIANT >= 1000)
-    hipLaunchKernelGGL((gemm32_kernel<AK, BK, TN_GEMM_DEFAULT_VARIANT - 1000, HAS_CT>), grid, dim3(NT), 0, st, p);
-  else {
+#if TN_GEMM_DEFAULT_VARIANT >= 2000
+  p.stages = stages64;
+  hipLaunchKernelGGL((gemm4_kernel<AK, BK, TN_GEMM_DEFAULT_VARIANT - 2000, HAS_CT>), grid, dim3(256), 0, st, p);
+#elif TN_GEMM_DEFAULT_VARIANT >= 1000
+  hipLaunchKernelGGL((gemm32_kernel<AK, BK, TN_GEMM_DEFAULT_VARIANT - 1000, HAS_CT>), grid, dim3(NT), 0, st, p);
+#else
+  {
     p.stages = stages64;
     if (p.splitk > 1) {
       if constexpr (!HAS_CT) {
@@ -1815,6 +847,7 @@ static int launch_variant(int variant, dim3 grid, hipStream_t st, Params p) {
       hipLaunchKernelGGL((gemm_kernel<AK, BK, DPL, DAS, DIL, HAS_CT>), grid, dim3(NT), 0, st, p);
     }
   }
+#endif
   return 0;
 #undef TN_V
 #undef TN_V32
@@ -1825,6 +858,13 @@ static int launch_variant(int variant, dim3 grid, hipStream_t st, Params p) {
 }  // namespace tn
 
 extern "C" {
+
+// One workgroup per CU walking a fixed tile list (1, default) or one workgroup per tile (0).  A host that runs collectives
+// beside the compute (RCCL kernels hold CUs) selects 0 — touchnet_amd/bin/train.py — instead of changing the process
+// environment; TN_GEMM_PERSIST in the environment still overrides it.
+static int g_persistent = 1;
+void tn_gemm_set_persistent(int on) { g_persistent = on ? 1 : 0; }
+int tn_gemm_get_persistent(void) { return g_persistent; }
 
 // General entry: C[M,N] = sum_s opA_s · opB_s^T (+ bias) (+ C if accumulate); optional transposed copy Ct[N,M].
 //   a_kmaj / b_kmaj: 0 = operand stored [rows, K] (contraction-contiguous), 1 = stored [K, rows] (contraction-major).
@@ -1913,8 +953,8 @@ static int gemm_launch(const void* const* A, const void* const* B, const long lo
     p.kchunk = (p.stages + splitk - 1) / splitk;
     p.ws = (float*)workspace;
   }
-  const char* pe = getenv("TN_GEMM_PERSIST");
-  const bool persist = pe ? atoi(pe) != 0 : true;
+  const char* pe = getenv("TN_GEMM_PERSIST");        // (the environment wins: kernel-development A/B)
+  const bool persist = pe ? atoi(pe) != 0 : g_persistent != 0;
   hipStream_t st = (hipStream_t)stream;
   const char* e = getenv("TN_GEMM_VARIANT");     // kernel-development A/B switch (read per call: the sweep changes it)
   const int variant = e ? atoi(e) : TN_GEMM_DEFAULT_VARIANT;
