@@ -589,7 +589,39 @@ def boundary_case():
     mesh_names = sorted({c.value for n in ast.walk(dims) if isinstance(n, ast.Constant) and isinstance(n.value, str)
                          for c in [n] if c.value in ("pp", "dp_replicate", "dp_shard", "cp", "tp", "dp", "dp_shard_cp",
                                                      "dp_cp")})
+    # the ORDER in which the trainer drives model / optimizer objects: attribute-call chains inside `train_step` and the
+    # statements of the model set-up that follow `parallelize_fn` (what a data-parallel engine hidden behind the hooks
+    # has to live with: a meta-device model at parallelize time, `.to(float32)` afterwards, no gradient visible to
+    # clip_grad_norm_).  (name, line) pairs in source order.
+    train = klass(tree("touchnet/bin/train.py"), "Trainer")
+
+    def chain(n):
+        parts = []
+        while isinstance(n, ast.Attribute):
+            parts.append(n.attr)
+            n = n.value
+        if isinstance(n, ast.Name):
+            parts.append(n.id)
+        return ".".join(reversed(parts))
+
+    def calls_in(fn, wanted):
+        found = []
+        for node in ast.walk(fn):
+            if isinstance(node, ast.Call):
+                name = chain(node.func) if isinstance(node.func, ast.Attribute) else getattr(node.func, "id", "")
+                if any(name.endswith(w) for w in wanted):
+                    found.append([name, node.lineno])
+        return sorted(found, key=lambda x: x[1])
+
+    step_fn = next(n for n in train.body if isinstance(n, ast.FunctionDef) and n.name == "train_step")
+    init_fn = next(n for n in train.body if isinstance(n, ast.FunctionDef) and n.name == "__init__")
+    step_seq = calls_in(step_fn, ("optimizers.zero_grad", ".backward", "clip_grad_norm_", "optimizers.step",
+                                  "lr_schedulers.step", "train_spec.loss_fn", "train_spec.acc_fn"))
+    setup_seq = calls_in(init_fn, ("train_spec.parallelize_fn", "model.to_empty", "model.post_init",
+                                   "train_spec.additional_post_init_fn", "model.train", "model.to",
+                                   "train_spec.build_optimizers_fn", "train_spec.build_lr_schedulers_fn"))
     out = {"train_spec_fields": fields, "train_spec_required": required, "train_py_calls": calls,
+           "train_step_sequence": step_seq, "model_setup_sequence": setup_seq,
            "parallel_dims": {"fields": [n.target.id for n in dims.body if isinstance(n, ast.AnnAssign)],
                              "properties": sorted(f.name for f in dims.body if isinstance(f, ast.FunctionDef)
                                                   and ("property" in deco(f) or "cached_property" in deco(f))),
@@ -721,10 +753,184 @@ def kimi_decoder_case():
     save("kimi_decoder.npz", **arrs)
 
 
+# ------------------------------------------------------------------ device-shaped model fixtures
+# The fixtures above use head_dim 8 / 16: shapes the MI355X attention kernels do not take.  These are the SAME reference
+# modules at the smallest widths the kernels accept (head_dim 64), run in float32 on bf16-ROUNDED weights (what the device
+# model holds), so that a `-m gpu` test can load the fixture into the product model on the MI355X and compare with the
+# reference's own outputs without the product's wiring in between.  Weights are stored as bf16 bits (uint16), gradients
+# as float16 (their tolerance on the device is two orders of magnitude wider).
+def _bf16_round_(model):
+    with torch.no_grad():
+        for p in model.parameters():
+            p.copy_(p.bfloat16().float())
+
+
+def _bits(t):
+    return t.detach().bfloat16().view(torch.int16).cpu().numpy().view(np.uint16)
+
+
+def _dev_text_config():
+    from transformers import LlamaConfig
+    cfg = LlamaConfig.from_json_file(f"{R.REF}/tests/assets/config/tiny_llama.json")
+    cfg.update(dict(vocab_size=64, hidden_size=128, intermediate_size=128, num_hidden_layers=2, num_attention_heads=2,
+                    num_key_value_heads=1, head_dim=64))
+    return cfg
+
+
+def _model_arrays(model, out, batch, ps, pt, keys):
+    arrs = {f"param/{n}": _bits(p) for n, p in model.named_parameters()}
+    arrs.update({f"grad/{n}": npy(p.grad).astype(np.float16) for n, p in model.named_parameters() if p.grad is not None})
+    for k in keys:
+        arrs[f"batch/{k}"] = npy(batch[k])
+    arrs["batch/num_sentence"] = np.array(batch["num_sentence"])
+    arrs["logits"] = npy(out.logits)
+    arrs["loss_per_sample"], arrs["loss_per_token"] = npy(ps), npy(pt)
+    return arrs
+
+
+def tiny_llama_dev_case():
+    from transformers import LlamaForCausalLM
+    cfg = _dev_text_config()
+    cfg._attn_implementation = "eager"
+    torch.manual_seed(20)
+    model = LlamaForCausalLM(cfg).float()
+    _bf16_round_(model)
+    rng = np.random.RandomState(21)
+    sents = [[int(v) for v in rng.randint(3, 64, size=int(n))] for n in rng.randint(4, 60, size=12)]
+    dcfg = types.SimpleNamespace(dataset_batchsize=2, dataset_text_seqlen=128, dataloader_drop_last_batch=False)
+    batch = next(iter(ref_batch_text(({"input_ids": s} for s in sents), dcfg, TOK)))
+    out = model(input_ids=batch["input_ids"], attention_mask=_allow4d(batch["attention_mask"]),
+                position_ids=batch["position_ids"])
+    ps, pt = ref_ce(out.logits, batch["labels"], batch["sentence_lens"], batch["num_sentence"])
+    ps.backward()
+    arrs = _model_arrays(model, out, batch, ps, pt, ("input_ids", "labels", "position_ids", "attention_mask", "sentence_lens"))
+    # (the json's 4.51-style rope_theta / rope_scaling: transformers 5.x folds both into `rope_parameters`)
+    rp = dict(cfg.rope_parameters)
+    theta = rp.pop("rope_theta")
+    desc = {k: getattr(cfg, k) for k in ("vocab_size", "hidden_size", "intermediate_size", "num_hidden_layers",
+                                         "num_attention_heads", "num_key_value_heads", "head_dim", "rms_norm_eps",
+                                         "tie_word_embeddings")}
+    desc.update(rope_theta=theta, rope_scaling=rp)
+    arrs["config_json"] = np.array(str(desc))
+    save("tiny_llama_dev.npz", **arrs)
+
+
+def touch_audio_dev_case():
+    from touchnet.models.touch_audio.configuration_touch_audio import TouchAudioConfig
+    from touchnet.models.touch_audio.modeling_touch_audio import TouchAudioForCausalLM
+    F = 16
+    cfg = TouchAudioConfig(text_config=_dev_text_config().to_dict(),
+                           audio_config={"model_type": "touch_audio_projector", "input_size": F}, pad_token_id=0)
+    cfg._attn_implementation = "eager"
+    cfg.text_config._attn_implementation = "eager"
+    torch.manual_seed(22)
+    model = TouchAudioForCausalLM(cfg).float()
+    _bf16_round_(model)
+    rng = np.random.RandomState(23)
+    n = 10
+    feats = [torch.from_numpy(rng.randn(int(a), F).astype(np.float32)).bfloat16().float().numpy()
+             for a in rng.randint(6, 40, size=n)]
+    ids = [[int(v) for v in rng.randint(3, 64, size=int(t))] for t in rng.randint(2, 12, size=n)]
+    dcfg = types.SimpleNamespace(dataset_batchsize=2, dataset_text_seqlen=128, dataset_audio_seqlen=128,
+                                 audiofeat_num_mel_bins=F, audiofeat_stack_length=1, dataloader_drop_last_batch=False)
+    data = ({"audiofeat": torch.from_numpy(f), "input_ids": i} for f, i in zip(feats, ids))
+    batch = next(iter(ref_batch_asr(data, dcfg, TOK)))
+    out = model(input_ids=batch["input_ids"], input_features=batch["input_features"],
+                attention_mask=_allow4d(batch["attention_mask"]), position_ids=batch["position_ids"])
+    ps, pt = ref_ce(out.logits, batch["labels"], batch["sentence_lens"], batch["num_sentence"])
+    ps.backward()
+    arrs = _model_arrays(model, out, batch, ps, pt,
+                         ("input_ids", "labels", "position_ids", "attention_mask", "sentence_lens", "input_features"))
+    arrs["input_size"] = np.array(F)
+    save("touch_audio_dev.npz", **arrs)
+
+
+def qwen2_audio_tower_dev_case():
+    from transformers.models.qwen2_audio.configuration_qwen2_audio import Qwen2AudioEncoderConfig
+    from transformers.models.qwen2_audio.modeling_qwen2_audio import Qwen2AudioEncoder
+    ref = R.load_file_as("ref_qwen2_audio_init", "touchnet/models/qwen2_audio/__init__.py")
+    dims = dict(num_mel_bins=16, encoder_layers=2, encoder_attention_heads=2, encoder_ffn_dim=256, d_model=128,
+                max_source_positions=50)
+    acfg = Qwen2AudioEncoderConfig(**dims, dropout=0.0, attention_dropout=0.0, activation_dropout=0.0)
+    acfg._attn_implementation = "sdpa"
+    torch.manual_seed(24)
+    tower = Qwen2AudioEncoder(acfg).float().eval()
+    with torch.no_grad():
+        tower.embed_positions.weight.copy_(torch.randn_like(tower.embed_positions.weight) * 0.1)
+    _bf16_round_(tower)
+    for layer in tower.layers:                       # qwen2_audio/__init__.py:191-192
+        layer.self_attn.is_causal = True
+
+    class AsTuple(torch.nn.Module):                  # 4.51.3 layers return a tuple, 5.x a tensor
+        def __init__(self, inner):
+            super().__init__()
+            self.inner = inner
+
+        def forward(self, h, mask=None, **kw):
+            return (self.inner(h, mask),)
+    tower.layers = torch.nn.ModuleList([AsTuple(l) for l in tower.layers])
+    mel = torch.randn(3, 16, 100).bfloat16().float()  # 100 mel frames -> 50 positions -> 25 tokens per clip
+    out = ref.forward_audio_tower(tower, mel).last_hidden_state
+    arrs = {f"param/{n.replace('.inner', '')}": _bits(p) for n, p in tower.named_parameters()}
+    arrs["embed_positions"] = _bits(tower.embed_positions.weight)
+    arrs["mel"], arrs["out"] = npy(mel), npy(out)
+    arrs["config_json"] = np.array(str(dims))
+    save("qwen2_audio_tower_dev.npz", **arrs)
+
+
+def kimi_decoder_dev_case():
+    mk = R.load_kimi_modeling()
+    from touchnet.models.kimi_audio.configuration_kimi_audio import KimiAudioConfig
+    kw = dict(vocab_size=64, hidden_size=128, intermediate_size=128, num_hidden_layers=2, num_attention_heads=2,
+              num_key_value_heads=1, rms_norm_eps=1e-6, rope_theta=1e6, kimia_mimo_layers=1,
+              kimia_mimo_transformer_from_layer_index=0, use_whisper_feature=False, use_cache=False, pad_token_id=None,
+              initializer_range=0.1)
+    cfg = KimiAudioConfig(**kw)
+    cfg._attn_implementation = "eager"
+    cfg.layer_types = ["full_attention"] * (kw["num_hidden_layers"] + kw["kimia_mimo_layers"])
+    torch.manual_seed(25)
+    model = mk.MoonshotKimiaModel(cfg).float().eval()
+    R.adapt_decoder_layers_to_4_51(list(model.layers) + list(model.mimo_layers))
+    lm_head = torch.nn.Linear(128, 64, bias=False)
+    mimo_output = torch.nn.Linear(128, 64, bias=False)
+    g = torch.Generator().manual_seed(26)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith("bias"):
+                p.normal_(std=0.05, generator=g)
+    for m in (model, lm_head, mimo_output):
+        _bf16_round_(m)
+    B, T = 2, 128
+    a, t = torch.randint(0, 64, (B, T), generator=g), torch.randint(0, 64, (B, T), generator=g)
+    doc = torch.cat([torch.ones(B, 50), 2 * torch.ones(B, 60), torch.zeros(B, 18)], 1).long()
+    pos = torch.cat([torch.arange(50), torch.arange(60), torch.zeros(18, dtype=torch.long)]).repeat(B, 1)
+    emb = model.get_input_embeddings()
+    inputs_embeds = emb(a) + emb(t)
+    out = model(input_ids=None, inputs_embeds=inputs_embeds, attention_mask=_allow4d(doc), position_ids=pos,
+                use_cache=False, return_dict=True)
+    hidden, mimo = out.last_hidden_state
+    text_logits, audio_logits = lm_head(hidden), mimo_output(mimo)
+    labels = torch.where(doc > 0, torch.randint(0, 64, (B, T), generator=g), torch.full((B, T), -100))
+    sl = torch.where(doc == 1, torch.full((B, T), 50), torch.where(doc == 2, torch.full((B, T), 60), torch.ones(B, T, dtype=torch.long)))
+    ps, pt = ref_ce(text_logits, labels, sl, 4)
+    ps.backward()
+    arrs = {f"param/model.{n}": _bits(p) for n, p in model.named_parameters()}
+    arrs["param/lm_head.weight"], arrs["param/mimo_output.weight"] = _bits(lm_head.weight), _bits(mimo_output.weight)
+    arrs.update({f"grad/model.{n}": npy(p.grad).astype(np.float16) for n, p in model.named_parameters() if p.grad is not None})
+    arrs["grad/lm_head.weight"] = npy(lm_head.weight.grad).astype(np.float16)
+    arrs.update({"batch/audio_input_ids": npy(a), "batch/text_input_ids": npy(t), "batch/attention_mask": npy(doc),
+                 "batch/position_ids": npy(pos), "batch/labels": npy(labels), "batch/sentence_lens": npy(sl),
+                 "text_logits": npy(text_logits), "audio_logits": npy(audio_logits), "loss_per_sample": npy(ps),
+                 "loss_per_token": npy(pt)})
+    arrs["config_json"] = np.array(str({k: v for k, v in kw.items() if k not in ("use_whisper_feature", "use_cache", "pad_token_id")}))
+    save("kimi_decoder_dev.npz", **arrs)
+
+
 if __name__ == "__main__":
     only = set(sys.argv[1:])
     for fn in (text_cases, asr_cases, ce_cases, docmask_cases, rope_cases, tiny_llama_case,
                touch_audio_case, qwen2_audio_tower_case, frontend_cases, fbank_cases, bestrq_cases, touchdataset_case,
-               boundary_case, qwen2_audio_data_case, kimi_decoder_case):
+               boundary_case, qwen2_audio_data_case, kimi_decoder_case, tiny_llama_dev_case, touch_audio_dev_case,
+               qwen2_audio_tower_dev_case, kimi_decoder_dev_case):
         if not only or fn.__name__ in only:
             fn()

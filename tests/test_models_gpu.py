@@ -1,7 +1,7 @@
 """GPU parity of the assembled models / training step (HIP kernels, bf16) against the oracle (fp32 eager on
 the same bf16-rounded weights and batch).  Tolerances (north_star): loss within 1e-3 relative — asserted; logits on
 the valid (non-pad) rows within 8 % (worst element) / 0.6 % (mean) of the logit scale and every parameter gradient
-within 8 % of its own scale
+within 6 % of its own scale (observed <= 4.1 %; round 4 tightened it from 8 %)
 (bf16 activations through the stack vs fp32 activations in the oracle: a few bf16 ulps per op)."""
 import numpy as np
 import pytest
@@ -33,7 +33,7 @@ def _oracle_run(model_cls, cfg, state, fwd, batch):
 LOSS_REL = 1e-3      # north_star: "loss matching reference within 1e-3 rel"
 
 
-def _device_vs_oracle(tr, model_cls, cfg, fwd, batch, cpu_batch=None, logit_tol=8e-2, logit_mean_tol=6e-3, grad_tol=8e-2):
+def _device_vs_oracle(tr, model_cls, cfg, fwd, batch, cpu_batch=None, logit_tol=8e-2, logit_mean_tol=6e-3, grad_tol=6e-2):
     """One forward / loss / backward of the product model on the device vs the oracle on the CPU: loss (1e-3 rel),
     logits on valid rows, ALL parameter gradients."""
     data = tr.next_batch(batch)

@@ -203,6 +203,71 @@ def test_flat_data_parallel_engine_over_a_single_rank_rccl_group_trains_like_the
     assert abs(norm - ref_norm) / ref_norm < max(tol, 1e-4), (norm, ref_norm)
 
 
+def test_flat_engine_through_the_reference_hooks_on_device(rccl_single_rank, monkeypatch):
+    """The reference trainer's sequence (boundary.json: parallelize_fn on a meta model -> to_empty -> post_init ->
+    .to(float32) -> build_optimizers_fn; per step zero_grad / backward / clip_grad_norm_ / step) with the real kernels:
+    `parallelize_fn` marks, `build_optimizers_fn` builds the flat engine on bf16 views + FusedAdamW whose masters are the
+    trainer's float32 numbers; three steps follow the plain trainer's losses and the reference's own clip sees no gradient."""
+    import touchnet_amd.specs as specs
+    from touchnet_amd.bin.train import TrainConfig, Trainer, _MeshView
+    from touchnet_amd.data.synthetic import text_batch
+    from touchnet_amd.models.llama import DecoderConfig
+    from touchnet_amd.utils.distributed import ParallelDims, build_dp_mesh
+    from touchnet_amd.utils.train_spec import get_train_spec
+    from touchnet_amd.utils.zero_dp import FlatEngineOptimizer
+    cfg = DecoderConfig.from_dict(dict(CFG, model_type="llama"))
+    kw = dict(training_model_name="llama_mi355", training_enable_fused_ce=True, lr_scheduler_warmup_steps=0,
+              lr_scheduler_lr=1e-3)
+    batches = [text_batch(1024, 4, 512, seed=s, max_len=90) for s in range(3)]
+    plain = Trainer(TrainConfig(**kw), cfg, torch.device(DEV))
+    ref = [float(plain.train_step(plain.next_batch(b))["loss_per_sample"]) for b in batches]
+    monkeypatch.setenv("TN_DP_FORCE_COLLECTIVES", "1")
+    job = TrainConfig(**kw, training_dp_engine="flat")
+    spec = get_train_spec("llama_mi355")
+    mesh = build_dp_mesh("cuda", 1)
+    dims = ParallelDims(dp_replicate=1, dp_shard=2, cp=1, tp=1, pp=1, world_size=2, enable_loss_parallel=False)  # (takes the dp branch)
+    dev = torch.device(DEV, 0)
+    torch.manual_seed(job.training_seed)
+    with torch.device("meta"):
+        model = spec.model_cls(cfg)
+    model = spec.parallelize_fn(model, _MeshView({"dp_shard_cp": mesh}), dims, job)
+    assert all(p.is_meta for p in model.parameters())
+    model.to_empty(device=dev)
+    with torch.no_grad():
+        model.post_init()
+        spec.additional_post_init_fn(model, dev)
+    model.train()
+    model = model.to(torch.float32)
+    f32 = {n: p.detach().clone() for n, p in model.named_parameters()}
+    opt = spec.build_optimizers_fn([model], job)
+    lrs = spec.build_lr_schedulers_fn(opt, job)
+    assert isinstance(opt, FlatEngineOptimizer) and not opt.engine.identity
+    assert all(p.dtype == torch.bfloat16 for p in model.parameters())
+    # the masters are the float32 numbers, not the rounded ones
+    b0 = opt.engine.buckets[0]
+    m0 = opt.inner.state[0]["master"]
+    p0, o0 = b0.params[0], b0.offsets[0]
+    name0 = next(n for n, p in model.named_parameters() if p is p0)
+    assert torch.equal(m0[o0:o0 + p0.numel()], f32[name0].reshape(-1))
+    got = []
+    for b in batches:
+        data = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in b.items()}
+        ns = torch.tensor([float(data.pop("num_sentence"))], device=dev)
+        opt.zero_grad()
+        pred = model(**data, num_sentence=ns, ce_chunk_tokens=job.training_ce_chunk_tokens)
+        pred.loss.backward()
+        assert all(p.grad is None for p in model.parameters())
+        norm = torch.nn.utils.clip_grad_norm_(list(model.parameters()), job.training_max_norm)
+        assert float(norm) == 0.0
+        opt.step()
+        lrs.step()
+        got.append(float(pred.loss))
+        assert float(opt.last_grad_norm) > 0
+    # (the plain trainer starts from bf16-rounded masters, this one from the float32 draw: same numbers to bf16 rounding)
+    for a, b in zip(got, ref):
+        assert abs(a - b) / abs(b) < 2e-3, (got, ref)
+
+
 def _lp_worker(rank, world, port, ret):
     """one of two processes on the SAME GPU (gloo carries the device tensors of the tiny statistics exchanges)"""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -294,7 +359,10 @@ def _flat2_worker(rank, world, port, ref_losses, ret):
                           lr_scheduler_lr=1e-3, training_dp_engine="flat", training_max_norm=1e9)
         tr = Trainer(job, cfg, torch.device(DEV, 0), dp_mesh=mesh)
         eng = tr.dp_engine
-        assert eng is not None and eng.world == 2 and not eng.identity and os.environ.get("TN_GEMM_PERSIST") == "0"
+        from touchnet_amd import _C
+        # (collectives beside the compute: one workgroup per tile, chosen by a library call, not through the environment)
+        assert eng is not None and eng.world == 2 and not eng.identity and _C.lib().tn_gemm_get_persistent() == 0
+        assert "TN_GEMM_PERSIST" not in os.environ
         losses = []
         for s in range(3):
             b = text_batch(1024, 2, 512, seed=10 * s + rank, max_len=90)          # each rank its own rows

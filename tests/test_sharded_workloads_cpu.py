@@ -573,6 +573,128 @@ def test_flat_data_parallel_engine_trains_like_one_process(world):
                              "rest.lm_head"]
 
 
+def _reference_hooks_worker(rank, world, port, cfg_dict, ref_state, batches, ref_after, ref_norm, ret):
+    """The flat engine driven ONLY through the TrainSpec hooks, in the order touchnet/bin/train.py calls them
+    (tests/golden/boundary.json: `model_setup_sequence` :259-297, `train_step_sequence` :396-474)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import json
+    import oracle.ops as oops
+    import touchnet_amd.specs as specs
+    from touchnet_amd.bin.train import TrainConfig, _MeshView
+    from touchnet_amd.models.backend import use_ops
+    from touchnet_amd.utils.distributed import ParallelDims, build_dp_mesh, init_distributed
+    from touchnet_amd.utils.train_spec import get_train_spec
+    from touchnet_amd.utils.zero_dp import FlatEngineOptimizer
+    try:
+        init_distributed("cpu")
+        mesh = build_dp_mesh("cpu", world)
+        fixture = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "boundary.json")))
+        specs.OPTIMIZER_FACTORY = lambda shards, group: ShardAdamW(shards, group=group)
+        spec = get_train_spec("llama_mi355")
+        job = TrainConfig(training_model_name="llama_mi355", training_enable_fused_ce=False,
+                          training_mixed_precision_param="float32", training_dp_engine="flat")
+        dims = ParallelDims(dp_replicate=1, dp_shard=world, cp=1, tp=1, pp=1, world_size=world, enable_loss_parallel=False)
+        dev = torch.device("cpu")
+        st = {}
+        torch.manual_seed(17)
+        with torch.device("meta"):                                       # train.py:179-182
+            st["model"] = spec.model_cls(spec.config_cls.from_dict(cfg_dict))
+        setup = {
+            "self.train_spec.parallelize_fn": lambda: st.__setitem__("model", spec.parallelize_fn(
+                st["model"], _MeshView({"dp_shard_cp": mesh}), dims, job)),
+            "model.to_empty": lambda: st["model"].to_empty(device=dev),
+            "model.post_init": lambda: st["model"].post_init(),
+            "self.train_spec.additional_post_init_fn": lambda: spec.additional_post_init_fn(st["model"], dev),
+            "model.train": lambda: st["model"].train(),
+            "model.to": lambda: st.__setitem__("model", st["model"].to(torch.float32)),
+            "self.train_spec.build_optimizers_fn": lambda: st.__setitem__("opt", spec.build_optimizers_fn([st["model"]], job)),
+            "self.train_spec.build_lr_schedulers_fn": lambda: st.__setitem__("lrs", spec.build_lr_schedulers_fn(st["opt"], job)),
+        }
+        first = next(line for name, line in fixture["model_setup_sequence"] if name.endswith("parallelize_fn"))
+        with use_ops(oops), torch.no_grad():
+            for name, line in fixture["model_setup_sequence"]:
+                if line >= first:                                        # (earlier entries: the pipeline-parallel branch)
+                    setup[name]()
+                    if name.endswith("parallelize_fn"):                  # still on the meta device, nothing sharded yet
+                        assert all(p.is_meta for p in st["model"].parameters()) and st["model"]._tn_flat_dp is not None
+        model, opt, lrs = st["model"], st["opt"], st["lrs"]
+        assert isinstance(opt, FlatEngineOptimizer) and model._tn_flat_engine is opt.engine
+        assert not any(hasattr(p, "_local_tensor") for p in model.parameters())      # no FSDP2 DTensors
+        with torch.no_grad():
+            for name, p in model.named_parameters():
+                p.copy_(ref_state[name])                                 # (views: writes the flat buffers)
+        opt.inner.opt.param_groups[0]["lr"] = 1e-2                       # (the reference run's constant rate)
+        norms = []
+        with use_ops(oops):
+            for step in range(2):
+                b = dict(batches[step][rank])
+                ns = torch.tensor([float(sum(x["num_sentence"] for x in batches[step]))])      # train.py:339-343
+                labels, sl = b.pop("labels"), b.pop("sentence_lens")
+                b.pop("num_sentence")
+                data = {k: b[k] for k in ("input_ids", "position_ids", "attention_mask")}
+                seen = {"zero": 0}
+                for name, line in fixture["train_step_sequence"]:
+                    if name.endswith("optimizers.zero_grad"):
+                        seen["zero"] += 1
+                        if seen["zero"] == 1:
+                            opt.zero_grad()
+                            pred = model(**data)                          # train.py:436
+                        elif not torch.isfinite(norm):                    # train.py:467-471: the skip branch
+                            opt.zero_grad()
+                    elif name.endswith("loss_fn"):
+                        loss, _ = spec.loss_fn(pred.logits, labels, sl, ns)
+                    elif name.endswith("acc_fn"):
+                        spec.acc_fn(pred.logits, labels)
+                    elif name.endswith(".backward"):
+                        loss.backward()
+                    elif name == "clip_grad_norm_":
+                        # the reference's clip sees no gradient at all: norm 0, nothing scaled, no nan
+                        assert all(p.grad is None for p in model.parameters())
+                        norm = torch.nn.utils.clip_grad_norm_([p for p in model.parameters()], job.training_max_norm)
+                        assert float(norm) == 0.0
+                    elif name.endswith("optimizers.step"):
+                        if torch.isfinite(norm):
+                            opt.step()
+                    elif name.endswith("lr_schedulers.step"):
+                        lrs.step()
+                        opt.inner.opt.param_groups[0]["lr"] = 1e-2
+                norms.append(float(opt.last_grad_norm))
+        worst = max(float((p.detach() - ref_after[n]).abs().max()) for n, p in model.named_parameters())
+        assert worst < 2e-5, worst
+        assert norms[0] == pytest.approx(ref_norm[0], rel=1e-4) and norms[1] == pytest.approx(ref_norm[1], rel=1e-4)
+        ret[rank] = ("ok", worst)
+    except Exception as e:
+        import traceback
+        ret[rank] = ("fail", traceback.format_exc(), repr(e))
+    finally:
+        if dist.is_initialized():
+            dist.barrier()
+            dist.destroy_process_group()
+
+
+def test_flat_engine_behind_the_reference_hooks_in_the_reference_call_order():
+    """`parallelize_fn` (meta model) -> to_empty / post_init / .to(float32) -> `build_optimizers_fn` ->
+    per step zero_grad / backward / clip_grad_norm_ / step, replayed from the call-order fixture on 2 gloo ranks, ends two
+    AdamW steps at the same parameters and gradient norms as one process on the averaged loss (= what the repo's own
+    Trainer reaches with the same engine, test_flat_data_parallel_engine_trains_like_one_process)."""
+    from touchnet_amd.data.synthetic import text_batch
+    from touchnet_amd.models.llama import DecoderConfig, PackedCausalLM
+    world = 2
+    cfg_dict = dict(TINY, num_hidden_layers=3, tie_word_embeddings=False)
+    batches = [[text_batch(16, 2, 32, seed=100 + 10 * s + r, max_len=9) for r in range(world)] for s in range(2)]
+    fwd = lambda m, b, ns: m(input_ids=b["input_ids"], position_ids=b["position_ids"], attention_mask=b["attention_mask"],
+                             labels=b["labels"], sentence_lens=b["sentence_lens"], num_sentence=ns)
+    state, after, norms = _flat_reference(PackedCausalLM, DecoderConfig.from_dict(cfg_dict), batches, world, fwd)
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_reference_hooks_worker, args=(world, _free_port(), cfg_dict, state, batches, after, norms, ret),
+                 nprocs=world, join=True)
+        results = dict(ret)
+    for r in range(world):
+        assert results[r][0] == "ok", results[r][1]
+
+
 def test_flat_engine_with_a_branch_that_takes_no_part_in_the_step():
     """Kimi-Audio's text-head step never runs the mimo layers: their buckets receive no gradient on any rank, are skipped
     by the engine and the optimizer alike (no collective is issued for them) and keep their parameters."""

@@ -16,8 +16,21 @@ from touchnet_amd.utils.optimizer import FusedAdamW, LRScheduler
 from touchnet_amd.utils.train_spec import TrainSpec, _train_specs, get_train_spec, register_train_spec  # noqa: F401
 
 
+# tests drive the host logic on CPU with a torch optimizer: `(named_params_or_shards, process_group) -> optimizer`
+OPTIMIZER_FACTORY = None
+
+
 def _build_optimizers(model_parts, job):
     from touchnet_amd.models.tensor_parallel import tp_param_ids
+    if len(model_parts) == 1 and getattr(model_parts[0], "_tn_flat_dp", None) is not None:
+        # `parallelize_fn` chose the flat data-parallel engine (training_dp_engine=flat): the engine is built HERE, on the
+        # parameters the trainer has materialised in between, and what comes back drives it through the trainer's own
+        # zero_grad() / step() calls (utils/zero_dp.py, bottom)
+        from touchnet_amd.utils.zero_dp import build_flat_engine_optimizer
+        make = OPTIMIZER_FACTORY or (lambda shards, group: FusedAdamW(
+            shards, lr=job.lr_scheduler_lr, weight_decay=job.optimizer_weight_decay, max_norm=job.training_max_norm,
+            process_group=group))
+        return build_flat_engine_optimizer(model_parts[0], make)
     many = len(model_parts) > 1
     params = [(f"{i}.{n}" if many else n, p) for i, m in enumerate(model_parts) for n, p in m.named_parameters()]
     tp_group, tp_ids = tp_param_ids(model_parts)

@@ -327,3 +327,88 @@ class FlatShardedDataParallel:
         if self.cuda and b.params_ready is not None:
             torch.cuda.current_stream().wait_event(b.params_ready)
             b.params_ready = None
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The engine behind the reference's own hooks (touchnet/bin/train.py).  Its trainer calls, in this order
+# (tests/golden/boundary.json `model_setup_sequence` / `train_step_sequence`):
+#     model = parallelize_fn(model ON THE META DEVICE, world_mesh, parallel_dims, job)       :259
+#     model.to_empty(device); model.post_init(); additional_post_init_fn(...); model.to(float32)   :274-283
+#     optimizers = build_optimizers_fn([model], job);  lr_schedulers = build_lr_schedulers_fn(optimizers, job)   :296-297
+#     per step:  optimizers.zero_grad();  forward;  loss.backward();  clip_grad_norm_(model parameters, max_norm);
+#                optimizers.step()  (or optimizers.zero_grad() on a non-finite norm);  lr_schedulers.step()      :396-474
+# The flat buffers cannot exist while the model is on the meta device, so `parallelize_fn` only MARKS the model
+# (`mark_flat_engine`) and `build_optimizers_fn` — the first hook that sees real tensors — builds the engine
+# (`build_flat_engine_optimizer`): parameters go to the compute dtype (`training_mixed_precision_param`, what FSDP2's
+# MixedPrecisionPolicy would all-gather in), the float32 values the trainer just created become the optimizer's master
+# copy.  After `backward()` the parameters carry no `.grad` (every gradient sits in a reduce-scatter input), so the
+# trainer's own clip_grad_norm_ computes 0 and scales nothing; norm, clip and the skip on a non-finite norm happen on
+# the device inside `step()` (utils/optimizer.FusedAdamW), whose result is kept in `last_grad_norm`.
+# ---------------------------------------------------------------------------------------------------------------------
+def mark_flat_engine(model: nn.Module, mesh, reduce_dtype: torch.dtype, param_dtype: torch.dtype) -> None:
+    model._tn_flat_dp = {"mesh": mesh, "reduce_dtype": reduce_dtype, "param_dtype": param_dtype}
+
+
+class FlatEngineOptimizer:
+    """The `optimizers` object of the reference trainer for a model on the flat engine (see above)."""
+
+    def __init__(self, engine: FlatShardedDataParallel, inner):
+        self.engine, self.inner = engine, inner
+        self.last_grad_norm = None
+
+    lr = property(lambda self: self.inner.lr, lambda self, v: setattr(self.inner, "lr", v))
+
+    def zero_grad(self, *args, **kwargs) -> None:
+        self.inner.zero_grad()
+        self.engine.zero_grad()
+
+    def step(self, lr=None):
+        from touchnet_amd.models.backend import ops as _ops
+        if hasattr(_ops(), "sync_wgrad_stream"):
+            _ops().sync_wgrad_stream()
+        self.engine.finish_backward()          # reduce-scatters ran under the backward; shards go to the optimizer
+        self.last_grad_norm = self.inner.step(lr) if lr is not None else self.inner.step()
+        self.engine.gather_params()            # all-gathers of the updated slices travel under the next forward
+        return self.last_grad_norm
+
+    def state_dict(self):
+        return self.inner.state_dict()
+
+    def load_state_dict(self, sd) -> None:
+        self.inner.load_state_dict(sd)
+        # the bf16 slices were rewritten from the loaded masters on this rank only: every rank needs every slice
+        self.engine.gather_params()
+        self.engine.wait_params()
+
+
+def build_flat_engine_optimizer(model: nn.Module, make_optimizer):
+    """`make_optimizer(named_shards, process_group)` -> the optimizer over the engine's shards.  Returns the
+    FlatEngineOptimizer; the engine is also left at `model._tn_flat_engine`."""
+    mark = model._tn_flat_dp
+    pdt = mark["param_dtype"]
+    # float32 values of the parameters that are about to be rounded to the compute dtype (same storage as the
+    # parameters hold now: no copy until the cast below allocates the new tensors)
+    keep = {}
+    with torch.no_grad():
+        for p in model.parameters():
+            if p.requires_grad and p.is_floating_point() and p.dtype != pdt:
+                keep[id(p)] = p.data
+                p.data = p.data.to(pdt)
+    engine = FlatShardedDataParallel(model, mark["mesh"], reduce_dtype=mark["reduce_dtype"])
+    inner = make_optimizer(engine.named_shards(), mark["mesh"].get_group())
+    masters = getattr(inner, "state", None)
+    if keep and isinstance(masters, list) and len(masters) == len(engine.buckets):
+        # the optimizer drew its master copies from the rounded slices: give them the trainer's float32 numbers
+        with torch.no_grad():
+            for b, st in zip(engine.buckets, masters):
+                m = st.get("master") if isinstance(st, dict) else None
+                if m is None or m.dtype != torch.float32 or m.data_ptr() == b.shard.data.data_ptr():
+                    continue
+                lo, hi = engine.rank * b.S, (engine.rank + 1) * b.S
+                for p, o in zip(b.params, b.offsets):
+                    src = keep.get(id(p))
+                    a, e = max(lo, o), min(hi, o + p.numel())
+                    if src is not None and e > a:
+                        m[a - lo:e - lo].copy_(src.reshape(-1)[a - o:e - o])
+    model._tn_flat_engine = engine
+    return FlatEngineOptimizer(engine, inner)
