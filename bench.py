@@ -615,22 +615,26 @@ def main():
                                       "share of the tokens")
         if (args.cp > 1 or args.tp > 1):
             line["kernels_note"] = "per-kernel rooflines are reported on the headline workload (python bench.py)"
-            rows_local = wl.B * wl.T // layout["cp"]
-            lm_rows = rows_local
-            if wl.job.training_enable_fused_ce and not args.all_rows_lm_head and not args.compact_lm_head:
-                bound = (wl.tokens.get("labelled_rows_max_cp", [None] * layout["cp"])[trainer.cp.rank]
-                         if layout["cp"] > 1 else wl.tokens.get("labelled_rows_max"))
-                if bound is not None:
-                    lm_rows = min(rows_local, (int(bound) + 255) // 256 * 256)
-            line["config"]["lm_head_rows"] = f"{lm_rows} of this rank's {rows_local} positions"
-            ex = executed_flops_per_gpu(wl, trainer, layout, lm_rows) / (elapsed / args.steps) / MFMA_PEAK
-            line["step_mfu_executed_flops"] = round(ex, 4)
-            line["roofline"].update({"achieved": round(ex * MFMA_PEAK / 1e12, 1), "frac": round(ex, 4),
-                                     "formula_achieved": round(fpt * (tps / gpus_in_job) / 1e12, 1),
-                                     "formula_frac": round(mfu, 4),
-                                     "note": "one GPU's training step against the dense bf16 MFMA peak: `frac` on the FLOPs "
-                                             "this rank executes (bench.executed_flops_per_gpu), `formula_frac` by the "
-                                             "reference MFU formula on its share of the tokens"})
+            try:                                   # (never lose the headline number to a diagnostics failure)
+                rows_local = wl.B * wl.T // layout["cp"]
+                lm_rows = rows_local
+                toks = getattr(wl, "tokens", {})       # (the frontend-fed ASR workloads build their batch per step)
+                if wl.job.training_enable_fused_ce and not args.all_rows_lm_head and not args.compact_lm_head:
+                    bound = (toks.get("labelled_rows_max_cp", [None] * layout["cp"])[trainer.cp.rank]
+                             if layout["cp"] > 1 else toks.get("labelled_rows_max"))
+                    if bound is not None:
+                        lm_rows = min(rows_local, (int(bound) + 255) // 256 * 256)
+                line["config"]["lm_head_rows"] = f"{lm_rows} of this rank's {rows_local} positions"
+                ex = executed_flops_per_gpu(wl, trainer, layout, lm_rows) / (elapsed / args.steps) / MFMA_PEAK
+                line["step_mfu_executed_flops"] = round(ex, 4)
+                line["roofline"].update({"achieved": round(ex * MFMA_PEAK / 1e12, 1), "frac": round(ex, 4),
+                                         "formula_achieved": round(fpt * (tps / gpus_in_job) / 1e12, 1),
+                                         "formula_frac": round(mfu, 4),
+                                         "note": "one GPU's training step against the dense bf16 MFMA peak: `frac` on the "
+                                                 "FLOPs this rank executes (bench.executed_flops_per_gpu), `formula_frac` by "
+                                                 "the reference MFU formula on its share of the tokens"})
+            except Exception as e:
+                line["executed_flops_error"] = repr(e)
         elif not args.no_kernel_rooflines and args.workload != "tiny":
             try:
                 line["kernels"], allowed_pairs = kernel_rooflines(wl)

@@ -1,0 +1,46 @@
+"""bench.py's N > 1 code path end to end on ONE MI355X: the driver's 8-GPU launch line, with two
+ranks sharing the GPU over gloo (TN_DIST_BACKEND=gloo; RCCL refuses two ranks on one device) — process-group init, mesh
+build (dp / cp / tp), the Trainer with its engines, barrier + synchronize fences, the MAX all-reduce of the elapsed time and
+rank 0's JSON line.  Small workload ("tiny"): what is under test is the bench's own plumbing, not a number."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _launch(extra, n=2):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, TN_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("TN_FORCE_FSDP", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1",
+           "--workload", "tiny", "--no-cpu-baseline", "--no-kernel-rooflines", *extra]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{") and '"metric"' in l]
+    assert len(lines) == 1, r.stdout[-2000:]              # rank 0 prints ONE line
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("extra,label", [([], "dp2"), (["--dp-engine", "fsdp2"], None), (["--cp", "2"], "cp2"),
+                                         (["--tp", "2"], "tp2")])
+def test_bench_two_ranks_on_one_gpu(extra, label):
+    if extra == ["--dp-engine", "fsdp2"]:
+        pytest.skip("FSDP2's DTensor mesh must be a cuda mesh (RCCL): not runnable with two ranks on one GPU")
+    line = _launch(extra)
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["warmup"] == 1 and line["scaling"] == "weak"
+    assert line["value"] > 0 and line["ms_per_step"] > 0 and line["loss_per_sample_last"] == line["loss_per_sample_last"]
+    if label is not None:
+        assert label in line["config"]["parallelism"], line["config"]["parallelism"]
+    # whole-job tokens: dp ranks each bring B x T, cp / tp peers share one batch
+    per_rank = 1 * 512
+    dp = 2 if not extra else 1
+    assert abs(line["value"] * line["ms_per_step"] / 1e3 - per_rank * dp) / (per_rank * dp) < 0.02

@@ -594,3 +594,37 @@ def test_tensor_parallel_two_ranks_equals_single_process(mode):
         assert results[r][1] < 2e-5 and results[r][2] < 2e-5, results[r]
         # 3 + 1 mimo blocks x (7 weights + 3 biases) (+ the head's vocabulary shard)
         assert results[r][3] == 4 * 10 + (1 if mode == "loss_parallel" else 0)
+
+
+def _group_mesh_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    try:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from touchnet_amd.utils.distributed import GroupMesh
+        m = GroupMesh({"dp_shard": 2, "cp": 2}, {"dp": ("dp_replicate", "dp_shard"), "dp_shard_cp": ("dp_shard", "cp")})
+        assert m.mesh_dim_names == ("dp_shard", "cp") and m["cp"].size() == 2 and m["dp_shard_cp"].size() == 4
+        assert m["dp_shard"].get_local_rank() == rank // 2 and m["cp"].get_local_rank() == rank % 2
+        assert m["dp_shard_cp"].get_local_rank() == rank and m["dp"].size() == 2
+        # the groups are the ones a row-major DeviceMesh has: cp peers are neighbours, dp peers two apart
+        t = torch.tensor([float(rank)])
+        dist.all_reduce(t, group=m["cp"].get_group())
+        u = torch.tensor([float(rank)])
+        dist.all_reduce(u, group=m["dp_shard"].get_group())
+        ret[rank] = ("ok", float(t), float(u))
+    except Exception as e:
+        import traceback
+        ret[rank] = ("fail", traceback.format_exc(), repr(e))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_group_mesh_has_device_mesh_layout():
+    """utils/distributed.GroupMesh (gloo groups for several ranks on one GPU) lays ranks out like torch's DeviceMesh."""
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_group_mesh_worker, args=(4, _free_port(), ret), nprocs=4, join=True)
+        res = dict(ret)
+    for r in range(4):
+        assert res[r][0] == "ok", res[r][1]
+        assert res[r][1] == float((r // 2) * 4 + 1) and res[r][2] == float(2 * (r % 2) + 2)

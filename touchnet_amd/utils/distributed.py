@@ -22,7 +22,12 @@ def init_distributed(device_type: str = None, timeout_s: int = 300) -> tuple[int
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if device_type is None:
         device_type = "cuda" if torch.cuda.is_available() else "cpu"
+    # TN_DIST_BACKEND=gloo on devices: several ranks may SHARE a GPU (RCCL refuses two ranks on one device, gloo stages
+    # device buffers through the host) — how the N > 1 code paths run end to end on a one-GPU box (bench.py, tests)
+    backend_env = os.environ.get("TN_DIST_BACKEND")
     if device_type == "cuda":
+        if backend_env == "gloo":
+            local = local % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local)
     force = os.environ.get("TN_FORCE_FSDP") == "1"      # 1-rank RCCL group: exercises the sharded path on one GPU
     if (world > 1 or force) and not dist.is_initialized():
@@ -30,17 +35,91 @@ def init_distributed(device_type: str = None, timeout_s: int = 300) -> tuple[int
         os.environ.setdefault("MASTER_PORT", "29512")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC only on this host driver
         os.environ.setdefault("TORCH_NCCL_AVOID_RECORD_STREAMS", "1")  # distributed.py:391
-        backend = "nccl" if device_type == "cuda" else "gloo"
+        backend = backend_env or ("nccl" if device_type == "cuda" else "gloo")
         kw = {}
-        if device_type == "cuda":
+        if device_type == "cuda" and backend == "nccl":
             kw["device_id"] = torch.device("cuda", local)
         dist.init_process_group(backend=backend, timeout=timedelta(seconds=timeout_s), **kw)
     return rank, local, world
 
 
+def _gloo_on_devices(device_type: str) -> bool:
+    return device_type == "cuda" and os.environ.get("TN_DIST_BACKEND") == "gloo"
+
+
+class GroupMesh:
+    """The slice of torch's DeviceMesh API this path uses — `mesh[name]`, `get_group()`, `size()`, `get_local_rank()`,
+    `mesh_dim_names`, `ndim` — over plain gloo groups.  Why not a DeviceMesh: with CUDA present torch builds a mesh's
+    groups as "cpu:gloo,cuda:nccl", i.e. device tensors go through RCCL, which refuses two ranks on one GPU; under
+    TN_DIST_BACKEND=gloo (several ranks sharing a GPU: bench.py / tests on a one-GPU box) every group must be gloo's.
+    Rank layout = DeviceMesh's: row-major over the dimensions in the order given; a flattened name spans its parts."""
+
+    def __init__(self, sizes: dict, flats: dict = None, _views=None, _name=None):
+        self._sizes, self._name, self._views = dict(sizes), _name, _views
+        if _views is None:
+            names = [n for n in sizes]
+            world, rank = dist.get_world_size(), dist.get_rank()
+            total = 1
+            for n in names:
+                total *= sizes[n]
+            if total != world:
+                raise ValueError(f"mesh {sizes} does not cover WORLD_SIZE {world}")
+            coords = lambda r: {n: (r // _stride(names, sizes, n)) % sizes[n] for n in names}
+            mine = coords(rank)
+            self._views = {}
+            spans = {n: (n,) for n in names}
+            spans.update({k: tuple(p for p in v if p in sizes) for k, v in (flats or {}).items()})
+            for view, parts in spans.items():
+                if not parts:
+                    continue
+                # every rank creates every group, in one global order (new_group is collective)
+                keys = sorted({tuple(c[n] for n in names if n not in parts) for c in map(coords, range(world))})
+                for key in keys:
+                    ranks = [r for r in range(world) if tuple(coords(r)[n] for n in names if n not in parts) == key]
+                    g = dist.new_group(ranks, backend="gloo")
+                    if rank in ranks:
+                        local = 0
+                        for n in parts:
+                            local = local * sizes[n] + mine[n]
+                        self._views[view] = (g, len(ranks), local)
+        self.mesh_dim_names = tuple(sizes) if _name is None else (_name,)
+        self.ndim = len(self.mesh_dim_names)
+
+    def __getitem__(self, names):
+        name = names[0] if isinstance(names, (tuple, list)) and len(names) == 1 else names
+        if not isinstance(name, str) or name not in self._views:
+            raise KeyError(names)
+        return GroupMesh(self._sizes, _views=self._views, _name=name)
+
+    def _one(self):
+        if self._name is None:
+            if len(self._views) and len(self._sizes) == 1:
+                return self._views[next(iter(self._sizes))]
+            raise RuntimeError("index the mesh by a dimension name first")
+        return self._views[self._name]
+
+    def get_group(self, dim=None):
+        return self._one()[0]
+
+    def size(self, dim=None):
+        return self._one()[1]
+
+    def get_local_rank(self, dim=None):
+        return self._one()[2]
+
+
+def _stride(names, sizes, n):
+    s = 1
+    for m in names[names.index(n) + 1:]:
+        s *= sizes[m]
+    return s
+
+
 def build_dp_mesh(device_type: str, world_size: int):
     """1-D `dp` (= dp_shard) mesh over all ranks: the FSDP2 data-parallel configuration of the reference
     recipes (examples/audio/sft/asr/wenetspeech/run.sh:55-75: dp_shard=8, tp=cp=pp=1)."""
+    if _gloo_on_devices(device_type):
+        return GroupMesh({"dp": world_size})
     from torch.distributed.device_mesh import init_device_mesh
     return init_device_mesh(device_type, (world_size,), mesh_dim_names=("dp",))
 
@@ -102,9 +181,11 @@ class ParallelDims:
         degrees = {"pp": self.pp, "dp_replicate": self.dp_replicate, "dp_shard": self.dp_shard, "cp": self.cp,
                    "tp": self.tp}
         names = tuple(n for n, d in degrees.items() if d > 1)
-        mesh = init_device_mesh(device_type, tuple(degrees[n] for n in names), mesh_dim_names=names)
         flat = {"dp": ("dp_replicate", "dp_shard"), "dp_shard_cp": ("dp_shard", "cp"),
                 "dp_cp": ("dp_replicate", "dp_shard", "cp")}
+        if _gloo_on_devices(device_type):
+            return GroupMesh({n: degrees[n] for n in names}, flat)
+        mesh = init_device_mesh(device_type, tuple(degrees[n] for n in names), mesh_dim_names=names)
         for flat_name, parts in flat.items():                    # all process groups are created here, up front
             present = tuple(n for n in parts if n in names)
             if present:
