@@ -81,6 +81,15 @@ def packed_attention(q, k, v, mask, scale=None):
     return _nn.attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), mask.allow, scale)
 
 
+def bidirectional_attention(q, k, v, mask, scale=None):
+    """every key of the query's own document, before and after it (transformers' WhisperEncoder self-attention as used at
+    touchnet/models/kimi_audio/modeling_kimi_audio.py:337-339, 942-947); pad rows give 0"""
+    scale = q.shape[-1] ** -0.5 if scale is None else scale
+    doc = mask.doc
+    allow = (doc[:, :, None] > 0) & (doc[:, :, None] == doc[:, None, :])
+    return _nn.attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), allow, scale)
+
+
 def _num_sentence_dev(num_sentence, device):
     if isinstance(num_sentence, torch.Tensor):
         return num_sentence.to(device=device, dtype=torch.float32).reshape(1)

@@ -926,11 +926,80 @@ def kimi_decoder_dev_case():
     save("kimi_decoder_dev.npz", **arrs)
 
 
+def kimi_audio_input_case():
+    """MoonshotKimiaForCausalLM.prepare_audio_input_embs (modeling_kimi_audio.py:933-985) RUN from the reference's source:
+    its CustomWhisperEncoder (transformers' WhisperEncoder) + VQAdaptor + embedding sum x sqrt(2) + masked_scatter between
+    the media markers, at kernel-sized tiny widths (head_dim 64) on bf16-rounded weights.  The method is called unbound on
+    a stand-in `self` that carries exactly the attributes it reads; the frozen GLM-4-voice speech tokenizer
+    (`self.speech_tokenizer`, out of scope) is a stub returning fixed ids.  A linear read-out of the result gives
+    gradients for every parameter on the path (encoder, adaptor, embedding)."""
+    mk = R.load_kimi_modeling()
+    from transformers import WhisperConfig
+    H, d, S4 = 128, 128, 4
+    dims = dict(num_mel_bins=16, d_model=d, encoder_layers=2, encoder_attention_heads=2, encoder_ffn_dim=256,
+                max_source_positions=40)
+    wcfg = WhisperConfig(**dims, dropout=0.0, attention_dropout=0.0, activation_dropout=0.0)
+    wcfg._attn_implementation = "sdpa"
+    torch.manual_seed(30)
+    enc = mk.CustomWhisperEncoder(wcfg).float().eval()
+    with torch.no_grad():                                 # (CustomWhisperEncoder skips HF's init: draw everything here)
+        for n, p in enc.named_parameters():
+            if p.dim() > 1:
+                p.normal_(std=0.05)
+            elif n.endswith("bias"):
+                p.normal_(std=0.02)
+            else:
+                p.fill_(1.0)
+        enc.embed_positions.weight.copy_(torch.randn_like(enc.embed_positions.weight) * 0.1)
+    kcfg = types.SimpleNamespace(kimia_adaptor_input_dim=S4 * d, hidden_size=H, rms_norm_eps=1e-6, kimia_token_offset=96)
+    adaptor = mk.VQAdaptor(kcfg).float()
+    emb = torch.nn.Embedding(160, H)
+    with torch.no_grad():
+        emb.weight.normal_(std=0.1)
+        for p in adaptor.parameters():
+            if p.dim() > 1:
+                p.normal_(std=0.05)
+    for m in (enc, adaptor, emb):
+        _bf16_round_(m)
+    g = torch.Generator().manual_seed(31)
+    B, T, begin, end = 2, 32, 90, 91
+    a = torch.randint(0, 80, (B, T), generator=g)
+    spans = [(3, 10), (5, 7)]                              # (position of the begin marker, frames between the markers)
+    for b, (p0, n) in enumerate(spans):
+        a[b, p0], a[b, p0 + n + 1] = begin, end
+    feats = torch.randn(B, 16, 80, generator=g).bfloat16().float()
+    ids = torch.randint(0, 60, (B, 10), generator=g)
+
+    class Tok:                                             # stand-in for the frozen WhisperVQEncoder (`:957-963`)
+        def __call__(self, input_features=None, attention_mask=None, return_dict=True):
+            return ids.clone()
+    fake = types.SimpleNamespace(speech_encoder=enc, speech_tokenizer=Tok(), config=kcfg,
+                                 model=types.SimpleNamespace(vq_adaptor=adaptor, kimia_media_begin=begin, kimia_media_end=end),
+                                 get_input_embeddings=lambda: emb)
+    fake.create_mask_between_markers = lambda **kw: mk.MoonshotKimiaForCausalLM.create_mask_between_markers(fake, **kw)
+    out = mk.MoonshotKimiaForCausalLM.prepare_audio_input_embs(fake, audio_input_ids=a, audio_input_embs=emb(a),
+                                                               whisper_input_features=feats, whisper_attention_mask=None)
+    readout = torch.randn(B, T, H, generator=g) * 0.1
+    (out * readout).sum().backward()
+    arrs = {f"param/speech_encoder.{n}": _bits(p) for n, p in enc.named_parameters()}
+    arrs["param/speech_encoder.embed_positions.weight"] = _bits(enc.embed_positions.weight)
+    arrs.update({f"param/model.vq_adaptor.{n}": _bits(p) for n, p in adaptor.named_parameters()})
+    arrs["param/model.embed_tokens.weight"] = _bits(emb.weight)
+    arrs.update({f"grad/speech_encoder.{n}": npy(p.grad).astype(np.float16) for n, p in enc.named_parameters() if p.grad is not None})
+    arrs.update({f"grad/model.vq_adaptor.{n}": npy(p.grad).astype(np.float16) for n, p in adaptor.named_parameters()})
+    arrs["grad/model.embed_tokens.weight"] = npy(emb.weight.grad).astype(np.float16)
+    arrs.update({"audio_input_ids": npy(a), "whisper_input_features": npy(feats), "speech_tokenizer_ids": npy(ids),
+                 "readout": npy(readout), "out": npy(out), "markers": np.array([begin, end]),
+                 "config_json": np.array(str(dict(dims, hidden_size=H, kimia_adaptor_input_dim=S4 * d, rms_norm_eps=1e-6,
+                                                  kimia_token_offset=96, vocab_size=160)))})
+    save("kimi_audio_input.npz", **arrs)
+
+
 if __name__ == "__main__":
     only = set(sys.argv[1:])
     for fn in (text_cases, asr_cases, ce_cases, docmask_cases, rope_cases, tiny_llama_case,
                touch_audio_case, qwen2_audio_tower_case, frontend_cases, fbank_cases, bestrq_cases, touchdataset_case,
                boundary_case, qwen2_audio_data_case, kimi_decoder_case, tiny_llama_dev_case, touch_audio_dev_case,
-               qwen2_audio_tower_dev_case, kimi_decoder_dev_case):
+               qwen2_audio_tower_dev_case, kimi_decoder_dev_case, kimi_audio_input_case):
         if not only or fn.__name__ in only:
             fn()

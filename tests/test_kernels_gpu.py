@@ -282,6 +282,37 @@ def test_packed_attention_fwd_bwd(B, T, Nh, Nkv, D, maxdoc, pad):
         assert float(qd.grad.float().cpu()[pad_rows].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("B,T,Nh,Nkv,D,maxdoc,pad", [(2, 300, 4, 4, 64, 300, 0), (1, 512, 4, 2, 128, 200, 40),
+                                                    (3, 1500, 2, 2, 64, 1500, 0)])
+def test_bidirectional_attention_from_two_causal_launches(B, T, Nh, Nkv, D, maxdoc, pad):
+    """functional.bidirectional_attention (Whisper's encoder self-attention for Kimi-Audio's speech encoder): keys at or
+    before the query + keys at or after it (the causal kernel on the reversed batch) merged by log-sum-exp, the diagonal
+    taken out once.  Against the fp32 oracle (softmax over all same-document keys): output, dQ, dK, dV; pad rows exactly 0."""
+    import oracle.ops as oops
+    F = _f()
+    doc = _docs(B, T, T + Nh, maxdoc, pad)
+    g = torch.Generator().manual_seed(T + 1)
+    q = torch.randn(B, T, Nh, D, generator=g).bfloat16()
+    k = torch.randn(B, T, Nkv, D, generator=g).bfloat16()
+    v = torch.randn(B, T, Nkv, D, generator=g).bfloat16()
+    do = torch.randn(B, T, Nh, D, generator=g).bfloat16()
+    qr, kr, vr = [_ref(t) for t in (q, k, v)]
+    ref = oops.bidirectional_attention(qr, kr, vr, oops.build_packed_mask(doc))
+    ref.backward(do.float())
+    qd, kd, vd = [_dev(t) for t in (q, k, v)]
+    out = F.bidirectional_attention(qd, kd, vd, F.build_packed_mask(doc.to(DEV)))
+    out.backward(do.to(DEV))
+    torch.cuda.synchronize()
+    _close(out, ref, 2e-2, 2e-2, "O")
+    pad_rows = (doc == 0)
+    if pad_rows.any():
+        assert float(out.float().cpu()[pad_rows].abs().max()) == 0.0
+        assert float(qd.grad.float().cpu()[pad_rows].abs().max()) == 0.0
+    _close(vd.grad, vr.grad, 4e-2, 3e-2, "dV")
+    _close(kd.grad, kr.grad, 4e-2, 3e-2, "dK")
+    _close(qd.grad, qr.grad, 4e-2, 3e-2, "dQ")
+
+
 def test_packed_attention_online_softmax_rescale():
     """Force a large running-max jump at a late KV tile (guide rule 26: the rescale branch needs its own test)."""
     F = _f()

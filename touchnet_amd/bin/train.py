@@ -148,7 +148,10 @@ class Trainer:
             view = {"dp_shard_cp": fsdp_mesh}
             if tp > 1:
                 view["tp"] = self.tp_mesh
-            model = self.spec.parallelize_fn(model, _MeshView(view), dims, job)
+            # (the flat engine, when chosen, is this Trainer's own business below: the hook is asked for FSDP2 / TP / AC)
+            import dataclasses
+            model = self.spec.parallelize_fn(model, _MeshView(view), dims,
+                                             dataclasses.replace(job, training_dp_engine="fsdp2"))
         if sharded:                                                # fp32 shards, bf16 compute
             model.to_empty(device=device)
             with torch.no_grad():

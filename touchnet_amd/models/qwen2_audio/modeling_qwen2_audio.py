@@ -75,9 +75,9 @@ class LayerNorm(nn.Module):
 
 
 class EncoderAttention(nn.Module):
-    def __init__(self, dim, heads):
+    def __init__(self, dim, heads, causal: bool = True):
         super().__init__()
-        self.num_heads, self.head_dim = heads, dim // heads
+        self.num_heads, self.head_dim, self.causal = heads, dim // heads, causal
         self.k_proj = nn.Linear(dim, dim, bias=False)
         self.v_proj = nn.Linear(dim, dim, bias=True)
         self.q_proj = nn.Linear(dim, dim, bias=True)
@@ -92,15 +92,17 @@ class EncoderAttention(nn.Module):
         q = q.view(B, T, self.num_heads, self.head_dim)
         k = k.view(B, T, self.num_heads, self.head_dim)
         v = v.view(B, T, self.num_heads, self.head_dim)
-        a = ops().packed_attention(q, k, v, mask, self.head_dim ** -0.5)
+        # (causal: the Qwen2-Audio tower as the reference forces it; bidirectional: Whisper's own encoder, Kimi-Audio)
+        attend = ops().packed_attention if self.causal else ops().bidirectional_attention
+        a = attend(q, k, v, mask, self.head_dim ** -0.5)
         return ops().linear_group(a.view(B, T, C), [(self.out_proj.weight, self.out_proj.bias)], wgrad="nt",
                                   dgrad_tn=False)[0]
 
 
 class EncoderLayer(nn.Module):
-    def __init__(self, cfg: AudioEncoderConfig):
+    def __init__(self, cfg: AudioEncoderConfig, causal: bool = True):
         super().__init__()
-        self.self_attn = EncoderAttention(cfg.d_model, cfg.encoder_attention_heads)
+        self.self_attn = EncoderAttention(cfg.d_model, cfg.encoder_attention_heads, causal)
         self.self_attn_layer_norm = LayerNorm(cfg.d_model)
         self.fc1 = nn.Linear(cfg.d_model, cfg.encoder_ffn_dim)
         self.fc2 = nn.Linear(cfg.encoder_ffn_dim, cfg.d_model)
@@ -124,14 +126,14 @@ TOWER_CONV_GEMM = os.environ.get("TN_TOWER_CONV", "own") != "miopen"
 
 
 class Qwen2AudioEncoder(nn.Module):
-    def __init__(self, cfg: AudioEncoderConfig):
+    def __init__(self, cfg: AudioEncoderConfig, causal: bool = True):
         super().__init__()
         self.config = cfg
         self.conv1 = nn.Conv1d(cfg.num_mel_bins, cfg.d_model, kernel_size=3, padding=1)
         self.conv2 = nn.Conv1d(cfg.d_model, cfg.d_model, kernel_size=3, stride=2, padding=1)
         self.embed_positions = nn.Embedding(cfg.max_source_positions, cfg.d_model)
         self.embed_positions.requires_grad_(False)
-        self.layers = nn.ModuleList([EncoderLayer(cfg) for _ in range(cfg.encoder_layers)])
+        self.layers = nn.ModuleList([EncoderLayer(cfg, causal) for _ in range(cfg.encoder_layers)])
         self.layer_norm = LayerNorm(cfg.d_model)
 
     def positions(self, seq_len):
