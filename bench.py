@@ -75,10 +75,12 @@ def llama_1b_text_config():
                          "original_max_position_embeddings": 8192, "rope_type": "llama3"}})
 
 
-def kimi_audio_7b_config():
+def kimi_audio_7b_config(use_whisper_feature: bool = False):
     from touchnet_amd.models.kimi_audio import KimiAudioConfig
-    # examples/audio/sft/asr/wenetspeech/config/Kimi-Audio-7B.json (the decoder keys)
+    # examples/audio/sft/asr/wenetspeech/config/Kimi-Audio-7B.json (the decoder keys; with `use_whisper_feature` also the
+    # whisper-large-v3 speech encoder + VQ adaptor: KimiAudioConfig's defaults)
     return KimiAudioConfig.from_dict({
+        "use_whisper_feature": use_whisper_feature,
         "hidden_size": 3584, "intermediate_size": 18944, "num_attention_heads": 28, "num_key_value_heads": 4,
         "num_hidden_layers": 28, "head_dim": 128, "rms_norm_eps": 1e-6, "rope_theta": 1000000.0, "vocab_size": 168448,
         "initializer_range": 0.02, "tie_word_embeddings": False, "kimia_mimo_layers": 6,
@@ -186,17 +188,32 @@ class Workload:
             self.data_desc = (f"synthetic long audio: documents of up to 40 consecutive 30 s windows (20 min, 750 audio "
                               f"tokens each) + ~50 transcript tokens per window, packed B={self.B} x T={self.T}: "
                               f"{n_audio} clips per row group, {len(clips)} of them on this rank")
-        elif name == "kimi_audio_7b":
-            self.B, self.T = B or 2, T or 8192
+        elif name in ("kimi_audio_7b", "kimi_audio_7b_speech"):
+            speech = name.endswith("_speech")
+            self.B, self.T = B or (1 if speech else 2), T or 8192
             self.job.training_model_name = "kimi_audio_mi355"
             self.job.lr_scheduler_lr = 2e-5
-            self.model_config = kimi_audio_7b_config()
+            self.model_config = kimi_audio_7b_config(use_whisper_feature=speech)
             self.seq_cfg = self.model_config
             c = self.model_config
             tok = synthetic.kimi_audio_plan(c.kimia_token_offset, c.kimia_token_offset, c.vocab_size - c.kimia_token_offset,
-                                            self.B, self.T, seed)
+                                            self.B, self.T, seed,
+                                            media_markers=(c.kimia_media_begin, c.kimia_media_end) if speech else None)
+            if speech:
+                # the reference batch's `whisper_input_features`: one 30 s-padded clip per media-marker pair; the log-mel
+                # runs on the device inside the step, like for the Qwen2-Audio workload
+                g = torch.Generator().manual_seed(seed)
+                clip_tokens = tok.pop("clip_tokens")
+                n_clips = len(clip_tokens)
+                wav = torch.zeros(n_clips, 480000)
+                for i, na in enumerate(clip_tokens):
+                    n = min(480000, max(int(na), 1) * 1280)
+                    wav[i, :n] = (torch.randn(n, generator=g) * 0.1).clamp_(-1, 1)
+                self.wav = wav.to(device)
             self.tokens = {k: (v.to(device) if isinstance(v, torch.Tensor) else v) for k, v in tok.items()}
-            self.data_desc = (f"synthetic interleaved audio/text: U[2, 14.5] s of 12.5 Hz audio codes on the audio stream, "
+            self.data_desc = ((f"synthetic Kimi-Audio SFT form: {n_clips} x 30 s-padded 16 kHz clips -> Whisper speech encoder "
+                               f"(1500 frames each) + VQ adaptor, written between the media markers; " if speech else "")
+                              + f"synthetic interleaved audio/text: U[2, 14.5] s of 12.5 Hz audio codes on the audio stream, "
                               f"then a U{{5..40}}-token transcript on the text stream (labels on the transcript, text head), "
                               f"packed B={self.B} x T={self.T}")
         elif name in ("llama_asr_1b", "tiny"):
@@ -219,6 +236,11 @@ class Workload:
         F = self.F
         if self.name == "kimi_audio_7b":
             return dict(self.tokens)                 # (discrete codes: the frozen VQ tokenizer is the loader's, out of scope)
+        if self.name == "kimi_audio_7b_speech":
+            mel = torch.stack([F.log_mel_spectrogram(w, 128) for w in self.wav])       # [n, 3000, 128]
+            batch = dict(self.tokens)
+            batch["whisper_input_features"] = mel.transpose(1, 2)
+            return batch
         if self.name.startswith("qwen2_audio_7b"):
             mel = torch.stack([F.log_mel_spectrogram(w, 128) for w in self.wav])       # [n, 3000, 128]
             batch = dict(self.tokens)
@@ -313,7 +335,15 @@ def executed_flops_per_gpu(wl: "Workload", trainer, layout: dict, lm_head_rows: 
     fl = 6.0 * layer * L * rows / tp
     fl += 3.5 * 4.0 * D * (Nh / tp) * pairs * L
     fl += 6.0 * c.vocab_size * H * lm_head_rows / (tp if wl.job.training_enable_loss_parallel else 1)
-    if hasattr(wl, "wav"):
+    if hasattr(wl, "wav") and wl.name == "kimi_audio_7b_speech":
+        # the speech encoder runs on all 1500 frames of every 30 s-padded clip (like the reference: transformers'
+        # WhisperEncoder ignores the frame mask), BIDIRECTIONAL attention: every (query, key) pair of a clip
+        ac = wl.model_config.speech_encoder_dims()
+        enc = sum(p.numel() for p in trainer.model.speech_encoder.parameters())
+        n = wl.wav.shape[0]
+        fl += 6.0 * enc * n * 1500 + 3.5 * 4.0 * 64 * ac.encoder_attention_heads * n * (1500 * 1500) * ac.encoder_layers
+        fl += 6.0 * (4 * ac.d_model * H + H * H) * n * 375                      # VQ adaptor on the x4-stacked frames
+    elif hasattr(wl, "wav"):
         ac = wl.model_config.audio_config
         tower = sum(p.numel() for p in trainer.model.audio_tower.parameters())
         n = wl.wav.shape[0]
@@ -547,7 +577,7 @@ def main():
     tokens_per_step = wl.B * wl.T * layout["dp"] / (share if emu else 1)
     tps = tokens_per_step * args.steps / elapsed
     gpus_in_job = 1 if emu else world
-    if wl.name == "kimi_audio_7b":
+    if wl.name.startswith("kimi_audio_7b"):
         # the recipe trains the TEXT head: the mimo branch (6 layers + the audio head) is not executed, and the reference
         # formula (kimi_audio/__init__.py:63-80: L + L_mimo layers, all parameters) must not be credited with it
         fpt = trainer.spec.get_num_flop_per_token_fn(trainer.num_params_wo_emb, wl.model_config, wl.T, with_mimo=False)
@@ -608,7 +638,7 @@ def main():
                          "note": "whole training step per GPU against the dense bf16 MFMA peak (reference MFU "
                                  "formula); per-kernel rooflines of the hand-written HIP kernels in `kernels`"},
         }
-        if wl.name == "kimi_audio_7b":
+        if wl.name.startswith("kimi_audio_7b"):
             line["mfu_convention"] = ("6*N + 12*L*H*Dh*T per token over the EXECUTED graph only: 28 decoder layers + text "
                                       "head (the reference formula, kimi_audio/__init__.py:63-80, also counts the 6 mimo "
                                       "layers and the audio head, which a text-head step never runs), times this GPU's "

@@ -995,11 +995,73 @@ def kimi_audio_input_case():
     save("kimi_audio_input.npz", **arrs)
 
 
+class _KimiTokenizer:
+    """Stand-in for the reference's BaseTokenizer over the Kimi vocabulary (tokenizers are out of scope): the special
+    tokens <|...|> of the two prompt templates map to fixed ids, every other character to 10 + ord % 200; same call
+    surface as used at processing_kimi_audio.py:82-110 (`tokenize(text, add_special_tokens=False)`, `.pad`)."""
+    SPECIAL = {"<|im_kimia_user_msg_start|>": 300, "<|im_kimia_text_blank|>": 301, "<|im_media_begin|>": 302,
+               "<|im_media_end|>": 303, "<|im_kimia_speech_ct_id|>": 304, "<|im_msg_end|>": 305,
+               "<|im_kimia_assistant_msg_start|>": 306, "<|im_kimia_text_eos|>": 307}
+    pad = 0
+
+    def tokenize(self, text, add_special_tokens=False):
+        ids, i = [], 0
+        while i < len(text):
+            for sp, v in self.SPECIAL.items():
+                if text.startswith(sp, i):
+                    ids.append(v)
+                    i += len(sp)
+                    break
+            else:
+                ids.append(10 + ord(text[i]) % 200)
+                i += 1
+        return ids
+
+
+def kimi_audio_data_case():
+    """The reference's Kimi-Audio batcher (processing_kimi_audio.py:37-224) RUN on synthetic waveforms with HF's
+    WhisperFeatureExtractor and the stand-in tokenizer above: token streams, labels, sentence lengths, masks, the
+    batching rule (two batches + the last one) and a sample of the log-mel features."""
+    from transformers import WhisperFeatureExtractor
+    sys.modules.setdefault("touchnet.data", types.ModuleType("touchnet.data")).DataConfig = object
+    dp = types.ModuleType("touchnet.data.datapipe")
+    dp.LowLevelTouchDatapipe = dp.MidLevelTouchDatapipe = object
+    sys.modules.setdefault("touchnet.data.datapipe", dp)
+    tk = types.ModuleType("touchnet.tokenizer.tokenizer")
+    tk.BaseTokenizer = object
+    sys.modules.setdefault("touchnet.tokenizer", types.ModuleType("touchnet.tokenizer"))
+    sys.modules.setdefault("touchnet.tokenizer.tokenizer", tk)
+    mod = R.load_file_as("ref_kimi_processing", "touchnet/models/kimi_audio/processing_kimi_audio.py")
+    proc = WhisperFeatureExtractor(feature_size=128)
+    rng = np.random.RandomState(13)
+    durs = [0.31, 1.0, 2.503, 0.9999, 4.0, 29.99, 0.05]
+    texts = ["ab", "hello world", "x", "the quick brown fox", "tail", "long", "tiny"]
+    samples = []
+    for d, tx in zip(durs, texts):
+        n = int(d * 16000)
+        samples.append({"waveform": torch.from_numpy((rng.randn(1, n) * 0.05).astype(np.float32)), "txt": tx})
+    samples[2]["instruct"] = "Translate:"
+    cfg = types.SimpleNamespace(dataset_batchsize=2, dataset_text_seqlen=100, dataloader_drop_last_batch=False,
+                                text_min_length_in_tokens_for_filter=1, text_max_length_in_tokens_for_filter=420)
+    batches = list(mod.dynamic_batch(iter([dict(s) for s in samples]), cfg, proc, _KimiTokenizer()))
+    out = {"n_batches": np.array(len(batches)), "durations": np.array(durs), "texts": np.array(texts), "wave_seed": np.array(13)}
+    for i, b in enumerate(batches):
+        for k in ("text_input_ids", "audio_input_ids", "attention_mask", "labels", "sentence_lens"):
+            out[f"b{i}/{k}"] = npy(b[k])
+        out[f"b{i}/num_sentence"] = np.array(b["num_sentence"])
+        out[f"b{i}/whisper_attention_mask_sum"] = npy(b["whisper_attention_mask"].sum(1))
+        feat = npy(b["whisper_input_features"])                      # [n, 128, 3000]
+        out[f"b{i}/mel_head"] = feat[:, :, :40].astype(np.float32)
+        out[f"b{i}/mel_strided"] = feat[:, :, ::97].astype(np.float32)
+    save("kimi_audio_data.npz", **out)
+
+
 if __name__ == "__main__":
     only = set(sys.argv[1:])
     for fn in (text_cases, asr_cases, ce_cases, docmask_cases, rope_cases, tiny_llama_case,
                touch_audio_case, qwen2_audio_tower_case, frontend_cases, fbank_cases, bestrq_cases, touchdataset_case,
                boundary_case, qwen2_audio_data_case, kimi_decoder_case, tiny_llama_dev_case, touch_audio_dev_case,
-               qwen2_audio_tower_dev_case, kimi_decoder_dev_case, kimi_audio_input_case):
+               qwen2_audio_tower_dev_case, kimi_decoder_dev_case, kimi_audio_input_case,
+               kimi_audio_data_case):
         if not only or fn.__name__ in only:
             fn()

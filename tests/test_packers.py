@@ -154,3 +154,67 @@ def test_synthetic_short_utterance_plan_counts_audio_tokens_like_the_batcher():
     ref, n_ref = synthetic.qwen2_audio_plan(156032, 151646, 2, 8192, 2025)
     assert n_ref == 20 and ref["audio_positions"].numel() == 15000 and ref["labelled_rows_max"] == 526
     assert np.unique(ref["audio_output_lengths"].numpy()).tolist() == [750]
+
+
+class _KimiTok:
+    """the stand-in tokenizer tests/golden/make_golden.py::_KimiTokenizer ran the reference's batcher with"""
+    SPECIAL = {"<|im_kimia_user_msg_start|>": 300, "<|im_kimia_text_blank|>": 301, "<|im_media_begin|>": 302,
+               "<|im_media_end|>": 303, "<|im_kimia_speech_ct_id|>": 304, "<|im_msg_end|>": 305,
+               "<|im_kimia_assistant_msg_start|>": 306, "<|im_kimia_text_eos|>": 307}
+    pad = 0
+
+    def tokenize(self, text, add_special_tokens=False):
+        ids, i = [], 0
+        while i < len(text):
+            for sp, v in self.SPECIAL.items():
+                if text.startswith(sp, i):
+                    ids.append(v)
+                    i += len(sp)
+                    break
+            else:
+                ids.append(10 + ord(text[i]) % 200)
+                i += 1
+        return ids
+
+
+def test_kimi_audio_batcher_equals_the_reference_dynamic_batch(golden):
+    """models/kimi_audio/processing_kimi_audio.py::batch_kimi_audio against the batches the reference's `dynamic_batch`
+    (touchnet/models/kimi_audio/processing_kimi_audio.py:37-224) produced from the same waveforms (kimi_audio_data.npz):
+    both token streams, labels, sentence lengths, masks and the batching rule bit-exact; log-mel features (oracle
+    frontend here, the HIP kernel is held to the same fixture family on the device) at 1e-3."""
+    import types
+
+    import numpy as np
+    import oracle.ops as oops
+    from touchnet_amd.models.backend import use_ops
+    from touchnet_amd.models.kimi_audio.processing_kimi_audio import batch_kimi_audio, num_audio_tokens
+    g = golden("kimi_audio_data.npz")
+    rng = np.random.RandomState(int(g["wave_seed"]))
+    samples = []
+    for d, tx in zip(g["durations"], g["texts"]):
+        n = int(float(d) * 16000)
+        samples.append({"waveform": torch.from_numpy((rng.randn(1, n) * 0.05).astype(np.float32)), "txt": str(tx)})
+    samples[2]["instruct"] = "Translate:"
+    cfg = types.SimpleNamespace(dataset_batchsize=2, dataset_text_seqlen=100, dataloader_drop_last_batch=False,
+                                text_min_length_in_tokens_for_filter=1, text_max_length_in_tokens_for_filter=420)
+    with use_ops(oops):
+        batches = list(batch_kimi_audio(iter(samples), cfg, None, _KimiTok(),
+                                        speech_tokenizer=lambda f, m: torch.arange(375) % 7))
+    assert len(batches) == int(g["n_batches"]) and len(batches) >= 3
+    for i, b in enumerate(batches):
+        for k in ("text_input_ids", "audio_input_ids", "attention_mask", "labels", "sentence_lens"):
+            assert torch.equal(b[k], torch.tensor(g[f"b{i}/{k}"])), (i, k)
+        assert b["num_sentence"] == int(g[f"b{i}/num_sentence"])
+        assert torch.equal(b["whisper_attention_mask"].sum(1).cpu().long(), torch.tensor(g[f"b{i}/whisper_attention_mask_sum"]).long())
+        feat = b["whisper_input_features"].cpu().numpy()
+        assert feat.shape[1:] == (128, 3000)
+        np.testing.assert_allclose(feat[:, :, :40], g[f"b{i}/mel_head"], atol=1e-3)
+        np.testing.assert_allclose(feat[:, :, ::97], g[f"b{i}/mel_strided"], atol=1e-3)
+        # one media-marker pair per row with exactly num_audio_tokens blanks between them; ids for the model's scatter
+        a = b["audio_input_ids"]
+        for r in range(a.shape[0]):
+            p0, p1 = int((a[r] == 302).nonzero()[0]), int((a[r] == 303).nonzero()[0])
+            assert p1 - p0 - 1 == -(-int(b["whisper_attention_mask"][r].sum()) // 8)
+        assert b["speech_tokenizer_ids"].shape == (a.shape[0], 375)
+        assert b["labelled_rows_max"] == int((b["labels"] != -100).sum())
+    assert num_audio_tokens(1) == 1 and num_audio_tokens(1281) == 2 and num_audio_tokens(480000) == 375

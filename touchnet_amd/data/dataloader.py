@@ -197,6 +197,12 @@ def build_datapipe(cfg, tokenizer, dp_rank: int, dp_world_size: int):
     if kind == "qwen2_audio":
         from touchnet_amd.models.qwen2_audio.processing_qwen2_audio import batch_qwen2_audio_packed
         return stage(batch_qwen2_audio_packed, cfg, tokenizer)
+    if kind == "kimi_audio":
+        # kimi_audio_datapipe (processing_kimi_audio.py:227-241): the reference's batcher takes (processor, tokenizer);
+        # the features are computed on the device here, the frozen speech tokenizer — when the loader has one — rides on
+        # the data config (`speech_tokenizer`: callable(features, mask) -> ids)
+        from touchnet_amd.models.kimi_audio.processing_kimi_audio import batch_kimi_audio
+        return stage(batch_kimi_audio, cfg, None, tokenizer, getattr(cfg, "speech_tokenizer", None))
     raise NotImplementedError(f"datapipe_type {kind!r}")
 
 

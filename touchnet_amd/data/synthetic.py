@@ -198,7 +198,8 @@ def qwen2_audio_long_plan(vocab: int, audio_token: int, batchsize: int, seqlen: 
 
 
 def kimi_audio_plan(vocab_text: int, audio_code_base: int, n_codes: int, batchsize: int, seqlen: int, seed: int = 2025,
-                    blank_id: int = 0, audio_s=(2.0, 14.5), codes_per_s: float = 12.5, text_tokens=(5, 40)):
+                    blank_id: int = 0, audio_s=(2.0, 14.5), codes_per_s: float = 12.5, text_tokens=(5, 40),
+                    media_markers=None):
     """Config E ("text / audio id streams of equal length (processing_kimi_audio.py:112-116),
     V=168448 logits, text head only"): interleaved audio/text documents — a span of discrete audio codes (12.5 Hz GLM-4
     voice tokens of a U[audio_s] s utterance) on the AUDIO stream with blanks on the TEXT stream, then its transcript on
@@ -213,6 +214,7 @@ def kimi_audio_plan(vocab_text: int, audio_code_base: int, n_codes: int, batchsi
     doc = np.zeros((B, T), dtype=np.int64)
     sentence_lens = np.ones((B, T), dtype=np.int64)
     n_sent = n_lab = 0
+    clip_codes = []
     for b in range(B):
         col, d = 0, 1
         while True:
@@ -222,8 +224,16 @@ def kimi_audio_plan(vocab_text: int, audio_code_base: int, n_codes: int, batchsi
             if col + tot > T:
                 break
             a0 = col + 1
-            audio[b, a0:a0 + na] = audio_code_base + rng.randint(0, n_codes, size=na)
-            text[b, col], text[b, a0 + na] = 3, 4
+            codes = rng.randint(0, n_codes, size=na)
+            if media_markers is None:
+                audio[b, a0:a0 + na] = audio_code_base + codes
+                text[b, col], text[b, a0 + na] = 3, 4
+            else:
+                # the reference's prompt form (processing_kimi_audio.py:33-34): blanks between <|im_media_begin|> and
+                # <|im_media_end|> on the AUDIO stream — the model writes the continuous speech embeddings there
+                # (modeling_kimi_audio.py:969-978); the speech tokenizer's ids of the clip travel beside the batch
+                audio[b, col], audio[b, a0 + na] = media_markers
+                clip_codes.append(codes)
             ids = rng.randint(5, vocab_text - 2000, size=nt)
             t0 = a0 + na + 1
             text[b, t0:t0 + nt] = ids
@@ -237,6 +247,13 @@ def kimi_audio_plan(vocab_text: int, audio_code_base: int, n_codes: int, batchsi
             n_sent += 1
             n_lab += nt + 1
     t = torch.from_numpy
-    return {"text_input_ids": t(text), "audio_input_ids": t(audio), "labels": t(labels),
-            "position_ids": t(position_ids), "attention_mask": t(doc), "sentence_lens": t(sentence_lens),
-            "num_sentence": n_sent, "labelled_rows_max": n_lab}
+    out = {"text_input_ids": t(text), "audio_input_ids": t(audio), "labels": t(labels),
+           "position_ids": t(position_ids), "attention_mask": t(doc), "sentence_lens": t(sentence_lens),
+           "num_sentence": n_sent, "labelled_rows_max": n_lab}
+    if media_markers is not None:
+        ids = np.zeros((len(clip_codes), 375), dtype=np.int64)         # 30 s-padded clips: 375 tokens, the first na used
+        for i, c in enumerate(clip_codes):
+            ids[i, :len(c)] = c
+        out["speech_tokenizer_ids"] = t(ids)
+        out["clip_tokens"] = [len(c) for c in clip_codes]
+    return out
