@@ -475,6 +475,9 @@ def main():
                     help="with --tp: vocabulary-parallel lm_head + CE (the reference's enable_loss_parallel)")
     ap.add_argument("--no-sequence-parallel", action="store_true",
                     help="with --tp: keep the residual stream / norms replicated (all-reduce per block output)")
+    ap.add_argument("--emulate-shards", type=int, default=0,
+                    help="with --emulate-rank: shard the optimizer state / gradient buckets like rank 0 of a data-parallel "
+                         "group of this size (flat engine, collectives replaced by local copies): a real rank's MEMORY")
     ap.add_argument("--dp-engine", choices=("flat", "fsdp2"), default=None,
                     help="data parallelism for N > 1: flat (default) = utils/zero_dp.py, flat per-block buffers + sharded "
                          "optimizer state; fsdp2 = torch fully_shard as the reference applies it (TN_DP_ENGINE)")
@@ -504,6 +507,9 @@ def main():
     dp_rank, cp_view = rank, None
     emu = layout["emulated"]
     if emu:
+        if args.emulate_shards > 1:
+            from touchnet_amd.utils.zero_dp import EmulatedShardMesh
+            fsdp_mesh = EmulatedShardMesh(args.emulate_shards, 0)
         if emu["group"] == "cp":
             cp_emulate = cp_view = (emu["size"], emu["rank"])
         else:
@@ -633,6 +639,7 @@ def main():
             "nonpad_tokens_per_step_rank0": nonpad,
             "loss_per_sample_last": round(loss, 5), "hip_event_ms_per_step_rank0": round(ev_ms, 2),
             "peak_mem_GB_rank0": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
+            **({"emulated_state_shards": args.emulate_shards} if args.emulate_shards > 1 else {}),
             "roofline": {"bound": "mfma", "achieved": round(fpt * (tps / gpus_in_job) / 1e12, 1), "peak": MFMA_PEAK / 1e12,
                          "unit": "TFLOP/s", "frac": round(mfu, 4), "traffic": None,
                          "note": "whole training step per GPU against the dense bf16 MFMA peak (reference MFU "
@@ -712,7 +719,9 @@ def main():
         # HBM traffic: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this same command (scripts/step_traffic.sh), kept only
         # while it describes the code that is running: the file carries the digest of the kernel sources and the GEMM
         # mode it was taken with, and a stale one is reported as such instead of as a number
-        tfile = os.path.join(ROOT, "profiles", f"r03_step_hbm_traffic_{wl.name}.json")
+        import glob as _glob
+        cands = sorted(_glob.glob(os.path.join(ROOT, "profiles", f"r*_step_hbm_traffic_{wl.name}.json")))
+        tfile = cands[-1] if cands else ""                      # (the newest round's measurement)
         if os.path.exists(tfile):
             t = json.load(open(tfile))
             stamp = os.path.join(ROOT, "touchnet_amd", "_lib", "build.stamp")

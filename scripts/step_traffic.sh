@@ -2,7 +2,7 @@
 # HBM traffic of one training step from the PMC counters (MI355X_MICROARCH.md, HBM section: FETCH_SIZE and WRITE_SIZE
 # in separate passes, kernel trace only; FETCH_SIZE x 2 on gfx950 for wide coalesced streams; both in KiB).
 #   usage (on the GPU box, from the repo root): bash scripts/step_traffic.sh [workload]
-# writes gpurun_out/step_traffic/{fetch,write}/... and gpurun_out/r03_step_hbm_traffic_<workload>.json (copy it to
+# writes gpurun_out/step_traffic/{fetch,write}/... and gpurun_out/<round>_step_hbm_traffic_<workload>.json (round tag: TN_ROUND, default r04) (copy it to
 # profiles/: bench.py reports it as roofline.traffic while its kernel-source digest and GEMM mode match the running code)
 set -e
 wl=${1:-qwen2_audio_7b}
@@ -46,6 +46,6 @@ out = {"workload": wl, "kernel_sources_digest": open(stamp).read().strip() if os
                  f"--warmup {warm}: kernels between consecutive optimizer steps ({n} whole steps averaged; model init and "
                  f"the first step excluded); FETCH_SIZE doubled per the gfx950 correction",
        "top_kernels_GB_per_step": {k: round(byt(v) / 1e9, 2) for k, v in top}}
-json.dump(out, open(f"gpurun_out/r03_step_hbm_traffic_{wl}.json", "w"), indent=1)
+json.dump(out, open(f"gpurun_out/{os.environ.get('TN_ROUND', 'r04')}_step_hbm_traffic_{wl}.json", "w"), indent=1)
 print(json.dumps(out)[:900])
 PY

@@ -65,6 +65,20 @@ class Shard:
     dtype = property(lambda self: self.data.dtype)
 
 
+class EmulatedShardMesh:
+    """Stand-in mesh for `FlatShardedDataParallel`: one process as rank `rank` of a `size`-rank data-parallel group."""
+    emulated = True
+
+    def __init__(self, size: int, rank: int = 0):
+        self._size, self.rank = int(size), int(rank)
+
+    def size(self, dim=None):
+        return self._size
+
+    def get_group(self, dim=None):
+        return None
+
+
 class _Bucket:
     def __init__(self, name: str, params: List[nn.Parameter], world: int, rank: int, mesh):
         self.name, self.params = name, params
@@ -102,8 +116,15 @@ class FlatShardedDataParallel:
         the remaining parameters.  Inside a bucket that does take part, a parameter without a gradient counts as a zero
         gradient (torch would skip it; no such parameter exists in the models of this path)."""
         self.model, self.mesh = model, mesh
-        self.group = mesh.get_group()
-        self.world, self.rank = dist.get_world_size(self.group), dist.get_rank(self.group)
+        # `EmulatedShardMesh(N, r)`: ONE process plays rank r of an N-rank group (bench.py --emulate-shards): buckets,
+        # shard sizes, optimizer state and the staging pool are a real rank's; the reduce-scatter is replaced by a copy of
+        # this rank's slice, the all-gather is skipped (the other slices go stale: timing / memory emulation only)
+        self.emulated = bool(getattr(mesh, "emulated", False))
+        if self.emulated:
+            self.group, self.world, self.rank = None, mesh.size(), mesh.rank
+        else:
+            self.group = mesh.get_group()
+            self.world, self.rank = dist.get_world_size(self.group), dist.get_rank(self.group)
         self.reduce_dtype = reduce_dtype
         # One rank (TN_FORCE_FSDP=1 on a single GPU): reduce-scatter and all-gather are the identity, so the hooks write
         # straight into the persistent gradient shard and no collective is issued — RCCL would run its generic one-rank
@@ -119,7 +140,7 @@ class FlatShardedDataParallel:
             ps = [p for p in blk.parameters() if p.requires_grad and id(p) not in seen]
             seen.update(id(p) for p in ps)
             if ps:
-                self.buckets.append(_Bucket(f"block.{name}", ps, self.world, self.rank, mesh))
+                self.buckets.append(_Bucket(f"block.{name}", ps, self.world, self.rank, None if self.emulated else mesh))
                 self._hooked_modules.append((blk, self.buckets[-1]))
         # the remaining parameters: one bucket per owning module (embedding, final norm, each head, projector, stem ...).
         # A bucket is all-or-nothing for the optimizer: one NONE of whose parameters took part in a step is skipped like
@@ -130,7 +151,7 @@ class FlatShardedDataParallel:
             ps = [p for p in mod.parameters(recurse=False) if p.requires_grad and id(p) not in seen]
             seen.update(id(p) for p in ps)
             if ps:
-                self.rest.append(_Bucket(f"rest.{mname or 'root'}", ps, self.world, self.rank, mesh))
+                self.rest.append(_Bucket(f"rest.{mname or 'root'}", ps, self.world, self.rank, None if self.emulated else mesh))
         self.buckets += self.rest
         self._of = {}
         for b in self.buckets:
@@ -139,7 +160,8 @@ class FlatShardedDataParallel:
                 p.register_post_accumulate_grad_hook(self._on_grad)
         # every replica starts from rank 0's numbers (the seeds agree already; this makes it unconditional)
         for b in self.buckets:
-            dist.broadcast(b.flat_p, src=dist.get_global_rank(self.group, 0), group=self.group)
+            if not self.emulated:
+                dist.broadcast(b.flat_p, src=dist.get_global_rank(self.group, 0), group=self.group)
         self.comm = torch.cuda.Stream(device=self.device) if self.cuda else None
         self._pool, self._pool_free_at = [], []          # staging buffers + the event after which each is reusable
         self._pool_numel = max(b.total for b in self.buckets if b not in self.rest) if len(self.rest) < len(self.buckets) else 0
@@ -255,13 +277,19 @@ class FlatShardedDataParallel:
             for st in F.wgrad_streams():                 # everything that wrote this bucket's views, wherever it ran
                 self.comm.wait_stream(st)
             with torch.cuda.stream(self.comm):
-                dist.reduce_scatter_tensor(b.gshard, b.stage, op=self.avg, group=self.group)
+                if self.emulated:
+                    b.gshard.copy_(b.stage[self.rank * b.S:(self.rank + 1) * b.S])
+                else:
+                    dist.reduce_scatter_tensor(b.gshard, b.stage, op=self.avg, group=self.group)
                 b.reduced = torch.cuda.Event()
                 b.reduced.record()
             if b not in self.rest:
                 self._pool_free_at[b._slot] = b.reduced
         else:
-            dist.reduce_scatter_tensor(b.gshard, b.stage, op=self.avg, group=self.group)
+            if self.emulated:
+                b.gshard.copy_(b.stage[self.rank * b.S:(self.rank + 1) * b.S])
+            else:
+                dist.reduce_scatter_tensor(b.gshard, b.stage, op=self.avg, group=self.group)
             if b not in self.rest:
                 self._pool_free_at[b._slot] = None
         b.launched = True
@@ -299,7 +327,7 @@ class FlatShardedDataParallel:
     def gather_params(self) -> None:
         """After the optimizer step (it rewrote this rank's slice of every flat buffer): all-gather the slices in the order
         the next forward needs them, on the side stream."""
-        if self.identity:
+        if self.identity or self.emulated:
             return
         order = self.rest + [b for b in self.buckets if b not in self.rest]
         if self.cuda:
