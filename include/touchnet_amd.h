@@ -166,6 +166,14 @@ int tn_adamw_multi(void* const* ps, void* const* ms, void* const* vs, const void
                    const long long* sizes, const long long* first_chunk, int ntensors, long long nchunks,
                    const float* state, float lr, float beta1, float beta2, float eps, float weight_decay, int g_dtype,
                    void* stream);
+/* The same update from at most `max_workgroups` workgroups (0 = one per chunk = tn_adamw_multi), each striding over the
+ * chunks: the form for a SIDE stream, where the update runs beside the next forward's kernels and must leave them the
+ * machine — the unbounded launch takes the whole HBM bandwidth and the MFMA kernels beside it run at half speed
+ * (profiles/r04e_*).  Same arithmetic per element. */
+int tn_adamw_multi_bounded(void* const* ps, void* const* ms, void* const* vs, const void* const* gs, void* const* shadows,
+                           const long long* sizes, const long long* first_chunk, int ntensors, long long nchunks,
+                           const float* state, float lr, float beta1, float beta2, float eps, float weight_decay,
+                           int g_dtype, int max_workgroups, void* stream);
 
 /* ---- bf16 transpose for the weight-gradient GEMMs of the linear layers: dst[c*dst_ld + r] = src[r*src_ld + c].
  *      Replaces the implicit operand transposes of torch.nn.functional.linear's backward (every nn.Linear of the

@@ -192,21 +192,14 @@ def test_fused_adamw_multi_tensor_mixed_shapes():
                 assert torch.equal(p.data, st["master"].bfloat16())    # the shadow the next forward reads
 
 
-@pytest.mark.parametrize("lens", [(40, 40, 40), (40, 17, 28)])
-def test_qwen2_audio_packed_forward_backward_small(lens):
-    """lens = audio tokens per clip.  (40, 40, 40): every frame of the padded clips reaches the decoder, the tower runs per
-    clip.  (40, 17, 28): clips shorter than their padding — the product tower runs on the kept frames only, packed
-    (Qwen2AudioEncoder.forward_valid), while the oracle follows the reference: all frames, then `:202-205`'s compaction."""
-    import touchnet_amd.specs  # noqa: F401
-    from touchnet_amd.bin.train import TrainConfig, Trainer
-    from touchnet_amd.models.qwen2_audio import Qwen2AudioConfig, Qwen2AudioPackedForConditionalGeneration
+def _qwen2_audio_small(lens):
+    """config + packed batch of the small Qwen2-Audio cases: three clips of `lens` audio tokens in three documents"""
+    from touchnet_amd.models.qwen2_audio import Qwen2AudioConfig
     cfg = Qwen2AudioConfig.from_dict({
         "audio_config": {"d_model": 128, "encoder_attention_heads": 2, "encoder_ffn_dim": 256, "encoder_layers": 2,
                          "max_source_positions": 50, "num_mel_bins": 16},
         "audio_token_index": 500,
         "text_config": dict(TEXT, model_type="qwen2", tie_word_embeddings=False, rope_scaling=None)})
-    tr = Trainer(TrainConfig(training_model_name="qwen2_audio_mi355", training_enable_fused_ce=False), cfg,
-                 torch.device(DEV))
     g = torch.Generator().manual_seed(0)
     B, T, n_audio, Tm = 2, 128, 3, 160          # 160 mel frames -> 80 -> 40 audio tokens (tiled positions: 80 > 50)
     ids = torch.randint(3, 480, (B, T), generator=g)
@@ -226,6 +219,20 @@ def test_qwen2_audio_packed_forward_backward_small(lens):
     batch = {"input_ids": ids, "labels": labels, "position_ids": pos, "attention_mask": doc, "sentence_lens": sl,
              "num_sentence": 3, "input_features": torch.randn(n_audio, 16, Tm, generator=g),
              "audio_positions": torch.cat(apos), "audio_output_lengths": torch.tensor(lens)}
+    return cfg, batch
+
+
+@pytest.mark.parametrize("lens", [(40, 40, 40), (40, 17, 28)])
+def test_qwen2_audio_packed_forward_backward_small(lens):
+    """lens = audio tokens per clip.  (40, 40, 40): every frame of the padded clips reaches the decoder, the tower runs per
+    clip.  (40, 17, 28): clips shorter than their padding — the product tower runs on the kept frames only, packed
+    (Qwen2AudioEncoder.forward_valid), while the oracle follows the reference: all frames, then `:202-205`'s compaction."""
+    import touchnet_amd.specs  # noqa: F401
+    from touchnet_amd.bin.train import TrainConfig, Trainer
+    from touchnet_amd.models.qwen2_audio import Qwen2AudioPackedForConditionalGeneration
+    cfg, batch = _qwen2_audio_small(lens)
+    tr = Trainer(TrainConfig(training_model_name="qwen2_audio_mi355", training_enable_fused_ce=False), cfg,
+                 torch.device(DEV))
     cpu_batch = dict(batch)
     cpu_batch["input_features"] = batch["input_features"].bfloat16().float()
     import touchnet_amd.models.qwen2_audio.modeling_qwen2_audio as mq
@@ -521,3 +528,51 @@ def test_dataloader_thread_uses_the_callers_device_and_orders_batches_by_event(m
     assert seen["thread"] != threading.current_thread().name
     assert (seen["thread"], torch.cuda.current_device()) in calls          # the producer thread adopted our device
     assert seen["stream"] not in (side.cuda_stream, torch.cuda.default_stream().cuda_stream)
+
+
+@pytest.mark.parametrize("family", ["llama", "qwen2_audio"])
+def test_optimizer_updates_under_the_next_forward_train_identically(family):
+    """`training_pipeline_optimizer`: the AdamW launches run block by block on a side stream and every block's forward
+    waits for ITS update only (utils/optimizer.py).  With the update stream HELD BACK by ~20 ms per step (so that a
+    consumer without a wait would read stale parameters) four steps give bit-identical losses, norms and parameters to
+    the Trainer that runs the update in front of the forward — and with the waits taken away they do NOT (the delay makes
+    the test sensitive to a missing wait)."""
+    import touchnet_amd.specs  # noqa: F401
+    from touchnet_amd.bin.train import TrainConfig, Trainer
+    from touchnet_amd.data.synthetic import text_batch
+    from touchnet_amd.models.llama import DecoderConfig
+    if family == "llama":
+        cfg = DecoderConfig.from_dict(TEXT)
+        job = dict(training_model_name="llama_mi355", lr_scheduler_warmup_steps=0, lr_scheduler_lr=2e-3)
+        batches = [text_batch(512, 4, 256, seed=s, max_len=60) for s in range(4)]
+    else:
+        cfg, b0 = _qwen2_audio_small((40, 17, 28))
+        job = dict(training_model_name="qwen2_audio_mi355", lr_scheduler_warmup_steps=0, lr_scheduler_lr=2e-3)
+        batches = [b0] * 4
+
+    def run(pipeline, delay=0, drop_hooks=False):
+        tr = Trainer(TrainConfig(**job, training_pipeline_optimizer=pipeline), cfg, torch.device(DEV))
+        assert (tr.optimizer._pipe is not None) == pipeline
+        if pipeline:
+            tr.optimizer._pipe_delay_cycles = delay
+        if drop_hooks:
+            for m in tr.model.modules():
+                m._forward_pre_hooks.clear()
+                m._forward_hooks.clear()
+        out = []
+        for b in batches:
+            r = tr.train_step(tr.next_batch(b))
+            out.append((float(r["loss_per_sample"]), float(r["grad_norm"])))
+        tr.optimizer.wait_updates()
+        torch.cuda.synchronize()
+        return out, {n: p.detach().clone() for n, p in tr.model.named_parameters()}, tr
+
+    ref, p_ref, _ = run(False)
+    got, p_got, tr = run(True, delay=40_000_000)
+    assert got == ref, (got, ref)
+    for n in p_ref:
+        assert torch.equal(p_ref[n], p_got[n]), n
+    groups, order = tr.optimizer._pipe[0], tr.optimizer._pipe[4]
+    assert len(groups) >= 4 and sorted(order) == list(range(len(groups))) and order[0] == 0
+    stale, _, _ = run(True, delay=40_000_000, drop_hooks=True)
+    assert stale != ref, "the held-back update stream did not show: the test cannot see a missing wait"

@@ -62,6 +62,7 @@ PROTOTYPES = {
     "tn_adamw_multi_chunk": [],
     "tn_adamw_prepare": [_vp, _vp, _f, _f, _f, _vp],
     "tn_adamw_multi": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _ll, _vp, _f, _f, _f, _f, _f, _i, _vp],
+    "tn_adamw_multi_bounded": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _ll, _vp, _f, _f, _f, _f, _f, _i, _i, _vp],
     "tn_pack_plan": [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "tn_pack_fill": [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _ll, _ll, _ll, _vp, _vp, _vp,
                      _vp, _vp, _vp, _vp, _vp],

@@ -49,6 +49,10 @@ class TrainConfig:
     training_ce_chunk_tokens: int = 4096       # rows of logits alive at once in the fused lm_head + CE (4096 x V x 2 B)
     training_cp_halo_exchange: bool = True     # CP: point-to-point exchange of the K/V chunks a rank can see (else all-gather)
     training_ce_compact_rows: bool = False     # opt-in: lm_head only on labelled positions (one host sync per step)
+    training_pipeline_optimizer: bool = False  # unsharded parameters on a GPU: the AdamW launches run block by block on a
+                                               # side stream under the NEXT forward (utils/optimizer.py); same arithmetic.
+                                               # Measured: NO gain on the 7B step (profiles/r04e_*: the HBM-bound update
+                                               # and the MFMA-bound forward share one power budget), so it is opt-in
     lr_scheduler_lr: float = 8e-4
     lr_scheduler_warmup_steps: int = 2000
     lr_scheduler_steps: int = 100000
@@ -189,6 +193,12 @@ class Trainer:
                                         weight_decay=job.optimizer_weight_decay, max_norm=job.training_max_norm,
                                         process_group=fsdp_mesh.get_group() if sharded else None,
                                         tp_group=tp_group, tp_param_ids=tp_ids)
+            want = os.environ.get("TN_PIPELINE_OPTIMIZER")              # "1" / "0" override the job's flag (A/B runs)
+            want = job.training_pipeline_optimizer if want is None else want == "1"
+            if (want and device.type == "cuda" and not sharded
+                    and not any(hasattr(p, "_local_tensor") for p in model.parameters())):
+                from touchnet_amd.utils.optimizer import pipeline_updates_under_forward
+                pipeline_updates_under_forward(model, self.optimizer)
         self.step = 0
 
     # ------------------------------------------------------------------ data

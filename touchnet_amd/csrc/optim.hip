@@ -188,10 +188,13 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(float* const* __restri
                                                           bf16_t* const* __restrict__ shadows,
                                                           const long long* __restrict__ sizes,
                                                           const long long* __restrict__ first_chunk, int ntensors,
+                                                          long long nchunks,
                                                           const float* __restrict__ state, float lr, float b1, float b2,
                                                           float eps, float wd) {
   if (state[4] != 0.f) return;                       // NaN / Inf total norm: the whole step is skipped
-  const long long c = blockIdx.x;
+  // one chunk per workgroup — or, with a bounded grid (tn_adamw_multi_bounded), a stride of gridDim.x chunks: the few
+  // resident workgroups then take a bounded share of the HBM bandwidth beside another stream's kernels
+  for (long long c = blockIdx.x; c < nchunks; c += gridDim.x) {
   int lo = 0, hi = ntensors - 1;                     // last t with first_chunk[t] <= c
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
@@ -247,6 +250,7 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(float* const* __restri
     m[i] = mi;
     v[i] = vi;
     if (shadow) shadow[i] = f2bf(pi);
+  }
   }
 }
 
@@ -336,24 +340,33 @@ int tn_adamw_prepare(const float* norm_sq, float* state, float beta1, float beta
 // Device tables of `ntensors` entries: p / m / v (fp32), g (g_dtype), shadow (bf16 copy of p or NULL), sizes
 // (elements, > 0), first_chunk[t] = sum_{u<t} ceil(sizes[u] / tn_adamw_multi_chunk()).  Uses the state written by
 // tn_adamw_prepare on the same stream.
-int tn_adamw_multi(void* const* ps, void* const* ms, void* const* vs, const void* const* gs, void* const* shadows,
-                   const long long* sizes, const long long* first_chunk, int ntensors, long long nchunks,
-                   const float* state, float lr, float beta1, float beta2, float eps, float weight_decay, int g_dtype,
-                   void* stream) {
-  if (ntensors <= 0 || nchunks <= 0 || nchunks > 0x7fffffffLL || state == nullptr) return TN_EINVAL;
+int tn_adamw_multi_bounded(void* const* ps, void* const* ms, void* const* vs, const void* const* gs,
+                           void* const* shadows, const long long* sizes, const long long* first_chunk, int ntensors,
+                           long long nchunks, const float* state, float lr, float beta1, float beta2, float eps,
+                           float weight_decay, int g_dtype, int max_workgroups, void* stream) {
+  if (ntensors <= 0 || nchunks <= 0 || nchunks > 0x7fffffffLL || state == nullptr || max_workgroups < 0) return TN_EINVAL;
   hipStream_t st = (hipStream_t)stream;
+  const unsigned grid = (unsigned)((max_workgroups > 0 && max_workgroups < nchunks) ? max_workgroups : nchunks);
   if (g_dtype == 0)
-    hipLaunchKernelGGL((adamw_multi_kernel<float>), dim3((unsigned)nchunks), dim3(256), 0, st, (float* const*)ps,
+    hipLaunchKernelGGL((adamw_multi_kernel<float>), dim3(grid), dim3(256), 0, st, (float* const*)ps,
                        (float* const*)ms, (float* const*)vs, gs, (bf16_t* const*)shadows, sizes, first_chunk, ntensors,
-                       state, lr, beta1, beta2, eps, weight_decay);
+                       nchunks, state, lr, beta1, beta2, eps, weight_decay);
   else if (g_dtype == 1)
-    hipLaunchKernelGGL((adamw_multi_kernel<bf16_t>), dim3((unsigned)nchunks), dim3(256), 0, st, (float* const*)ps,
+    hipLaunchKernelGGL((adamw_multi_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (float* const*)ps,
                        (float* const*)ms, (float* const*)vs, gs, (bf16_t* const*)shadows, sizes, first_chunk, ntensors,
-                       state, lr, beta1, beta2, eps, weight_decay);
+                       nchunks, state, lr, beta1, beta2, eps, weight_decay);
   else
     return TN_EINVAL;
   TN_LAUNCH_CHECK();
   return TN_OK;
+}
+
+int tn_adamw_multi(void* const* ps, void* const* ms, void* const* vs, const void* const* gs, void* const* shadows,
+                   const long long* sizes, const long long* first_chunk, int ntensors, long long nchunks,
+                   const float* state, float lr, float beta1, float beta2, float eps, float weight_decay, int g_dtype,
+                   void* stream) {
+  return tn_adamw_multi_bounded(ps, ms, vs, gs, shadows, sizes, first_chunk, ntensors, nchunks, state, lr, beta1, beta2,
+                                eps, weight_decay, g_dtype, 0, stream);
 }
 
 }  // extern "C"

@@ -18,6 +18,7 @@ applies, touchnet/models/helper_func.py:165):
 """
 from __future__ import annotations
 
+import os
 from typing import Any, Dict, Iterable, List, Optional
 
 import torch
@@ -75,6 +76,43 @@ class FusedAdamW:
         self.norm_sq = torch.zeros(1, dtype=torch.float32, device=dev)
         self.step_state = torch.zeros(8, dtype=torch.float32, device=dev)   # tn_adamw_prepare's device state
         self._partial, self._keep = None, None
+        self._pipe = None                     # (groups, group of parameter i, side stream, events): pipeline_updates()
+        self._pipe_delay_cycles = 0           # tests: hold the update stream back so that a missing wait shows
+        # workgroups of a side-stream update launch (tn_adamw_multi_bounded): few enough to leave the forward's kernels the
+        # machine, enough to finish under it
+        self.side_workgroups = int(os.environ.get("TN_ADAMW_SIDE_WORKGROUPS", "128"))
+
+    # ------------------------------------------------------------------ updates under the next forward
+    def pipeline_updates(self, groups: List[List[int]]) -> None:
+        """Run the AdamW launches on a SIDE stream, one launch per group of parameter indices (in the order given), and
+        record one event per group: the caller makes the consumer of group g wait for it (`wait_group`).  The update is
+        HBM-bound (28 B per parameter), the forward that follows is MFMA-bound: issued like this the update of block
+        i+1… runs under the forward of block i instead of in front of it.  The norm / clip state is computed on the
+        calling stream first, so the arithmetic is unchanged.  Plain (unsharded) parameters only."""
+        if any(hasattr(p, "_local_tensor") for p in self.params):
+            raise ValueError("pipeline_updates: sharded parameters are updated by their data-parallel engine's schedule")
+        seen = sorted(i for g in groups for i in g)
+        if seen != list(range(len(self.params))):
+            raise ValueError("pipeline_updates: the groups must cover every parameter exactly once")
+        of = {i: gi for gi, g in enumerate(groups) for i in g}
+        self._pipe = ([list(g) for g in groups], of, torch.cuda.Stream(),
+                      [torch.cuda.Event() for _ in groups], list(range(len(groups))))
+
+    def set_launch_order(self, order: List[int]) -> None:
+        """order of the groups' launches on the side stream (default: as given) — the order the forward consumes them in"""
+        if sorted(order) != list(range(len(self._pipe[0]))):
+            raise ValueError("set_launch_order: a permutation of the group indices")
+        self._pipe[4][:] = list(order)
+
+    def wait_group(self, gi: int) -> None:
+        """the calling stream waits for the last update of group `gi` (no-op before the first step)"""
+        if self._pipe is not None:
+            torch.cuda.current_stream().wait_event(self._pipe[3][gi])
+
+    def wait_updates(self) -> None:
+        """the calling stream waits for every pending update (checkpoints, evaluation, anything outside the hooks)"""
+        if self._pipe is not None:
+            torch.cuda.current_stream().wait_stream(self._pipe[2])
 
     # ------------------------------------------------------------------ multi-tensor tables
     @staticmethod
@@ -116,6 +154,7 @@ class FusedAdamW:
         lib, p_, st = _C.lib(), _C.ptr, _C.stream
         lr = self.lr if lr is None else lr
         b1, b2 = self.betas
+        self.wait_updates()                   # (pipelined: the last step's launches read what `_keep` is about to release)
         self.norm_sq.zero_()
         by_dtype: Dict[torch.dtype, list] = {}
         for i, p in enumerate(self.params):
@@ -140,9 +179,20 @@ class FusedAdamW:
         _C.check(lib.tn_adamw_prepare(p_(self.norm_sq), p_(self.step_state), b1, b2, float(self.max_norm), st()),
                  "tn_adamw_prepare")
         chunk = int(lib.tn_adamw_multi_chunk())
-        for dt, items in by_dtype.items():
-            rows = [[], [], [], [], [], [], []]
-            tot = 0
+        # launches: one per gradient dtype — or, pipelined, per (group, dtype) on the side stream; ONE table upload either way
+        if self._pipe is None:
+            launches = [(None, items) for items in by_dtype.values()]
+        else:
+            groups, of = self._pipe[0], self._pipe[1]
+            launches = []
+            for gi in self._pipe[4]:
+                for items in by_dtype.values():
+                    sub = [it for it in items if of[it[0]] == gi]
+                    launches.append((gi, sub))
+        rows = [[], [], [], [], [], [], []]
+        spans = []
+        for gi, items in launches:
+            tot, a = 0, len(rows[0])
             for i, g in items:
                 s = self.state[i]
                 lp = _local(self.params[i].data)
@@ -154,11 +204,32 @@ class FusedAdamW:
                 rows[5].append(g.numel())
                 rows[6].append(tot)
                 tot += (g.numel() + chunk - 1) // chunk
-            t = self._table(rows, items[0][1].device)
-            _C.check(lib.tn_adamw_multi(p_(t[0]), p_(t[1]), p_(t[2]), p_(t[3]), p_(t[4]), p_(t[5]), p_(t[6]),
-                                        len(items), tot, p_(self.step_state), float(lr), b1, b2, self.eps,
-                                        self.weight_decay, _C.dcode(items[0][1]), st()), "tn_adamw_multi")
+            spans.append((gi, a, len(rows[0]), tot, _C.dcode(items[0][1]) if items else 0))
+        if rows[0]:
+            t = self._table(rows, _local(self.params[0]).device)
             keep.append(t)
+
+            bound = 0 if self._pipe is None else self.side_workgroups
+
+            def launch(a, b, tot, code):
+                _C.check(lib.tn_adamw_multi_bounded(p_(t[0][a:b]), p_(t[1][a:b]), p_(t[2][a:b]), p_(t[3][a:b]),
+                                                    p_(t[4][a:b]), p_(t[5][a:b]), p_(t[6][a:b]), b - a, tot,
+                                                    p_(self.step_state), float(lr), b1, b2, self.eps, self.weight_decay,
+                                                    code, bound, st()), "tn_adamw_multi_bounded")
+            if self._pipe is None:
+                for _, a, b, tot, code in spans:
+                    launch(a, b, tot, code)
+            else:
+                side, events = self._pipe[2], self._pipe[3]
+                side.wait_stream(torch.cuda.current_stream())      # gradients, norm state and the table are ready
+                with torch.cuda.stream(side):
+                    if self._pipe_delay_cycles:
+                        torch.cuda._sleep(int(self._pipe_delay_cycles))
+                    for k, (gi, a, b, tot, code) in enumerate(spans):
+                        if b > a:
+                            launch(a, b, tot, code)
+                        if k + 1 == len(spans) or spans[k + 1][0] != gi:
+                            events[gi].record(side)
         self._keep = keep                     # tables / gradients stay alive until the next step (async launches)
         return self.norm_sq.sqrt().squeeze(0)
 
@@ -182,6 +253,7 @@ class FusedAdamW:
         return DTensor.from_local(t, mesh, p.placements, run_check=False, shape=p.shape, stride=p.stride())
 
     def state_dict(self) -> Dict[str, Any]:
+        self.wait_updates()
         return {"step_state": self.step_state.clone(),
                 "state": {n: {"master": self._as_saved(i, s["master"]), "exp_avg": self._as_saved(i, s["m"]),
                               "exp_avg_sq": self._as_saved(i, s["v"])}
@@ -192,6 +264,7 @@ class FusedAdamW:
     @torch.no_grad()
     def load_state_dict(self, sd: Dict[str, Any]) -> None:
         st = sd["state"]
+        self.wait_updates()
         if len(st) != len(self.state):
             raise ValueError(f"optimizer state has {len(st)} tensors, this optimizer {len(self.state)}")
         self.step_state.copy_(sd["step_state"])
@@ -208,6 +281,93 @@ class FusedAdamW:
                 lp.copy_(s["master"])
         h = sd.get("hyper", {})
         self.lr = h.get("lr", self.lr)
+
+
+def update_groups(model: torch.nn.Module, names: List[str]):
+    """Groups for `FusedAdamW.pipeline_updates` in the order a forward consumes the parameters `names` (optimizer order):
+    [early] + one group per repeated block (the children of the model's outermost `nn.ModuleList`s, in registration
+    order) + [late], where `late` are the parameters registered behind the last block (final norm, lm_head) and `early`
+    every other parameter outside the blocks.  Returns (groups, blocks) with blocks = [(module, group index)]."""
+    strip = lambda n: n.replace("_checkpoint_wrapped_module.", "")
+    blocks = []                                                   # (prefix, module)
+    for name, mod in model.named_modules():
+        if isinstance(mod, torch.nn.ModuleList) and not any(strip(name).startswith(p + ".") for p, _ in blocks):
+            for cname, child in mod.named_children():
+                if any(True for _ in child.parameters()):
+                    blocks.append((strip(f"{name}.{cname}" if name else cname), child))
+    owner = []
+    for n in names:
+        hit = [bi for bi, (p, _) in enumerate(blocks) if n.startswith(p + ".")]
+        owner.append(hit[0] if hit else None)
+    inside = [i for i, o in enumerate(owner) if o is not None]
+    last = max(inside) if inside else -1
+    early = [i for i, o in enumerate(owner) if o is None and i < last]
+    late = [i for i, o in enumerate(owner) if o is None and i > last]
+    groups, out = [early], []
+    for bi, (_, mod) in enumerate(blocks):
+        mine = [i for i, o in enumerate(owner) if o == bi]
+        if mine:
+            out.append((mod, len(groups)))
+            groups.append(mine)
+    groups.append(late)
+    return groups, out
+
+
+def pipeline_updates_under_forward(model: torch.nn.Module, optimizer: "FusedAdamW"):
+    """`optimizer.step()` returns once the norm is known; the parameter updates run on a side stream, block by block, and
+    each block's forward waits for ITS update only (forward pre-hooks; the parameters outside the blocks are waited for
+    at the model's entry, the ones behind the last block — final norm, lm_head — behind the last block).  The reference
+    runs `optimizers.step()` to completion in front of the next forward (touchnet/bin/train.py:467-474); the values
+    every kernel reads are the same, only 40 ms of HBM-bound work per step (7 B parameters, one GPU) move under
+    MFMA-bound work.  Returns the hook handles."""
+    groups, blocks = update_groups(model, optimizer.names)
+    optimizer.pipeline_updates(groups)
+    late, last_block = len(groups) - 1, (blocks[-1][1] if blocks else None)
+    at_entry = [0] if blocks else [0, late]           # groups the model's entry waits for
+    fired, learning = [], [True]
+
+    def entry(m, a):
+        if learning[0]:
+            optimizer.wait_updates()
+        for gi in at_entry:
+            optimizer.wait_group(gi)
+
+    def block(gi):
+        def hook(m, a):
+            if learning[0] and gi not in fired:
+                fired.append(gi)
+            optimizer.wait_group(gi)
+        return hook
+
+    def first_forward_done(m, a, o):
+        # The FIRST forward (nothing is pending yet) shows which blocks are really entered through __call__ and in which
+        # order: a block whose hook never fired (its weights are read by its parent directly) is waited for at the entry
+        # from now on, and the launches follow the order of use.
+        if not learning[0]:
+            return
+        learning[0] = False
+        silent = [gi for _, gi in blocks if gi not in fired]
+        at_entry.extend(silent)
+        order = [0] + silent
+        for gi in fired:
+            order.append(gi)
+            if gi == last_block:
+                order.append(late)
+        if late not in order:
+            order.append(late)
+            if late not in at_entry:
+                at_entry.append(late)
+        optimizer.set_launch_order(order)
+
+    handles = [model.register_forward_pre_hook(entry)]
+    for mod, gi in blocks:
+        handles.append(mod.register_forward_pre_hook(block(gi)))
+    if blocks:
+        handles.append(blocks[-1][0].register_forward_hook(lambda m, a, o: optimizer.wait_group(late)))
+    handles.append(model.register_forward_hook(first_forward_done))
+    # anything that reads the parameters outside a forward
+    handles.append(model.register_state_dict_pre_hook(lambda m, prefix, keep_vars: optimizer.wait_updates()))
+    return handles
 
 
 def linear_warmup_linear_decay(step: int, warmup: int, total: int, min_ratio: float = 0.0) -> float:
