@@ -137,6 +137,13 @@ int tn_log_mel(const float* wav, const float* mel_fb, float* feat, float* scratc
                void* stream);
 int tn_audiofeat_stack(const float* feat, float* out, int T, int F, int stack, int stride, int normalize,
                        void* stream);
+/* Feature-level augmentation of the reference's datapipe, touchnet/data/functions.py:193-255 (audiofeat_spec_aug,
+ * audiofeat_spec_sub, audiofeat_spec_trim), applied in ONE gather pass: x [T, F] -> y [out_rows, F].  The random draws
+ * are the caller's (host arrays): t_masks / f_masks = n x [start, end) stripes set to zero, subs = n x (start, end, pos):
+ * rows [start, end) take rows [start - pos, end - pos) of x (later entries win), out_rows <= T drops the tail.  At most 16
+ * entries each; y must not alias x. */
+int tn_feat_augment(const float* x, float* y, int T, int F, int out_rows, const int* t_masks, int n_t,
+                    const int* f_masks, int n_f, const int* subs, int n_sub, void* stream);
 
 /* ---- fused AdamW on fp32 master weights with bf16 shadow write-back and device-side
  *      skip-on-nonfinite — touchnet/utils/optimizer.py:157-172 + touchnet/bin/train.py:458-474.

@@ -2,6 +2,7 @@
 
 Restates, in NumPy float32/float64 on the CPU,
   * ``audiofeat_stack``                     touchnet/data/functions.py:258-286
+  * ``spec_aug / spec_sub / spec_trim``     touchnet/data/functions.py:193-255
   * ``audio_compute_log_mel_spectrogram``   touchnet/data/functions.py:159-190
     (librosa.filters.mel(sr, n_fft, n_mels) = slaney scale + slaney norm is a
     third-party dependency, pyproject.toml:17 `librosa>=0.11.0`; restated from its
@@ -47,6 +48,47 @@ def audiofeat_stack(feat, stack, stride, normalize=True):
         std = out.std(axis=-1, keepdims=True, ddof=1, dtype=np.float32)
         out = (out - mean) / (std + np.float32(1e-5))
     return out.astype(np.float32)
+
+
+# --------------------------------------------------------------------------- feature-level augmentation
+# touchnet/data/functions.py:193-255, loop by loop, with the reference's calls of the global `random` module in the
+# reference's order (pinned: tests/golden/audiofeat_augment.npz holds outputs of the reference's own stage functions
+# for given seeds).
+def spec_aug(x, num_t_mask, num_f_mask, max_t, max_f, rng):
+    """functions.py:193-217.  `rng`: the `random` module (or a random.Random)."""
+    y = np.array(x, dtype=np.float32, copy=True)
+    max_frames, max_freq = y.shape
+    for _ in range(num_t_mask):
+        start = rng.randint(0, max_frames - 1)
+        length = rng.randint(1, max_t)
+        y[start:min(max_frames, start + length), :] = 0
+    for _ in range(num_f_mask):
+        start = rng.randint(0, max_freq - 1)
+        length = rng.randint(1, max_f)
+        y[:, start:min(max_freq, start + length)] = 0
+    return y
+
+
+def spec_sub(x, num_t_sub, max_t, rng):
+    """functions.py:220-239: rows [start, end) <- rows [start - pos, end - pos) of the INPUT."""
+    x = np.asarray(x, dtype=np.float32)
+    y = x.copy()
+    max_frames = y.shape[0]
+    for _ in range(num_t_sub):
+        start = rng.randint(0, max_frames - 1)
+        length = rng.randint(1, max_t)
+        end = min(max_frames, start + length)
+        pos = rng.randint(0, start)
+        y[start:end, :] = x[start - pos:end - pos, :]
+    return y
+
+
+def spec_trim(x, max_t, rng):
+    """functions.py:242-255: drop `length` tail frames when that is less than half of them."""
+    x = np.asarray(x, dtype=np.float32)
+    max_frames = x.shape[0]
+    length = rng.randint(1, max_t)
+    return x[:max_frames - length].copy() if length < max_frames / 2 else x
 
 
 # --------------------------------------------------------------------------- log-mel

@@ -202,6 +202,24 @@ def log_mel_spectrogram(wav, num_mel_bins=128, padding=0):
                                                     padding=padding)).float()
 
 
+def feat_augment(feat, t_masks=(), f_masks=(), subs=(), out_rows=None):
+    """the product op's contract (touchnet_amd.functional.feat_augment) on the CPU: stripes, substitutions, trim"""
+    x = feat.detach().cpu().float()
+    y = x.clone()
+    for a, b, pos in subs:
+        y[a:b] = x[a - pos:b - pos]
+    keep = torch.ones(x.shape[0], dtype=torch.bool)
+    for a, b in t_masks:
+        keep[a:b] = False
+    src = torch.arange(x.shape[0])
+    for a, b, pos in subs:
+        src[a:b] = torch.arange(a - pos, b - pos)
+    y[~keep[src]] = 0
+    for a, b in f_masks:
+        y[:, a:b] = 0
+    return y[:x.shape[0] if out_rows is None else out_rows].clone()
+
+
 def audiofeat_stack(feat, stack, stride, normalize=True):
     from . import frontend as _fe
     return torch.from_numpy(_fe.audiofeat_stack(feat.detach().cpu().numpy(), stack, stride, normalize)).float()

@@ -1056,12 +1056,70 @@ def kimi_audio_data_case():
     save("kimi_audio_data.npz", **out)
 
 
+def audiofeat_augment_case():
+    """touchnet/data/functions.py:193-255 run here: every stage alone and the reference's chain spec_aug -> spec_sub ->
+    spec_trim (processing_touch_audio.py:468-473; chained generators, two utterances per chain so that the draws of the
+    second utterance follow the first one's through all stages), under `random.seed(seed)`.  Stored: inputs, the option
+    values, the seed and the outputs — the twins replay the same global `random` stream."""
+    import random
+    rng = np.random.RandomState(17)
+    out, names = {}, []
+
+    def cfg_of(**kw):
+        base = dict(audiofeat_spec_aug=False, audiofeat_spec_aug_num_t_mask=2, audiofeat_spec_aug_num_f_mask=2,
+                    audiofeat_spec_aug_max_t=50, audiofeat_spec_aug_max_f=10, audiofeat_spec_sub=False,
+                    audiofeat_spec_sub_num_t_sub=3, audiofeat_spec_sub_max_t=30, audiofeat_spec_trim=False,
+                    audiofeat_spec_trim_max_t=20)
+        base.update(kw)
+        return types.SimpleNamespace(**base)
+
+    def run(name, shapes, seed, **kw):
+        cfg = cfg_of(**kw)
+        xs = [rng.randn(T, F).astype(np.float32) for T, F in shapes]
+        data = iter([{"audiofeat": torch.from_numpy(x.copy())} for x in xs])
+        if cfg.audiofeat_spec_aug:
+            data = ref_fn.audiofeat_spec_aug(data, cfg)
+        if cfg.audiofeat_spec_sub:
+            data = ref_fn.audiofeat_spec_sub(data, cfg)
+        if cfg.audiofeat_spec_trim:
+            data = ref_fn.audiofeat_spec_trim(data, cfg)
+        random.seed(seed)
+        ys = [npy(smp["audiofeat"]) for smp in data]
+        names.append(name)
+        out[f"{name}/seed"] = np.array(seed)
+        out[f"{name}/cfg"] = np.array([int(cfg.audiofeat_spec_aug), cfg.audiofeat_spec_aug_num_t_mask,
+                                       cfg.audiofeat_spec_aug_num_f_mask, cfg.audiofeat_spec_aug_max_t,
+                                       cfg.audiofeat_spec_aug_max_f, int(cfg.audiofeat_spec_sub),
+                                       cfg.audiofeat_spec_sub_num_t_sub, cfg.audiofeat_spec_sub_max_t,
+                                       int(cfg.audiofeat_spec_trim), cfg.audiofeat_spec_trim_max_t])
+        out[f"{name}/n"] = np.array(len(xs))
+        for i, (x, y) in enumerate(zip(xs, ys)):
+            out[f"{name}/x{i}"], out[f"{name}/y{i}"] = x, y
+
+    # the wenetspeech ASR recipe's values (examples/audio/sft/asr/wenetspeech/run.sh:261-270)
+    run("recipe_aug_sub", [(217, 80), (123, 80)], 2025, audiofeat_spec_aug=True, audiofeat_spec_sub=True)
+    run("all_three", [(300, 24), (64, 80), (1000, 8)], 7, audiofeat_spec_aug=True, audiofeat_spec_sub=True,
+        audiofeat_spec_trim=True)
+    run("aug_only", [(200, 32), (37, 23)], 1, audiofeat_spec_aug=True)
+    run("sub_only", [(200, 16), (90, 16)], 2, audiofeat_spec_sub=True)
+    run("trim_only", [(200, 8), (30, 8), (41, 8)], 3, audiofeat_spec_trim=True)     # 30 frames: never trimmed by >= 15
+    # stripes wider than the matrix, many of them (overlaps, clipping at the ends), one-frame utterances
+    run("wide", [(20, 8), (1, 8), (2, 8)], 4, audiofeat_spec_aug=True, audiofeat_spec_aug_num_t_mask=5,
+        audiofeat_spec_aug_num_f_mask=4, audiofeat_spec_aug_max_t=40, audiofeat_spec_aug_max_f=12, audiofeat_spec_sub=True,
+        audiofeat_spec_sub_num_t_sub=8, audiofeat_spec_sub_max_t=15, audiofeat_spec_trim=True, audiofeat_spec_trim_max_t=3)
+    for seed in range(5, 9):
+        run(f"seed{seed}", [(150, 12), (151, 12)], seed, audiofeat_spec_aug=True, audiofeat_spec_sub=True,
+            audiofeat_spec_trim=True, audiofeat_spec_trim_max_t=100)
+    out["names"] = np.array(names)
+    save("audiofeat_augment.npz", **out)
+
+
 if __name__ == "__main__":
     only = set(sys.argv[1:])
     for fn in (text_cases, asr_cases, ce_cases, docmask_cases, rope_cases, tiny_llama_case,
                touch_audio_case, qwen2_audio_tower_case, frontend_cases, fbank_cases, bestrq_cases, touchdataset_case,
                boundary_case, qwen2_audio_data_case, kimi_decoder_case, tiny_llama_dev_case, touch_audio_dev_case,
                qwen2_audio_tower_dev_case, kimi_decoder_dev_case, kimi_audio_input_case,
-               kimi_audio_data_case):
+               kimi_audio_data_case, audiofeat_augment_case):
         if not only or fn.__name__ in only:
             fn()

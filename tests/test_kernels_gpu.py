@@ -366,6 +366,43 @@ def test_frontend_stack(golden):
             np.testing.assert_allclose(y, g[f"stack/{n}/y"], atol=5e-5, err_msg=n)
 
 
+def test_feature_augmentation_on_the_device_replays_the_reference_runs(golden):
+    """spec_aug -> spec_sub -> spec_trim of the reference's datapipe (functions.py:193-255) through the product stage
+    functions with the HIP gather kernel: bit-identical to the outputs of the reference's own stage functions under the
+    same seed — one fused launch per utterance, and the three standalone stages chained."""
+    import random
+    import types
+    from touchnet_amd.data import functions as fn
+    keys = ("audiofeat_spec_aug", "audiofeat_spec_aug_num_t_mask", "audiofeat_spec_aug_num_f_mask",
+            "audiofeat_spec_aug_max_t", "audiofeat_spec_aug_max_f", "audiofeat_spec_sub", "audiofeat_spec_sub_num_t_sub",
+            "audiofeat_spec_sub_max_t", "audiofeat_spec_trim", "audiofeat_spec_trim_max_t")
+    g = golden("audiofeat_augment.npz")
+    for n in [str(v) for v in g["names"]]:
+        cfg = types.SimpleNamespace(**{k: int(v) for k, v in zip(keys, g[f"{n}/cfg"])})
+        k = int(g[f"{n}/n"])
+        for fused in (True, False):
+            data = iter([{"audiofeat": torch.tensor(g[f"{n}/x{i}"]).to(DEV)} for i in range(k)])
+            if fused:
+                data = fn.audiofeat_augment(data, cfg)
+            else:
+                for flag, stage in (("audiofeat_spec_aug", fn.audiofeat_spec_aug), ("audiofeat_spec_sub", fn.audiofeat_spec_sub),
+                                    ("audiofeat_spec_trim", fn.audiofeat_spec_trim)):
+                    if getattr(cfg, flag):
+                        data = stage(data, cfg)
+            random.seed(int(g[f"{n}/seed"]))
+            for i, smp in enumerate(data):
+                y = smp["audiofeat"]
+                assert y.is_cuda and tuple(y.shape) == g[f"{n}/y{i}"].shape, (n, i, fused)
+                assert np.array_equal(y.cpu().numpy(), g[f"{n}/y{i}"]), (n, i, fused)
+    # the C ABI refuses what it cannot represent
+    F = _f()
+    x = torch.randn(8, 4, device=DEV)
+    with pytest.raises(Exception):
+        F.feat_augment(x, subs=[(2, 4, 3)])                 # pos > start: the source row would lie in front of x
+    with pytest.raises(Exception):
+        F.feat_augment(x, t_masks=[(0, 1)] * 17)
+
+
 def test_frontend_log_mel(golden):
     F = _f()
     g = golden("logmel.npz")

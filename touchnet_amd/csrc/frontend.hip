@@ -207,6 +207,39 @@ __global__ __launch_bounds__(256) void audiofeat_stack_kernel(const float* __res
   for (int e = lane; e < n; e += 64) out[(size_t)row * n + e] = (src(e) - mean) * inv;
 }
 
+// ---------------------------------------------------------------------------------------------- feature-level augmentation
+// touchnet/data/functions.py:193-255 (audiofeat_spec_aug, audiofeat_spec_sub, audiofeat_spec_trim) as ONE gather pass over
+// the [T, F] feature matrix: the random draws are the host's (same `random` calls in the same order as the reference's
+// stage functions, touchnet_amd/data/functions.py), the device applies them:
+//   y[t][f] = 0                      if row src(t) lies in a time stripe or f in a frequency stripe   (spec_aug :205-217)
+//           = x[src(t)][f]           with src(t) = t - pos_k for the LAST substitution k whose rows [start_k, end_k)
+//                                    contain t (later substitutions overwrite earlier ones, all read the stage's
+//                                    INPUT, :233-239), else t
+//   t < out_rows                     (spec_trim drops the tail rows, :250-253)
+// spec_aug runs in front of spec_sub in the reference's chain (processing_touch_audio.py:468-473), so the stripes are
+// tested on the SOURCE row.  HBM-bound: 8 B per element, one launch per utterance.
+struct AugPlan {
+  int n_t, n_f, n_s;
+  int t[16][2], f[16][2], s[16][3];
+};
+
+__global__ __launch_bounds__(256) void feat_augment_kernel(const float* __restrict__ x, float* __restrict__ y, int F,
+                                                           long long n, AugPlan plan) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int t = (int)(i / F), f = (int)(i % F);
+  int src = t;
+  for (int k = plan.n_s - 1; k >= 0; --k)
+    if (t >= plan.s[k][0] && t < plan.s[k][1]) {
+      src = t - plan.s[k][2];
+      break;
+    }
+  bool zero = false;
+  for (int k = 0; k < plan.n_t; ++k) zero |= (src >= plan.t[k][0] && src < plan.t[k][1]);
+  for (int k = 0; k < plan.n_f; ++k) zero |= (f >= plan.f[k][0] && f < plan.f[k][1]);
+  y[i] = zero ? 0.f : x[(size_t)src * F + f];
+}
+
 // int16 PCM -> float32 in [-1, 1): x * 2^-15, exactly numpy's `astype(float32) / 32768.0` of the reference's
 // datapipe (touchnet/data/datapipe.py:164).  Lets the caller upload 2 bytes per sample.
 __global__ __launch_bounds__(256) void pcm16_to_f32_kernel(const int16_t* __restrict__ in, float* __restrict__ out,
@@ -272,6 +305,28 @@ int tn_audiofeat_stack(const float* feat, float* out, int T, int F, int stack, i
   const int t_lfr = (T + stride - 1) / stride;
   hipLaunchKernelGGL(audiofeat_stack_kernel, dim3((t_lfr + 3) / 4), dim3(256), 0, (hipStream_t)stream, feat, out, T,
                      F, stack, stride, t_lfr, normalize);
+  TN_LAUNCH_CHECK();
+  return TN_OK;
+}
+
+// x [T, F] -> y [out_rows, F] (out_rows <= T).  HOST arrays: t_masks / f_masks = n x [start, end), subs = n x (start, end,
+// pos) with 0 <= pos <= start; at most 16 of each.
+int tn_feat_augment(const float* x, float* y, int T, int F, int out_rows, const int* t_masks, int n_t,
+                    const int* f_masks, int n_f, const int* subs, int n_sub, void* stream) {
+  if (T <= 0 || F <= 0 || out_rows <= 0 || out_rows > T || n_t < 0 || n_f < 0 || n_sub < 0 || n_t > 16 || n_f > 16 ||
+      n_sub > 16 || x == y)
+    return TN_EINVAL;
+  AugPlan plan;
+  plan.n_t = n_t, plan.n_f = n_f, plan.n_s = n_sub;
+  for (int k = 0; k < n_t; ++k) plan.t[k][0] = t_masks[2 * k], plan.t[k][1] = t_masks[2 * k + 1];
+  for (int k = 0; k < n_f; ++k) plan.f[k][0] = f_masks[2 * k], plan.f[k][1] = f_masks[2 * k + 1];
+  for (int k = 0; k < n_sub; ++k) {
+    plan.s[k][0] = subs[3 * k], plan.s[k][1] = subs[3 * k + 1], plan.s[k][2] = subs[3 * k + 2];
+    if (plan.s[k][2] < 0 || plan.s[k][2] > plan.s[k][0] || plan.s[k][1] > T) return TN_EINVAL;   // source row stays inside x
+  }
+  const long long n = (long long)out_rows * F;
+  hipLaunchKernelGGL(feat_augment_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, F,
+                     n, plan);
   TN_LAUNCH_CHECK();
   return TN_OK;
 }

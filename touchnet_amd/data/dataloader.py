@@ -173,21 +173,26 @@ def build_datapipe(cfg, tokenizer, dp_rank: int, dp_world_size: int):
     if kind == "causal_lm":
         pipe = stage(functions.filter_samples, cfg)
         return stage(batch_text, cfg, tokenizer)
-    for aug in ("audio_speed_perturb", "audiofeat_spec_aug", "audiofeat_spec_sub", "audiofeat_spec_trim"):
-        if getattr(cfg, aug, False):
-            raise NotImplementedError(f"{aug}: augmentation stages are outside the MI355X path (SURVEY §2.1); "
-                                      f"chain the reference's stage function in front of the device frontend")
+    if getattr(cfg, "audio_speed_perturb", False):
+        # functions.py:99-114 hands the waveform to libsox (`speed` + `rate` effects): a third-party resampler whose
+        # output cannot be restated bit for bit here (and torchaudio is not in this image to pin one against)
+        raise NotImplementedError("audio_speed_perturb: chain the reference's (sox) stage function in front of the device "
+                                  "frontend, or perturb when the dataset is written")
+    augment = any(getattr(cfg, a, False) for a in ("audiofeat_spec_aug", "audiofeat_spec_sub", "audiofeat_spec_trim"))
     if kind == "touch_audio":
         labels_from_audio = hasattr(tokenizer, "quantizer") or type(tokenizer).__name__ == "BestRQTokenizer"
         if not labels_from_audio:
             pipe = stage(functions.text_tokenize, tokenizer)
         pipe = stage(functions.filter_samples, cfg)
+        pipe = stage(functions.audio_resample, cfg)
         if cfg.audio_feat_type == "fbank":
             pipe = stage(functions.audio_compute_fbank, cfg)
         elif cfg.audio_feat_type == "log_mel_spectrogram":
             pipe = stage(functions.audio_compute_log_mel_spectrogram, cfg)
         else:
             raise NotImplementedError(f"audio_feat_type {cfg.audio_feat_type!r} has no device kernel")
+        if augment:                                   # spec_aug -> spec_sub -> spec_trim: one launch per utterance
+            pipe = stage(functions.audiofeat_augment, cfg)
         pipe = stage(functions.audiofeat_stack, cfg)
         if labels_from_audio:
             return stage(batch_audio_packed, cfg, tokenizer)

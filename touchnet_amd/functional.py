@@ -1078,6 +1078,15 @@ def bestrq_tokenize(feat: torch.Tensor, quantizer: torch.Tensor, codebook: torch
     return L.bestrq_tokenize(_c(feat), _c(quantizer), _c(codebook))
 
 
+def feat_augment(feat: torch.Tensor, t_masks=(), f_masks=(), subs=(), out_rows: Optional[int] = None) -> torch.Tensor:
+    """fp32 [T, F] -> fp32 [out_rows, F]: zero stripes (spec_aug), row substitutions from earlier rows (spec_sub) and the
+    tail trim (spec_trim) of touchnet/data/functions.py:193-255 in one pass; the draws come from the caller."""
+    if not feat.is_cuda or feat.dim() != 2:
+        raise RuntimeError("feat_augment: expects a 2-D device tensor")
+    T = feat.shape[0]
+    return L.feat_augment(_c(feat).float(), list(t_masks), list(f_masks), list(subs), T if out_rows is None else int(out_rows))
+
+
 def audiofeat_stack(feat: torch.Tensor, stack: int, stride: int, normalize: bool = True) -> torch.Tensor:
     """feat fp32 [T, F] -> fp32 [ceil(T/stride), F*stack] (functions.py:258-286)."""
     return L.audiofeat_stack(_c(feat).float(), int(stack), int(stride), bool(normalize))

@@ -753,6 +753,25 @@ def _(feat, stack, stride, normalize):
     return feat.new_empty((feat.shape[0] + stride - 1) // stride, feat.shape[1] * stack)
 
 
+def feat_augment(feat: Tensor, t_masks, f_masks, subs, out_rows: int) -> Tensor:
+    """tn_feat_augment: the draws travel as kernel arguments (host int arrays), so this is a plain function, not a
+    registered op (no tensor carries them)."""
+    import ctypes as C
+    T, F = feat.shape
+    out = torch.empty(out_rows, F, dtype=torch.float32, device=feat.device)
+
+    def arr(rows, width):
+        flat = [int(v) for r in rows for v in r]
+        assert len(flat) == width * len(rows)
+        return (C.c_int * max(1, len(flat)))(*flat), len(rows)
+    tm, nt = arr(t_masks, 2)
+    fm, nf = arr(f_masks, 2)
+    sb, ns = arr(subs, 3)
+    _C.check(_lib().tn_feat_augment(_p(feat), _p(out), T, F, int(out_rows), C.cast(tm, C.c_void_p), nt,
+                                    C.cast(fm, C.c_void_p), nf, C.cast(sb, C.c_void_p), ns, _cur()), "tn_feat_augment")
+    return out
+
+
 @custom_op(f"{NS}::pcm16_to_f32", mutates_args=(), device_types="cuda")
 def pcm16_to_f32(pcm: Tensor) -> Tensor:
     out = torch.empty(pcm.shape, dtype=torch.float32, device=pcm.device)
