@@ -98,6 +98,13 @@ def _worker(rank, world, port, ref_state, ref_grads, ref_losses, total_ns, ret):
             batch = _batches(world)[rank]
             data = tr.next_batch(batch)
             assert float(data["num_sentence"]) == float(total_ns)          # global SUM over dp
+            # dev loop (train.py:553-621): no_grad forward, metrics reduced over dp: the loss parts ADD UP
+            m = tr.dev([batch, batch])
+            assert m["batches"] == 2 and tr.model.training
+            assert float(m["global_avg_loss_per_sample"]) == pytest.approx(sum(ref_losses), rel=1e-5)
+            assert float(m["global_max_loss_per_token"]) >= float(m["global_avg_loss_per_token"]) > 0
+            assert 0.0 <= float(m["global_min_acc"]) <= float(m["global_avg_acc"]) <= 1.0
+            assert all(p.grad is None for p in tr.model.parameters())
             tr.optimizer.zero_grad()
             loss, per_token, acc = tr.forward_loss(data)
             assert float(loss) == pytest.approx(ref_losses[rank], rel=1e-5, abs=1e-6)

@@ -200,6 +200,9 @@ class Trainer:
                 from touchnet_amd.utils.optimizer import pipeline_updates_under_forward
                 pipeline_updates_under_forward(model, self.optimizer)
         self.step = 0
+        # the reference's "dp_cp" mesh (loss / metric all-reduces, train.py:485-494): every rank that holds other rows or
+        # another part of the sequence
+        self.dp_cp_group = fsdp_mesh.get_group() if fsdp_mesh is not None and shard_world > 1 else None
 
     # ------------------------------------------------------------------ data
     def next_batch(self, batch: dict) -> dict:
@@ -296,3 +299,40 @@ class Trainer:
             self.dp_engine.gather_params()       # all-gathers of the updated slices travel under the next forward
         self.step += 1
         return {"loss_per_sample": loss.detach(), "loss_per_token": per_token, "acc": acc, "grad_norm": grad_norm}
+
+    # ------------------------------------------------------------------ metrics / evaluation
+    def reduce_metrics(self, loss_per_sample, loss_per_token, acc=None):
+        """The five numbers the reference logs (train.py:485-494, 571-583): loss per sample SUMMED over dp x cp (every
+        rank's loss is already divided by the global sentence count), loss per token mean / max, accuracy mean / min —
+        device scalars, no host sync."""
+        from touchnet_amd.utils.distributed import dist_max, dist_mean, dist_min
+        g = self.dp_cp_group
+        ls, lt = loss_per_sample.detach(), loss_per_token.detach()
+        zero = torch.zeros((), device=ls.device)
+        return (dist_sum(ls, g), dist_mean(lt, g), dist_max(lt, g),
+                dist_mean(acc.detach(), g) if acc is not None else zero,
+                dist_min(acc.detach(), g) if acc is not None else zero)
+
+    @torch.no_grad()
+    def dev_step(self, data: dict):
+        """train.py:553-586: the training forward under no_grad, reduced metrics"""
+        return self.reduce_metrics(*self.forward_loss(data))
+
+    @torch.no_grad()
+    def dev(self, batches) -> dict:
+        """train.py:588-621 without the logging backend: eval mode, every batch of the dev loader through `dev_step`,
+        per-batch metrics averaged (loss, accuracy) / extremes kept (max loss per token, min accuracy)."""
+        was_training = self.model.training
+        self.model.eval()
+        if getattr(self.optimizer, "wait_updates", None):
+            self.optimizer.wait_updates()
+        try:
+            metrics = [self.dev_step(self.next_batch(b)) for b in batches]
+        finally:
+            self.model.train(was_training)
+        if not metrics:
+            return {}
+        col = lambda i: torch.stack([m[i].reshape(()) for m in metrics])
+        return {"global_avg_loss_per_sample": col(0).mean(), "global_avg_loss_per_token": col(1).mean(),
+                "global_max_loss_per_token": col(2).max(), "global_avg_acc": col(3).mean(),
+                "global_min_acc": col(4).min(), "batches": len(metrics)}

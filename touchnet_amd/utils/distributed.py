@@ -139,6 +139,19 @@ def dist_max(x: torch.Tensor, group=None) -> torch.Tensor:
     return x
 
 
+def dist_min(x: torch.Tensor, group=None) -> torch.Tensor:
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        x = x.clone()
+        dist.all_reduce(x, op=dist.ReduceOp.MIN, group=group)
+    return x
+
+
+def dist_mean(x: torch.Tensor, group=None) -> torch.Tensor:
+    """mean over the group's ranks (touchnet/utils/distributed.py:215-217), as a device scalar"""
+    n = dist.get_world_size(group) if dist.is_initialized() else 1
+    return dist_sum(x, group) / n if n > 1 else x
+
+
 # ------------------------------------------------------------------------------------------------ parallel dims
 from dataclasses import dataclass  # noqa: E402
 
