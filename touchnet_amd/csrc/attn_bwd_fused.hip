@@ -239,6 +239,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kv_fused_kernel(
   const int per_head = SPT * nqt, total_c = per_head * G;
   // what the list builder needs to know about every wave's 32 kv rows
   if (lane == 0) wstat[wave] = i32x4_t{wminpos, wmax, w_uniform ? 1 : 0, 0};
+  __syncthreads();                      // (the builder reads ALL four waves' entries: without this barrier a wave that runs
+                                        //  ahead read stale LDS and dropped / mis-masked stages of a slower wave — seen as
+                                        //  one irreproducible dK / dV in some hundred launches, scripts/r04_determinism2.py)
   auto build_list = [&](int cb) {       // candidates [cb, cb + LCAP) -> n entries (+ NST + 1 empty ones behind them)
     const int c = cb + tid;
     QStage d = {0, 0, 0, 0};
