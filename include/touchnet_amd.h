@@ -94,6 +94,14 @@ int tn_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse
 int tn_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse2,
                 float* delta, void* dq, void* dk, void* dv, const int* doc, const int* meta, int B, int T, int Nh,
                 int Nkv, int D, float scale, void* stream);
+/* The same pair with the mask BIDIRECTIONAL inside a document (allowed = same positive document id; no causal term):
+ * transformers' WhisperEncoder layers, which the reference's Kimi-Audio speech encoder runs on every 30 s clip
+ * (touchnet/models/kimi_audio/modeling_kimi_audio.py:933-960; one clip = one document).  Same tensors, same metadata. */
+int tn_attn_fwd_bidir(const void* q, const void* k, const void* v, void* o, float* lse2, const int* doc, const int* meta,
+                      int B, int T, int Nh, int Nkv, int D, float scale, void* stream);
+int tn_attn_bwd_bidir(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse2,
+                      float* delta, void* dq, void* dk, void* dv, const int* doc, const int* meta, int B, int T, int Nh,
+                      int Nkv, int D, float scale, void* stream);
 
 /* Sequence-sharded query side — context parallelism (replaces torch's experimental ring-attention CP that the
  * reference enters at touchnet/utils/distributed.py:292-346 / touchnet/bin/train.py:354-389, which intercepts

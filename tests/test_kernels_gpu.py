@@ -306,12 +306,15 @@ def test_packed_attention_backward_is_reproducible_launch_after_launch(D):
             assert torch.equal(a, b), (it, name, float((a.float() - b.float()).abs().max()))
 
 
-@pytest.mark.parametrize("B,T,Nh,Nkv,D,maxdoc,pad", [(2, 300, 4, 4, 64, 300, 0), (1, 512, 4, 2, 128, 200, 40),
-                                                    (3, 1500, 2, 2, 64, 1500, 0)])
-def test_bidirectional_attention_from_two_causal_launches(B, T, Nh, Nkv, D, maxdoc, pad):
-    """functional.bidirectional_attention (Whisper's encoder self-attention for Kimi-Audio's speech encoder): keys at or
-    before the query + keys at or after it (the causal kernel on the reversed batch) merged by log-sum-exp, the diagonal
-    taken out once.  Against the fp32 oracle (softmax over all same-document keys): output, dQ, dK, dV; pad rows exactly 0."""
+@pytest.mark.parametrize("B,T,Nh,Nkv,D,maxdoc,pad", [
+    (2, 300, 4, 4, 64, 300, 0), (1, 512, 4, 2, 128, 200, 40), (3, 1500, 2, 2, 64, 1500, 0),     # 1500: one Whisper clip
+    (2, 384, 8, 4, 128, 7, 5),          # many tiny documents
+    (2, 200, 4, 1, 64, 70, 20),         # T not a multiple of 64, GQA 4:1
+    (1, 1024, 4, 4, 64, 300, 100), (1, 640, 2, 2, 128, 640, 0)])
+def test_bidirectional_attention_kernels(B, T, Nh, Nkv, D, maxdoc, pad):
+    """functional.bidirectional_attention (Whisper's encoder self-attention for Kimi-Audio's speech encoder):
+    tn_attn_fwd_bidir / tn_attn_bwd_bidir — the packed kernels without the causal term, key range up to the last tile of
+    the document.  Against the fp32 oracle (softmax over all same-document keys): output, dQ, dK, dV; pad rows exactly 0."""
     import oracle.ops as oops
     F = _f()
     doc = _docs(B, T, T + Nh, maxdoc, pad)

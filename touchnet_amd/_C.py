@@ -38,6 +38,8 @@ PROTOTYPES = {
     "tn_attn_build_meta": [_vp, _vp, _i, _i, _vp],
     "tn_attn_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp],
     "tn_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp],
+    "tn_attn_fwd_bidir": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp],
+    "tn_attn_bwd_bidir": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp],
     "tn_attn_fwd_seg": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _i, _vp],
     "tn_attn_fwd_seg_chunks": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _i, _i, C.c_ulonglong, _vp],
     "tn_attn_merge": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],

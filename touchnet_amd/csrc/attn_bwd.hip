@@ -142,8 +142,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(
   const int* m_min = meta.tmin + (size_t)b * meta.nt;
   const int* m_max = meta.tmax + (size_t)b * meta.nt;
   const int* m_minpos = meta.tminpos + (size_t)b * meta.nt;
-  const int qt_lo = k0 / kTile;                               // first 64-position query tile (q >= kv), global index
   const int t0 = 2 * kt, t1 = min(2 * kt + 1, meta.nt - 1);
+  const bool bidir = qv.bidir != 0;
+  // first 64-position query tile, global index: q >= kv under the causal mask; bidirectional: the first tile that shares
+  // a document with these kv rows
+  const int qt_lo = bidir ? min(meta.q_lo[(size_t)b * meta.nt + t0], meta.q_lo[(size_t)b * meta.nt + t1]) : k0 / kTile;
+  const int kvcap = bidir ? -0x7fffffff : kvrow;            // `kvcap <= q`: the causal term of the predicate
   const int bminpos = min(m_minpos[t0], m_minpos[t1]);
   const int bmax = max(m_max[t0], m_max[t1]);
   const int qhi64 = max(meta.kv_hi[(size_t)b * meta.nt + t0], meta.kv_hi[(size_t)b * meta.nt + t1]);
@@ -292,7 +296,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(
     const float* lse_s = reinterpret_cast<const float*>(smem + slot * STAGEB + 2 * IMGB);
     const float* delta_s = lse_s + 64;
     const int* docq = reinterpret_cast<const int*>(lse_s + 128);
-    if (uniform(TN_BWD_ABL != 3 && cur.qsb + BQ - 1 >= wk0 && tile_may_interact(cur.mp, cur.mx, wminpos, wmax))) {
+    if (uniform(TN_BWD_ABL != 3 && (bidir || cur.qsb + BQ - 1 >= wk0) && tile_may_interact(cur.mp, cur.mx, wminpos, wmax))) {
       const bool q_uniform = w_uniform && cur.mn == cur.mx && cur.mx == wmax && cur.left == BQ;
       // The work on one 32-row half (qs) of the stage, in pieces.  (Issuing both halves of an interior stage as ONE
       // straight-line block — S of half 1 under the exponentials of half 0 — measured 3-9 % SLOWER: 226 -> 242 VGPRs.)
@@ -323,7 +327,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             float pv = fast_exp2(sacc[4 * r4 + e] * scale_log2 - le[e]);
-            if (MASK) pv = ((kvrow <= cur.qsb + o + e) & (qd[e] == dkdoc) & (dkdoc > 0)) ? pv : 0.f;
+            if (MASK) pv = ((kvcap <= cur.qsb + o + e) & (qd[e] == dkdoc) & (dkdoc > 0)) ? pv : 0.f;
             p[4 * r4 + e] = pv;
           }
         }
@@ -354,8 +358,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(
 #pragma unroll
       for (int qs = 0; qs < BQ / 32; ++qs) {
         const int qsb = cur.qsb + 32 * qs;
-        if (!uniform(qsb + 31 >= wk0)) continue;                // every q of this half precedes the kv rows
-        const bool need_mask = uniform(!(q_uniform && qsb >= wk0 + 31));
+        if (!uniform(bidir || qsb + 31 >= wk0)) continue;       // every q of this half precedes the kv rows
+        const bool need_mask = uniform(!(q_uniform && (bidir || qsb >= wk0 + 31)));
         const f32x16_t sacc = s_of(qs);
         f32x16_t dpacc = zero16;
         if (DO_DK) dpacc = dp_of(qs);
@@ -457,7 +461,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(
   const int* m_max = meta.tmax + (size_t)b * meta.nt;
   const int* m_minpos = meta.tminpos + (size_t)b * meta.nt;
   const int t0 = q0 / kTile, t1 = min(t0 + 1, meta.nt - 1);
-  const int j_hi = t1;
+  const bool bidir = qv.bidir != 0;
+  const int j_hi = bidir ? max(t1, max(meta.kv_hi[(size_t)b * meta.nt + t0], meta.kv_hi[(size_t)b * meta.nt + t1])) : t1;
+  const int qcap = bidir ? 0x7fffffff : qrow;               // `kv <= qcap`: the causal term of the predicate
   // statistics window: the WIN tiles that END at the diagonal are the ones a packed batch needs; a longer reach (plain
   // causal beyond 16 k positions) starts below it and refills the window on the way up
   const int j_lo = min(meta.q_lo[(size_t)b * meta.nt + t0], meta.q_lo[(size_t)b * meta.nt + t1]);
@@ -561,12 +567,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(
     const bf16_t* Vs = Ks + Tile::SIZE;
     const int* docs = reinterpret_cast<const int*>(smem + slot * STAGEB + 2 * IMGB);
     const int k0 = cur.j * BN;
-    if (uniform(TN_BWD_ABL != 3 && k0 <= wq0 + 31 && tile_may_interact(wminpos, wmax, cur.mp, cur.mx))) {
+    if (uniform(TN_BWD_ABL != 3 && (bidir || k0 <= wq0 + 31) && tile_may_interact(wminpos, wmax, cur.mp, cur.mx))) {
       const bool need_mask = uniform(!(cur.mn == cur.mx && cur.mx == wminpos && wminpos == wmax && !w_has_zero &&
-                                       (k0 + BN - 1 <= wq0)));
+                                       (bidir || k0 + BN - 1 <= wq0)));
 #pragma unroll
       for (int blk = 0; blk < 2; ++blk) {
-        if (uniform(k0 + 32 * blk <= wq0 + 31)) {             // else: this 32-row KV block is above the diagonal
+        if (uniform(bidir || k0 + 32 * blk <= wq0 + 31)) {    // else: this 32-row KV block is above the diagonal
           f32x16_t sacc = mfma32(rrd.operand(Ks, 32 * blk, 0), qreg[0], zero16);
           f32x16_t dpacc = mfma32(rrd.operand(Vs, 32 * blk, 0), doreg[0], zero16);
 #pragma unroll
@@ -590,7 +596,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(
                 float pv = fast_exp2(sacc[r] * scale_log2 - lse2);
                 if (MASK) {
                   const int kv = k0 + 32 * blk + 8 * r4 + 4 * hi + e;
-                  pv = ((kv <= qrow) & (dkk[e] == dq) & (dq > 0)) ? pv : 0.f;
+                  pv = ((kv <= qcap) & (dkk[e] == dq) & (dq > 0)) ? pv : 0.f;
                 }
                 ds[r] = pv * (dpacc[r] - delta);
               }
@@ -669,7 +675,7 @@ static int attn_bwd_launch(const void* q, const void* k, const void* v, const vo
   if (D == 128) {
     hipLaunchKernelGGL((attn_delta_kernel<128>), dim3((rows * 16 + 255) / 256), block, 0, st, (const bf16_t*)o, dO,
                        delta, B, qv.rpb, Nh);
-    if (bwd_kv_split()) {
+    if (bwd_kv_split() || qv.bidir) {          // (the fused pass is causal only)
       hipLaunchKernelGGL((attn_bwd_kv_kernel<128, 0>), gk, block, 0, st, Q, K, V, dO, lse2, delta, (bf16_t*)dk,
                          (bf16_t*)dv, doc, m, qv, T, Nh, Nkv, scale, sl2);
       hipLaunchKernelGGL((attn_bwd_kv_kernel<128, 1>), gk, block, 0, st, Q, K, V, dO, lse2, delta, (bf16_t*)dk,
@@ -697,6 +703,15 @@ int tn_attn_bwd(const void* q, const void* k, const void* v, const void* o, cons
                 float* delta, void* dq, void* dk, void* dv, const int* doc, const int* meta, int B, int T, int Nh,
                 int Nkv, int D, float scale, void* stream) {
   const QView qv = {1, {0, 0}, {T, 0}, {0, 0}, T, 0, ~0ull};
+  return attn_bwd_launch(q, k, v, o, dout, lse2, delta, dq, dk, dv, doc, meta, B, T, Nh, Nkv, D, scale, qv, stream);
+}
+
+// Bidirectional inside a document, see tn_attn_fwd_bidir.
+int tn_attn_bwd_bidir(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse2,
+                      float* delta, void* dq, void* dk, void* dv, const int* doc, const int* meta, int B, int T, int Nh,
+                      int Nkv, int D, float scale, void* stream) {
+  QView qv = {1, {0, 0}, {T, 0}, {0, 0}, T, 0, ~0ull};
+  qv.bidir = 1;
   return attn_bwd_launch(q, k, v, o, dout, lse2, delta, dq, dk, dv, doc, meta, B, T, Nh, Nkv, D, scale, qv, stream);
 }
 

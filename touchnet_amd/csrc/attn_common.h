@@ -80,6 +80,11 @@ struct QView {
   // kv_tpc = 64-position tiles per chunk (0 = no restriction), bit c of kv_mask = chunk c takes part
   int kv_tpc;
   unsigned long long kv_mask;
+  // 0 = causal inside a document (every decoder; Qwen2-Audio's tower), 1 = BIDIRECTIONAL inside a document (the Whisper
+  // speech encoder of Kimi-Audio: transformers' WhisperEncoder has no causal mask,
+  // touchnet/models/kimi_audio/modeling_kimi_audio.py:933-960): the key range of a query tile then runs to the LAST
+  // tile that shares a document with it and the predicate loses its `kv <= q` term
+  int bidir;
   __device__ __forceinline__ bool kv_tile_on(int j) const { return kv_tpc == 0 || ((kv_mask >> (j / kv_tpc)) & 1ull); }
   __host__ __device__ int tiles(int s, int bm) const { return s < nseg ? (rows[s] + bm - 1) / bm : 0; }
   // tile `idx` of size bm over all segments -> local first row, global first position, rows left in segment

@@ -129,7 +129,12 @@ __global__ __launch_bounds__(64 * NW, D == 64 ? 3 : 2) void attn_fwd_kernel(cons
     bmax = max(bmax, m_max[t]);
     j = min(j, meta.q_lo[(size_t)b * meta.nt + t]);
   }
-  const int j_hi = t1, j_lo = j;
+  int j_hi = t1;
+  const int j_lo = j;
+  const bool bidir = qv.bidir != 0;
+  if (bidir)
+    for (int t = t0; t <= t1; ++t) j_hi = max(j_hi, meta.kv_hi[(size_t)b * meta.nt + t]);
+  const int qcap = bidir ? 0x7fffffff : qrow;          // `kv <= qcap`: the causal term of the predicate
 
   f32x16_t oacc[DBLK];
 #pragma unroll
@@ -175,9 +180,9 @@ __global__ __launch_bounds__(64 * NW, D == 64 ? 3 : 2) void attn_fwd_kernel(cons
       const int* docs = reinterpret_cast<const int*>(Vs + Tile::SIZE);
       const int j = e_cur.x, kmin = e_cur.y, kmax = e_cur.z, kminpos = e_cur.w;
       const int k0 = j * BN;
-    if (uniform(k0 <= wq0 + 31 && tile_may_interact(wminpos, wmax, kminpos, kmax))) {
+    if (uniform((bidir || k0 <= wq0 + 31) && tile_may_interact(wminpos, wmax, kminpos, kmax))) {
       const bool need_mask = uniform(
-          !(kmin == kmax && kmax == wminpos && wminpos == wmax && !w_has_zero && (k0 + BN - 1 <= wq0)));
+          !(kmin == kmax && kmax == wminpos && wminpos == wmax && !w_has_zero && (bidir || k0 + BN - 1 <= wq0)));
       // ---- S^T[kv, q] = K[kv, :] . Q[q, :]
       f32x16_t sacc[2];
 #pragma unroll
@@ -200,7 +205,7 @@ __global__ __launch_bounds__(64 * NW, D == 64 ? 3 : 2) void attn_fwd_kernel(cons
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               const int kv = k0 + 32 * blk + 8 * r4 + 4 * hi + e;
-              const bool ok = (kv <= qrow) & (dkk[e] == dq) & (dq > 0);
+              const bool ok = (kv <= qcap) & (dkk[e] == dq) & (dq > 0);
               sacc[blk][4 * r4 + e] = ok ? sacc[blk][4 * r4 + e] : -INFINITY;
             }
           }
@@ -399,7 +404,7 @@ static int attn_fwd_launch(const void* q, const void* k, const void* v, void* o,
   AttnMeta m = {meta, meta + n, meta + 2 * n, meta + 3 * n, meta + 4 * n, nt};
   const float sl2 = scale * 1.4426950408889634f;
   hipStream_t st = (hipStream_t)stream;
-  if (fwd_schedule(T, D) == 1 && (D == 64 || D == 128) && nt <= 1024)   // (the ping-pong kernel's LDS tile list)
+  if (!qv.bidir && fwd_schedule(T, D) == 1 && (D == 64 || D == 128) && nt <= 1024)   // (the ping-pong kernel's LDS tile list)
     return tn_attn_fwd_pp_launch(q, k, v, o, lse2, doc, m, qv, B, T, Nh, Nkv, D, sl2, st);
   dim3 grid(Nh, qv.tiles(0, 128) + qv.tiles(1, 128), B), block(256);
   if (D == 128)
@@ -417,6 +422,14 @@ static int attn_fwd_launch(const void* q, const void* k, const void* v, void* o,
 int tn_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse2, const int* doc, const int* meta,
                 int B, int T, int Nh, int Nkv, int D, float scale, void* stream) {
   const QView qv = {1, {0, 0}, {T, 0}, {0, 0}, T, 0, ~0ull};
+  return attn_fwd_launch(q, k, v, o, lse2, doc, meta, B, T, Nh, Nkv, D, scale, qv, stream);
+}
+
+// Bidirectional inside a document (no causal term): the Whisper speech encoder of Kimi-Audio.
+int tn_attn_fwd_bidir(const void* q, const void* k, const void* v, void* o, float* lse2, const int* doc,
+                      const int* meta, int B, int T, int Nh, int Nkv, int D, float scale, void* stream) {
+  QView qv = {1, {0, 0}, {T, 0}, {0, 0}, T, 0, ~0ull};
+  qv.bidir = 1;
   return attn_fwd_launch(q, k, v, o, lse2, doc, meta, B, T, Nh, Nkv, D, scale, qv, stream);
 }
 

@@ -119,70 +119,27 @@ def packed_attention(q, k, v, mask: PackedMask, scale: Optional[float] = None):
 
 
 class _BidirectionalAttention(torch.autograd.Function):
-    """softmax over ALL keys of the query's document (no causal restriction) on the document-CAUSAL kernels: the keys at
-    or before the query (one launch on the batch as it is) + the keys at or after it (one launch on the time-reversed
-    batch), merged by their log-sum-exp; the diagonal pair is in both parts and is taken out once, in closed form.
-    The two launches together visit every allowed (query, key) pair exactly once + the diagonal twice: no wasted tiles.
-    Backward: `tn_attn_bwd` on each part with the MERGED output and log-sum-exp (the gradient of a softmax over a union
-    of key sets does not care how the forward was split — same argument as `_SplitAttention`), minus the diagonal's
-    contribution, which the two parts both contain.
+    """softmax over ALL keys of the query's document (no causal restriction): `tn_attn_fwd_bidir` / `tn_attn_bwd_bidir`,
+    the packed-attention kernels with the causal term of the predicate switched off and the key range of a query tile
+    extended to the last tile that shares a document with it (csrc/attn_common.h QView::bidir).
     Used by the Whisper speech encoder of Kimi-Audio (touchnet/models/kimi_audio/modeling_kimi_audio.py:337-339, 942-947:
-    transformers' WhisperEncoder, bidirectional self-attention over the 1500 frames of a clip)."""
-
-    @staticmethod
-    def _diag_log2(q, k, scale):
-        g = q.shape[2] // k.shape[2]
-        kq = k.repeat_interleave(g, dim=2) if g > 1 else k
-        return (q.float() * kq.float()).sum(-1).transpose(1, 2) * (scale * 1.4426950408889634)     # [B, Nh, T]
+    transformers' WhisperEncoder, bidirectional self-attention over the 1500 frames of a clip).
+    (Round 4 first built it from two launches of the causal kernels — the batch and its time reversal — merged by their
+    log-sum-exp in torch: correct, but the flips and the fp32 merge were 32 % of the speech workload's step.)"""
 
     @staticmethod
     def forward(ctx, q, k, v, doc, meta, scale):
         q, k, v = _c(q), _c(k), _c(v)
-        docr = _c(doc.flip(1))
-        metar = L.attn_build_meta(docr)
-        o_a, l_a = L.attn_fwd(q, k, v, doc, meta, scale)
-        o_b, l_b = L.attn_fwd(_c(q.flip(1)), _c(k.flip(1)), _c(v.flip(1)), docr, metar, scale)
-        o_b, l_b = o_b.flip(1), l_b.flip(2)
-        l_d = _BidirectionalAttention._diag_log2(q, k, scale)
-        empty = torch.isinf(l_a) & (l_a > 0)                         # the kernels' "+inf = no key" (pad rows)
-        neg = torch.full_like(l_a, float("-inf"))
-        la, lb = torch.where(empty, neg, l_a), torch.where(torch.isinf(l_b) & (l_b > 0), neg, l_b)
-        m = torch.maximum(la, lb)
-        m0 = torch.where(empty, torch.zeros_like(m), m)
-        wa, wb = torch.exp2(la - m0), torch.exp2(lb - m0)
-        wd = torch.where(empty, torch.zeros_like(m), torch.exp2(l_d - m0))
-        z = wa + wb - wd
-        g = q.shape[2] // v.shape[2]
-        vq = (v.repeat_interleave(g, dim=2) if g > 1 else v).float()
-        tr = lambda w: w.transpose(1, 2).unsqueeze(-1)               # [B, Nh, T] -> [B, T, Nh, 1]
-        zs = torch.where(empty, torch.ones_like(z), z)
-        o = _c(((tr(wa) * o_a.float() + tr(wb) * o_b.float() - tr(wd) * vq) / tr(zs)).to(q.dtype))
-        lse = _c(torch.where(empty, l_a, m0 + torch.log2(zs)))
-        ctx.save_for_backward(q, k, v, o, lse, doc, meta, docr, metar, l_d)
+        o, lse = L.attn_fwd_bidir(q, k, v, doc, meta, scale)
+        ctx.save_for_backward(q, k, v, o, lse, doc, meta)
         ctx.scale = scale
         return o
 
     @staticmethod
     def backward(ctx, do):
-        q, k, v, o, lse, doc, meta, docr, metar, l_d = ctx.saved_tensors
-        do = _c(do)
-        scale = ctx.scale
-        dq_a, dk_a, dv_a = L.attn_bwd(q, k, v, o, do, lse, doc, meta, scale)
-        dq_b, dk_b, dv_b = L.attn_bwd(_c(q.flip(1)), _c(k.flip(1)), _c(v.flip(1)), _c(o.flip(1)), _c(do.flip(1)),
-                                      _c(lse.flip(2)), docr, metar, scale)
-        # the diagonal pair (t, t), present in both parts
-        g = q.shape[2] // k.shape[2]
-        rep = (lambda t: t.repeat_interleave(g, dim=2)) if g > 1 else (lambda t: t)
-        fold = (lambda t: t.view(*t.shape[:2], k.shape[2], g, t.shape[-1]).sum(3)) if g > 1 else (lambda t: t)
-        empty = torch.isinf(lse) & (lse > 0)
-        p_d = torch.where(empty, torch.zeros_like(lse), torch.exp2(l_d - torch.where(empty, torch.zeros_like(lse), lse)))
-        p_d = p_d.transpose(1, 2).unsqueeze(-1)                                       # [B, T, Nh, 1]
-        dof, of = do.float(), o.float()
-        ds_d = p_d * ((dof * rep(v).float()).sum(-1, keepdim=True) - (dof * of).sum(-1, keepdim=True))
-        dq = dq_a.float() + dq_b.flip(1).float() - scale * ds_d * rep(k).float()
-        dk = dk_a.float() + dk_b.flip(1).float() - fold(scale * ds_d * q.float())
-        dv = dv_a.float() + dv_b.flip(1).float() - fold(p_d * dof)
-        return dq.to(q.dtype), dk.to(k.dtype), dv.to(v.dtype), None, None, None
+        q, k, v, o, lse, doc, meta = ctx.saved_tensors
+        dq, dk, dv = L.attn_bwd_bidir(q, k, v, o, _c(do), lse, doc, meta, ctx.scale)
+        return dq, dk, dv, None, None, None
 
 
 def bidirectional_attention(q, k, v, mask: PackedMask, scale: Optional[float] = None):

@@ -319,6 +319,48 @@ def _(q, k, v, o, do, lse2, doc, meta, scale):
     return e(q), e(k), e(v)
 
 
+@custom_op(f"{NS}::attn_fwd_bidir", mutates_args=(), device_types="cuda")
+def attn_fwd_bidir(q: Tensor, k: Tensor, v: Tensor, doc: Tensor, meta: Tensor, scale: float) -> Tuple[Tensor, Tensor]:
+    """`attn_fwd` with the mask bidirectional inside a document (tn_attn_fwd_bidir)."""
+    q, k, v = _c(q), _c(k), _c(v)
+    if q.dtype != torch.bfloat16:
+        raise _C.KernelError("bidirectional_attention: bf16 only (MFMA 32x32x16 bf16 kernel)")
+    B, T, Nh, D = q.shape
+    Nkv = k.shape[2]
+    if tuple(doc.shape) != (B, T):
+        raise _C.KernelError(f"mask built for {tuple(doc.shape)}, got q {(B, T)}")
+    o = torch.empty_like(q)
+    lse2 = torch.empty(B, Nh, T, dtype=torch.float32, device=q.device)
+    _C.check(_lib().tn_attn_fwd_bidir(_p(q), _p(k), _p(v), _p(o), _p(lse2), _p(doc), _p(meta), B, T, Nh, Nkv, D,
+                                      float(scale), _cur()), "tn_attn_fwd_bidir")
+    return o, lse2
+
+
+@attn_fwd_bidir.register_fake
+def _(q, k, v, doc, meta, scale):
+    B, T, Nh, D = q.shape
+    return torch.empty_like(q, memory_format=torch.contiguous_format), q.new_empty(B, Nh, T, dtype=torch.float32)
+
+
+@custom_op(f"{NS}::attn_bwd_bidir", mutates_args=(), device_types="cuda")
+def attn_bwd_bidir(q: Tensor, k: Tensor, v: Tensor, o: Tensor, do: Tensor, lse2: Tensor, doc: Tensor, meta: Tensor,
+                   scale: float) -> Tuple[Tensor, Tensor, Tensor]:
+    do = _c(do)
+    B, T, Nh, D = q.shape
+    Nkv = k.shape[2]
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    delta = torch.empty_like(lse2)
+    _C.check(_lib().tn_attn_bwd_bidir(_p(q), _p(k), _p(v), _p(o), _p(do), _p(lse2), _p(delta), _p(dq), _p(dk), _p(dv),
+                                      _p(doc), _p(meta), B, T, Nh, Nkv, D, float(scale), _cur()), "tn_attn_bwd_bidir")
+    return dq, dk, dv
+
+
+@attn_bwd_bidir.register_fake
+def _(q, k, v, o, do, lse2, doc, meta, scale):
+    e = lambda t: torch.empty_like(t, memory_format=torch.contiguous_format)
+    return e(q), e(k), e(v)
+
+
 _STACKED_BWD = os.environ.get("TN_ATTN_BWD_STACKED", "1") != "0"      # (A/B switch)
 
 
@@ -800,6 +842,6 @@ def _(feat, quantizer, codebook):
 
 
 OPS = ("rmsnorm_fwd", "rmsnorm_bwd", "layernorm_fwd", "layernorm_bwd", "swiglu_fwd", "swiglu_bwd", "gelu_fwd",
-       "gelu_bwd", "rope_apply", "attn_fwd", "attn_bwd", "attn_bwd_stacked", "attn_build_meta", "attn_fwd_seg", "attn_fwd_seg_chunks", "attn_merge", "attn_bwd_seg", "ce_fwd",
+       "gelu_bwd", "rope_apply", "attn_fwd", "attn_bwd", "attn_fwd_bidir", "attn_bwd_bidir", "attn_bwd_stacked", "attn_build_meta", "attn_fwd_seg", "attn_fwd_seg_chunks", "attn_merge", "attn_bwd_seg", "ce_fwd",
        "ce_bwd", "ce_bwd_", "gemm_tn", "rope_table", "transpose_bf16_", "colsum_bf16", "swiglu_fwd_t", "swiglu_bwd_t",
        "ce_fwd_rows", "ce_reduce", "kaldi_fbank", "log_mel", "audiofeat_stack", "pcm16_to_f32", "bestrq_tokenize")
