@@ -152,6 +152,11 @@ int tn_audiofeat_stack(const float* feat, float* out, int T, int F, int stack, i
  * entries each; y must not alias x. */
 int tn_feat_augment(const float* x, float* y, int T, int F, int out_rows, const int* t_masks, int n_t,
                     const int* f_masks, int n_f, const int* subs, int n_sub, void* stream);
+/* Waveform-level speed perturbation, touchnet/data/functions.py:99-114 (sox `speed s` + `rate`): x [n_in] resampled to
+ * y [n_out], output n at input position n p / q, by a polyphase band-limited interpolation table tab [q][ntap] (device,
+ * float; built by the host side, touchnet_amd/functional.py::speed_perturb).  Not bit-comparable with libsox. */
+int tn_resample_polyphase(const float* x, float* y, const float* tab, long long n_in, long long n_out, int p, int q,
+                          int ntap, void* stream);
 
 /* ---- fused AdamW on fp32 master weights with bf16 shadow write-back and device-side
  *      skip-on-nonfinite — touchnet/utils/optimizer.py:157-172 + touchnet/bin/train.py:458-474.

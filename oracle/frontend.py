@@ -3,6 +3,7 @@
 Restates, in NumPy float32/float64 on the CPU,
   * ``audiofeat_stack``                     touchnet/data/functions.py:258-286
   * ``spec_aug / spec_sub / spec_trim``     touchnet/data/functions.py:193-255
+  * ``speed_perturb``                       touchnet/data/functions.py:99-114 (sox: PARITY UNPINNED, see the function)
   * ``audio_compute_log_mel_spectrogram``   touchnet/data/functions.py:159-190
     (librosa.filters.mel(sr, n_fft, n_mels) = slaney scale + slaney norm is a
     third-party dependency, pyproject.toml:17 `librosa>=0.11.0`; restated from its
@@ -48,6 +49,33 @@ def audiofeat_stack(feat, stack, stride, normalize=True):
         std = out.std(axis=-1, keepdims=True, ddof=1, dtype=np.float32)
         out = (out - mean) / (std + np.float32(1e-5))
     return out.astype(np.float32)
+
+
+# --------------------------------------------------------------------------- speed perturbation
+def speed_perturb(x, speed, zeros=32, rolloff=0.95, beta=14.769656459379492):
+    """touchnet/data/functions.py:99-114 (sox `speed s` + `rate sr`): the waveform resampled by 1 / s.  PARITY UNPINNED: libsox
+    is a third-party binary resampler, absent here like torchaudio; this is the float64 evaluation of the band-limited
+    interpolation the product kernel implements, written directly from the formula (no table):
+        y[n] = sum_k x[k] h(n s - k),  h(t) = c sinc(c t) kaiser(t / W),  c = rolloff min(1, 1 / s),  W = zeros / c
+    with floor(N / s) output samples."""
+    import fractions
+    x = np.asarray(x, dtype=np.float64).reshape(-1)
+    if speed == 1.0:
+        return x.astype(np.float32)
+    fr = fractions.Fraction(str(speed)).limit_denominator(1000)
+    s = fr.numerator / fr.denominator
+    n_out = max((x.size * fr.denominator) // fr.numerator, 1)
+    c = rolloff * min(1.0, 1.0 / s)
+    W = zeros / c
+    half = int(math.ceil(W)) + 1
+    y = np.zeros(n_out, dtype=np.float64)
+    for n in range(n_out):
+        pos = n * fr.numerator / fr.denominator
+        k = np.arange(max(0, int(math.floor(pos)) - half), min(x.size, int(math.floor(pos)) + half + 1))
+        t = pos - k
+        w = np.where(np.abs(t) < W, np.i0(beta * np.sqrt(np.clip(1.0 - (t / W) ** 2, 0.0, None))) / np.i0(beta), 0.0)
+        y[n] = np.dot(x[k], c * np.sinc(c * t) * w)
+    return y.astype(np.float32)
 
 
 # --------------------------------------------------------------------------- feature-level augmentation

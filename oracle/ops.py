@@ -202,6 +202,11 @@ def log_mel_spectrogram(wav, num_mel_bins=128, padding=0):
                                                     padding=padding)).float()
 
 
+def speed_perturb(wave, speed):
+    from . import frontend as _fe
+    return torch.from_numpy(_fe.speed_perturb(wave.detach().cpu().numpy(), speed))
+
+
 def feat_augment(feat, t_masks=(), f_masks=(), subs=(), out_rows=None):
     """the product op's contract (touchnet_amd.functional.feat_augment) on the CPU: stripes, substitutions, trim"""
     x = feat.detach().cpu().float()

@@ -1114,12 +1114,43 @@ def audiofeat_augment_case():
     save("audiofeat_augment.npz", **out)
 
 
+def speed_perturb_draws_case():
+    """touchnet/data/functions.py:99-114 run here with sox stood in by a recorder (torchaudio is not in this image): WHICH
+    speed the reference's stage draws for each of 24 consecutive samples under `random.seed(seed)`, and that it hands
+    sox exactly [['speed', s], ['rate', sample_rate]] for s != 1.  The twins replay the draws; the resampling itself has no
+    reference output to be held to (libsox), see oracle/frontend.py::speed_perturb."""
+    import random
+    import torchaudio                                          # the MagicMock installed by _ref_import
+    calls = []
+
+    def recorder(waveform, sample_rate, effects):
+        calls.append((int(sample_rate), [list(map(str, e)) for e in effects]))
+        return waveform, sample_rate
+    torchaudio.sox_effects.apply_effects_tensor = recorder
+    out = {}
+    for name, speeds, seed in (("recipe", [0.9, 1.0, 1.1], 2025), ("two", [0.9, 1.1], 3)):
+        cfg = types.SimpleNamespace(audio_speed_perturb_speeds=speeds)
+        data = iter([{"sample_rate": 16000, "waveform": torch.zeros(1, 160)} for _ in range(24)])
+        calls.clear()
+        random.seed(seed)
+        n = sum(1 for _ in ref_fn.audio_speed_perturb(data, cfg))
+        assert n == 24
+        random.seed(seed)
+        chosen = [random.choice(speeds) for _ in range(24)]       # (the stage makes exactly this one call per sample)
+        assert [float(c[1][0][1]) for c in calls] == [s for s in chosen if s != 1.0]
+        assert all(c[1] == [["speed", str(s)], ["rate", "16000"]] for c, s in zip(calls, [s for s in chosen if s != 1.0]))
+        out[f"{name}/speeds"] = np.array(speeds)
+        out[f"{name}/seed"] = np.array(seed)
+        out[f"{name}/chosen"] = np.array(chosen)
+    save("speed_perturb_draws.npz", **out)
+
+
 if __name__ == "__main__":
     only = set(sys.argv[1:])
     for fn in (text_cases, asr_cases, ce_cases, docmask_cases, rope_cases, tiny_llama_case,
                touch_audio_case, qwen2_audio_tower_case, frontend_cases, fbank_cases, bestrq_cases, touchdataset_case,
                boundary_case, qwen2_audio_data_case, kimi_decoder_case, tiny_llama_dev_case, touch_audio_dev_case,
                qwen2_audio_tower_dev_case, kimi_decoder_dev_case, kimi_audio_input_case,
-               kimi_audio_data_case, audiofeat_augment_case):
+               kimi_audio_data_case, audiofeat_augment_case, speed_perturb_draws_case):
         if not only or fn.__name__ in only:
             fn()

@@ -430,6 +430,40 @@ def test_feature_augmentation_on_the_device_replays_the_reference_runs(golden):
         F.feat_augment(x, t_masks=[(0, 1)] * 17)
 
 
+def test_speed_perturbation_on_the_device():
+    """functional.speed_perturb (polyphase table, fp32) against the oracle's float64 evaluation of the same band-limited
+    interpolation, directly from the formula: speech-like noise and a tone, both recipe speeds, an odd length; through the
+    datapipe stage too (int16 PCM in, the draw of `random.choice` decides)."""
+    import random
+    import types
+    from oracle import frontend as ofe
+    from touchnet_amd.data import functions as fn
+    F = _f()
+    rng = np.random.RandomState(3)
+    for n in (16000, 4801):
+        x = (rng.randn(n) * 0.1).astype(np.float32)
+        x[: n // 2] += np.sin(2 * np.pi * 700 * np.arange(n // 2) / 16000).astype(np.float32) * 0.5
+        for speed in (0.9, 1.1):
+            y = F.speed_perturb(torch.from_numpy(x).to(DEV), speed).cpu().numpy()
+            ref = ofe.speed_perturb(x, speed)
+            assert y.shape == ref.shape
+            assert np.abs(y - ref).max() < 5e-6, (n, speed, np.abs(y - ref).max())
+    assert F.speed_perturb(torch.from_numpy(x).to(DEV), 1.0).data_ptr() != 0
+    cfg = types.SimpleNamespace(audio_speed_perturb_speeds=[0.9, 1.0, 1.1])
+    pcm = (rng.randn(1, 8000) * 3000).astype(np.int16)
+    random.seed(11)
+    picks = [random.choice(cfg.audio_speed_perturb_speeds) for _ in range(6)]
+    random.seed(11)
+    outs = list(fn.audio_speed_perturb(iter([{"sample_rate": 16000, "waveform": torch.from_numpy(pcm.copy())} for _ in range(6)]), cfg))
+    for sp, smp in zip(picks, outs):
+        w = smp["waveform"]
+        assert w.shape[1] == (8000 if sp == 1.0 else 8000 * 10 // round(sp * 10))
+        if sp != 1.0:
+            assert w.is_cuda and w.dtype == torch.float32
+            ref = ofe.speed_perturb(pcm[0].astype(np.float32) / 32768.0, sp)
+            assert np.abs(w.cpu().numpy()[0] - ref).max() < 5e-6
+
+
 def test_frontend_log_mel(golden):
     F = _f()
     g = golden("logmel.npz")

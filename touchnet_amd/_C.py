@@ -49,6 +49,7 @@ PROTOTYPES = {
     "tn_kaldi_fbank": [_vp, _vp, _i, _i, _vp],
     "tn_log_mel": [_vp, _vp, _vp, _vp, _i, _i, _vp],
     "tn_audiofeat_stack": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "tn_resample_polyphase": [_vp, _vp, _vp, _ll, _ll, _i, _i, _i, _vp],
     "tn_feat_augment": [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp],
     "tn_sumsq_scratch_floats": [],
     "tn_sumsq": [_vp, _vp, _vp, _ll, _i, _vp],

@@ -240,6 +240,33 @@ __global__ __launch_bounds__(256) void feat_augment_kernel(const float* __restri
   y[i] = zero ? 0.f : x[(size_t)src * F + f];
 }
 
+// ---------------------------------------------------------------------------------------------- speed perturbation
+// touchnet/data/functions.py:99-114: sox `speed s` + `rate sr` = the waveform resampled by the factor 1/s (pitch and tempo
+// change together).  libsox's polyphase resampler is a third-party binary algorithm that cannot be restated bit for bit
+// (and torchaudio is not in this image to compare with): this kernel evaluates the band-limited interpolation
+//     y[n] = sum_k x[k] h(n s - k),   h(t) = c sinc(c t) kaiser(t / W),  c = 0.95 min(1, 1/s)
+// from a polyphase table the host builds in float64 for the rational speed p / q (touchnet_amd/functional.py): output n sits
+// at input position (n p) / q -> integer part i, phase r = (n p) mod q, and y[n] = sum_j x[i - half + 1 + j] tab[r][j].
+// PARITY UNPINNED against libsox (stated in DESIGN.md); held to a float64 evaluation of the same formula (oracle/frontend.py).
+__global__ __launch_bounds__(256) void resample_polyphase_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                 const float* __restrict__ tab, long long n_in,
+                                                                 long long n_out, int p, int q, int ntap) {
+  const long long n = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (n >= n_out) return;
+  const long long pos = n * p;
+  const long long i = pos / q;
+  const int r = (int)(pos - i * q);
+  const float* t = tab + (size_t)r * ntap;
+  const long long k0 = i - ntap / 2 + 1;
+  float acc = 0.f;
+  for (int j = 0; j < ntap; ++j) {
+    const long long k = k0 + j;
+    const float xv = (k >= 0 && k < n_in) ? x[k] : 0.f;
+    acc = fmaf(xv, t[j], acc);
+  }
+  y[n] = acc;
+}
+
 // int16 PCM -> float32 in [-1, 1): x * 2^-15, exactly numpy's `astype(float32) / 32768.0` of the reference's
 // datapipe (touchnet/data/datapipe.py:164).  Lets the caller upload 2 bytes per sample.
 __global__ __launch_bounds__(256) void pcm16_to_f32_kernel(const int16_t* __restrict__ in, float* __restrict__ out,
@@ -327,6 +354,16 @@ int tn_feat_augment(const float* x, float* y, int T, int F, int out_rows, const 
   const long long n = (long long)out_rows * F;
   hipLaunchKernelGGL(feat_augment_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, F,
                      n, plan);
+  TN_LAUNCH_CHECK();
+  return TN_OK;
+}
+
+// x [n_in] -> y [n_out] at the rational rate p / q input samples per output sample; tab: device float [q][ntap] (ntap even).
+int tn_resample_polyphase(const float* x, float* y, const float* tab, long long n_in, long long n_out, int p, int q,
+                          int ntap, void* stream) {
+  if (n_in <= 0 || n_out <= 0 || p <= 0 || q <= 0 || ntap <= 0 || (ntap & 1) || x == y) return TN_EINVAL;
+  hipLaunchKernelGGL(resample_polyphase_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     x, y, tab, n_in, n_out, p, q, ntap);
   TN_LAUNCH_CHECK();
   return TN_OK;
 }

@@ -173,11 +173,6 @@ def build_datapipe(cfg, tokenizer, dp_rank: int, dp_world_size: int):
     if kind == "causal_lm":
         pipe = stage(functions.filter_samples, cfg)
         return stage(batch_text, cfg, tokenizer)
-    if getattr(cfg, "audio_speed_perturb", False):
-        # functions.py:99-114 hands the waveform to libsox (`speed` + `rate` effects): a third-party resampler whose
-        # output cannot be restated bit for bit here (and torchaudio is not in this image to pin one against)
-        raise NotImplementedError("audio_speed_perturb: chain the reference's (sox) stage function in front of the device "
-                                  "frontend, or perturb when the dataset is written")
     augment = any(getattr(cfg, a, False) for a in ("audiofeat_spec_aug", "audiofeat_spec_sub", "audiofeat_spec_trim"))
     if kind == "touch_audio":
         labels_from_audio = hasattr(tokenizer, "quantizer") or type(tokenizer).__name__ == "BestRQTokenizer"
@@ -185,6 +180,8 @@ def build_datapipe(cfg, tokenizer, dp_rank: int, dp_world_size: int):
             pipe = stage(functions.text_tokenize, tokenizer)
         pipe = stage(functions.filter_samples, cfg)
         pipe = stage(functions.audio_resample, cfg)
+        if getattr(cfg, "audio_speed_perturb", False):            # wav-level augmentation (processing_touch_audio.py:457-459)
+            pipe = stage(functions.audio_speed_perturb, cfg)
         if cfg.audio_feat_type == "fbank":
             pipe = stage(functions.audio_compute_fbank, cfg)
         elif cfg.audio_feat_type == "log_mel_spectrogram":

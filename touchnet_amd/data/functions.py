@@ -27,6 +27,19 @@ def _dev_wave(sample):
     return w.reshape(-1)
 
 
+def audio_speed_perturb(data, config):
+    """functions.py:99-114: one `random.choice(config.audio_speed_perturb_speeds)` per sample (the reference's call, so the
+    global `random` stream stays aligned with the stages behind), then the waveform resampled ON THE DEVICE
+    (functional.speed_perturb; the reference hands it to libsox — band-limited interpolation of the same signal, not the
+    same bits)."""
+    for sample in data:
+        speed = random.choice(config.audio_speed_perturb_speeds)
+        if speed != 1.0:
+            w = ops().speed_perturb(_dev_wave(sample), float(speed))
+            sample["waveform"] = w.reshape(1, -1)
+        yield sample
+
+
 def audio_compute_fbank(data, config):
     for sample in data:
         assert sample["sample_rate"] == 16000, "device frontend: 16 kHz only (all reference recipes)"

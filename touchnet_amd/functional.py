@@ -1035,6 +1035,46 @@ def bestrq_tokenize(feat: torch.Tensor, quantizer: torch.Tensor, codebook: torch
     return L.bestrq_tokenize(_c(feat), _c(quantizer), _c(codebook))
 
 
+SPEED_ZEROS = 32            # zero crossings of the interpolation kernel on each side (at the cutoff's scale)
+SPEED_ROLLOFF = 0.95        # pass band as a fraction of the narrower Nyquist band
+SPEED_BETA = 14.769656459379492   # Kaiser window: ~ -150 dB side lobes
+_SPEED_TABLES = {}
+
+
+def speed_filter_bank(speed: float):
+    """(p, q, table [q, ntap] float64) of the polyphase band-limited interpolator for `speed` = p / q:
+    h(t) = c sinc(c t) kaiser(t / W), c = rolloff * min(1, 1 / speed), W = zeros / c input samples; row r holds
+    h(r / q - (j - ntap / 2 + 1)) for j = 0 .. ntap - 1."""
+    import fractions
+
+    import numpy as np
+    fr = fractions.Fraction(str(speed)).limit_denominator(1000)
+    p_, q_ = fr.numerator, fr.denominator
+    c = SPEED_ROLLOFF * min(1.0, q_ / p_)
+    W = SPEED_ZEROS / c
+    ntap = 2 * int(math.ceil(W))
+    j = np.arange(ntap, dtype=np.float64)[None, :] - (ntap // 2 - 1)          # input offset k - i
+    t = np.arange(q_, dtype=np.float64)[:, None] / q_ - j                     # (n s - k)
+    win = np.where(np.abs(t) < W, np.i0(SPEED_BETA * np.sqrt(np.clip(1.0 - (t / W) ** 2, 0.0, None))) / np.i0(SPEED_BETA), 0.0)
+    return p_, q_, c * np.sinc(c * t) * win
+
+
+def speed_perturb(wave: torch.Tensor, speed: float) -> torch.Tensor:
+    """fp32 waveform [N] on the device played `speed` times faster (pitch and tempo), same sample rate:
+    floor(N / speed) samples (touchnet/data/functions.py:99-114: sox `speed` + `rate`)."""
+    if not wave.is_cuda or wave.dim() != 1:
+        raise RuntimeError("speed_perturb: expects a 1-D device waveform")
+    if speed == 1.0:
+        return wave
+    key = (float(speed), wave.device)
+    if key not in _SPEED_TABLES:
+        p_, q_, tab = speed_filter_bank(speed)
+        _SPEED_TABLES[key] = (p_, q_, torch.from_numpy(tab).to(torch.float32).to(wave.device).contiguous())
+    p_, q_, tab = _SPEED_TABLES[key]
+    n_out = (wave.numel() * q_) // p_
+    return L.resample_polyphase(_c(wave).float(), tab, p_, q_, max(n_out, 1))
+
+
 def feat_augment(feat: torch.Tensor, t_masks=(), f_masks=(), subs=(), out_rows: Optional[int] = None) -> torch.Tensor:
     """fp32 [T, F] -> fp32 [out_rows, F]: zero stripes (spec_aug), row substitutions from earlier rows (spec_sub) and the
     tail trim (spec_trim) of touchnet/data/functions.py:193-255 in one pass; the draws come from the caller."""

@@ -795,6 +795,14 @@ def _(feat, stack, stride, normalize):
     return feat.new_empty((feat.shape[0] + stride - 1) // stride, feat.shape[1] * stack)
 
 
+def resample_polyphase(wave: Tensor, tab: Tensor, p: int, q: int, n_out: int) -> Tensor:
+    """tn_resample_polyphase on a 1-D fp32 device waveform"""
+    out = torch.empty(n_out, dtype=torch.float32, device=wave.device)
+    _C.check(_lib().tn_resample_polyphase(_p(wave), _p(out), _p(tab), wave.numel(), int(n_out), int(p), int(q),
+                                          int(tab.shape[1]), _cur()), "tn_resample_polyphase")
+    return out
+
+
 def feat_augment(feat: Tensor, t_masks, f_masks, subs, out_rows: int) -> Tensor:
     """tn_feat_augment: the draws travel as kernel arguments (host int arrays), so this is a plain function, not a
     registered op (no tensor carries them)."""
