@@ -138,7 +138,10 @@ def _flat_worker(rank, world, port, path, ret):
         sd2 = {"optimizer": opt2.state_dict()}
         dcp.load(sd2, checkpoint_id=path)
         opt2.load_state_dict(sd2["optimizer"])
-        ret[rank] = all(torch.equal(s[k], w[k]) for s, w in zip(opt2.state, want) for k in ("master", "m", "v"))
+        ok = all(torch.equal(s[k], w[k]) for s, w in zip(opt2.state, want) for k in ("master", "m", "v"))
+        # what the other world size must find: every rank's slices, in rank order
+        ret[rank] = (ok, [eng.buckets[i].total for i in range(len(eng.buckets))],
+                     [{k: v.clone() for k, v in s.items()} for s in want])
     finally:
         dist.destroy_process_group()
 
@@ -155,4 +158,28 @@ def test_dcp_round_trip_of_the_flat_engines_shards(tmp_path):
     for p in procs:
         p.join(300)
         assert p.exitcode == 0
-    assert ret[0] and ret[1], dict(ret)
+    assert ret[0][0] and ret[1][0], dict(ret)
+    # ---- the checkpoint written by TWO ranks is read by ONE: bucket lengths do not depend on the world size
+    # (worlds dividing 64), so DCP reshards the 1-D DTensors; the lone rank holds rank 0's slice followed by rank 1's
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1")
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        from torch.distributed.device_mesh import init_device_mesh
+        from touchnet_amd.models.llama import DecoderConfig, PackedCausalLM
+        from touchnet_amd.utils.zero_dp import FlatShardedDataParallel
+        cfg = DecoderConfig.from_dict(dict(vocab_size=16, hidden_size=64, intermediate_size=96, num_hidden_layers=2,
+                                           num_attention_heads=8, num_key_value_heads=4, head_dim=8,
+                                           tie_word_embeddings=False))
+        torch.manual_seed(5)
+        mesh = init_device_mesh("cpu", (1,))
+        eng = FlatShardedDataParallel(PackedCausalLM(cfg), mesh)
+        opt = FusedAdamW(eng.named_shards(), lr=1e-3, process_group=mesh.get_group())
+        assert [b.total for b in eng.buckets] == ret[0][1] == ret[1][1]
+        sd = {"optimizer": opt.state_dict()}
+        dcp.load(sd, checkpoint_id=str(tmp_path / "ck3"))
+        opt.load_state_dict(sd["optimizer"])
+        for i, st in enumerate(opt.state):
+            for k in ("master", "m", "v"):
+                assert torch.equal(st[k], torch.cat([ret[0][2][i][k], ret[1][2][i][k]])), (i, k)
+    finally:
+        dist.destroy_process_group()

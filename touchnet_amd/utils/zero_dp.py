@@ -86,7 +86,12 @@ class _Bucket:
         for p in params:
             self.offsets.append(off)
             off += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
-        self.total = (off + world * ALIGN - 1) // (world * ALIGN) * (world * ALIGN)
+        # The padded length does not depend on the world size for every world that divides 64 (else: their least common
+        # multiple): the optimizer state of a bucket is saved as a 1-D DTensor of this length sharded on dim 0, and a
+        # checkpoint written by N ranks can then be resharded by DCP onto M (it was padded to world * ALIGN)
+        import math
+        unit = ALIGN * (64 * world // math.gcd(64, world))
+        self.total = (off + unit - 1) // unit * unit
         self.S = self.total // world
         # gaps between parameters + the tail: staging bytes no gradient ever lands on (kept zero)
         self.gaps = [(o + p.numel(), (self.offsets[i + 1] if i + 1 < len(params) else self.total))
