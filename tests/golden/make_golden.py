@@ -1114,6 +1114,98 @@ def audiofeat_augment_case():
     save("audiofeat_augment.npz", **out)
 
 
+def qwen2_audio_model_dev_case():
+    """The reference's Qwen2-Audio forward (touchnet/models/qwen2_audio/__init__.py:134-249: feature lengths from
+    `feature_attention_mask`, tower, compaction of the valid audio rows, `masked_scatter`, causal language model) RUN on a batch
+    in the reference's own (unpacked, right-padded) format, + the reference loss and every gradient.  transformers 5.x moved
+    Qwen2AudioForConditionalGeneration's submodules (`.model.*`, `.lm_head`); the reference's forward is written against
+    4.51.3's layout (`.audio_tower`, `.multi_modal_projector`, `.language_model` = Qwen2ForCausalLM), so the three HF modules
+    are assembled in that layout in a plain nn.Module and handed to the reference's function as `self` — every statement of
+    the reference's forward and forward_audio_tower executes.  head_dim 64, bf16-representable weights (the `-m gpu` twin)."""
+    from transformers import Qwen2Config, Qwen2ForCausalLM
+    from transformers.models.qwen2_audio.configuration_qwen2_audio import Qwen2AudioConfig, Qwen2AudioEncoderConfig
+    from transformers.models.qwen2_audio.modeling_qwen2_audio import Qwen2AudioEncoder, Qwen2AudioMultiModalProjector
+    ref = R.load_file_as("ref_qwen2_audio_init", "touchnet/models/qwen2_audio/__init__.py")
+    adims = dict(num_mel_bins=16, encoder_layers=2, encoder_attention_heads=2, encoder_ffn_dim=128, d_model=128,
+                 max_source_positions=50)
+    tdims = dict(vocab_size=128, hidden_size=128, intermediate_size=128, num_hidden_layers=2, num_attention_heads=2,
+                 num_key_value_heads=1, head_dim=64, rope_theta=1e6, tie_word_embeddings=False, max_position_embeddings=512,
+                 rms_norm_eps=1e-6)
+    acfg = Qwen2AudioEncoderConfig(**adims, dropout=0.0, attention_dropout=0.0, activation_dropout=0.0)
+    tcfg = Qwen2Config(**tdims)
+    cfg = Qwen2AudioConfig(audio_config=acfg, text_config=tcfg, audio_token_index=120)
+    for c in (acfg, tcfg, cfg):
+        c._attn_implementation = "sdpa"
+    assert cfg.use_return_dict and not cfg.output_attentions and not cfg.output_hidden_states
+
+    class AsTuple(torch.nn.Module):                  # 4.51.3 encoder layers return a tuple, 5.x a tensor
+        def __init__(self, inner):
+            super().__init__()
+            self.inner = inner
+            self.self_attn = inner.self_attn         # (the reference sets `layer.self_attn.is_causal`, :191-192)
+
+        def forward(self, h, mask=None, **kw):
+            return (self.inner(h, mask),)
+
+    class Assembled(torch.nn.Module):                # 4.51.3's attribute layout
+        def __init__(self):
+            super().__init__()
+            self.config = cfg
+            self.audio_tower = Qwen2AudioEncoder(acfg)
+            self.multi_modal_projector = Qwen2AudioMultiModalProjector(cfg)
+            self.language_model = Qwen2ForCausalLM(tcfg)
+
+        def get_input_embeddings(self):
+            return self.language_model.get_input_embeddings()
+    torch.manual_seed(31)
+    model = Assembled().float().train()
+    with torch.no_grad():
+        model.audio_tower.embed_positions.weight.copy_(torch.randn_like(model.audio_tower.embed_positions.weight) * 0.1)
+    _bf16_round_(model)
+    model.audio_tower.layers = torch.nn.ModuleList([AsTuple(l) for l in model.audio_tower.layers])
+    type(model.audio_tower).forward = ref.forward_audio_tower        # (pre_init :261, on this process's class object)
+    assert model.audio_tower.device == torch.device("cpu")
+
+    # a batch as processing_qwen2_audio.py:119-147 yields it: two samples, right-padded; clips of 100 / 61 valid mel frames
+    # in a 100-frame buffer -> 25 / 15 audio tokens
+    g = torch.Generator().manual_seed(32)
+    B, T, Tm = 2, 64, 100
+    frames = torch.tensor([100, 61])
+    n_tok = (((frames - 1) // 2 + 1) - 2) // 2 + 1
+    ids = torch.full((B, T), 0, dtype=torch.int64)
+    attn = torch.zeros(B, T, dtype=torch.int64)
+    labels = torch.full((B, T), -100, dtype=torch.int64)
+    sl = torch.ones(B, T, dtype=torch.int64)
+    for b, (na, n_resp) in enumerate(zip(n_tok.tolist(), (11, 7))):
+        prompt = torch.cat([torch.randint(3, 110, (5,), generator=g), torch.full((na,), 120), torch.randint(3, 110, (4,), generator=g)])
+        resp = torch.randint(3, 110, (n_resp,), generator=g)
+        seq = torch.cat([prompt, resp])
+        n = seq.numel()
+        ids[b, :n], attn[b, :n] = seq, 1
+        lab = torch.cat([torch.full((prompt.numel() - 1,), -100), resp, torch.tensor([2])])          # (:100-101, eos = 2)
+        labels[b, :n] = lab
+        sl[b, :n] = n_resp + 1
+    feats = torch.randn(B, 16, Tm, generator=g).bfloat16().float()
+    fmask = (torch.arange(Tm)[None, :] < frames[:, None]).to(torch.int64)
+    feats = feats * fmask[:, None, :]                                     # the feature extractor pads with zeros
+    batch = {"input_ids": ids, "attention_mask": attn, "labels": labels, "sentence_lens": sl, "num_sentence": 2,
+             "input_features": feats, "feature_attention_mask": fmask}
+    out = ref.forward(model, input_ids=ids, input_features=feats, attention_mask=attn, feature_attention_mask=fmask,
+                      shift_labels=labels)
+    ps, pt = ref_ce(out.logits, labels, sl, batch["num_sentence"])
+    ps.backward()
+    strip = lambda n: n.replace(".inner", "")
+    arrs = {f"param/{strip(n)}": _bits(p) for n, p in model.named_parameters()}
+    arrs.update({f"grad/{strip(n)}": npy(p.grad).astype(np.float16) for n, p in model.named_parameters() if p.grad is not None})
+    for k in ("input_ids", "attention_mask", "labels", "sentence_lens", "input_features", "feature_attention_mask"):
+        arrs[f"batch/{k}"] = npy(batch[k])
+    arrs["batch/num_sentence"] = np.array(2)
+    arrs["logits"] = npy(out.logits)
+    arrs["loss_per_sample"], arrs["loss_per_token"] = npy(ps), npy(pt)
+    arrs["config_json"] = np.array(str({"audio_config": adims, "text_config": tdims, "audio_token_index": 120}))
+    save("qwen2_audio_model_dev.npz", **arrs)
+
+
 def speed_perturb_draws_case():
     """touchnet/data/functions.py:99-114 run here with sox stood in by a recorder (torchaudio is not in this image): WHICH
     speed the reference's stage draws for each of 24 consecutive samples under `random.seed(seed)`, and that it hands
@@ -1151,6 +1243,6 @@ if __name__ == "__main__":
                touch_audio_case, qwen2_audio_tower_case, frontend_cases, fbank_cases, bestrq_cases, touchdataset_case,
                boundary_case, qwen2_audio_data_case, kimi_decoder_case, tiny_llama_dev_case, touch_audio_dev_case,
                qwen2_audio_tower_dev_case, kimi_decoder_dev_case, kimi_audio_input_case,
-               kimi_audio_data_case, audiofeat_augment_case, speed_perturb_draws_case):
+               kimi_audio_data_case, audiofeat_augment_case, speed_perturb_draws_case, qwen2_audio_model_dev_case):
         if not only or fn.__name__ in only:
             fn()

@@ -55,6 +55,21 @@ def _touch_audio(g):
                                  position_ids=b["position_ids"], attention_mask=b["attention_mask"])
 
 
+def _qwen2_audio(g):
+    """The WHOLE Qwen2-Audio model on a batch in the reference's own unpacked format: `feature_attention_mask`, 0/1
+    `attention_mask`, no position ids, no audio index tensors — the keys processing_qwen2_audio.py:119-147 yields."""
+    from touchnet_amd.models.qwen2_audio import Qwen2AudioConfig, Qwen2AudioPackedForConditionalGeneration
+    d = ast.literal_eval(str(g["config_json"]))
+    cfg = Qwen2AudioConfig.from_dict({"audio_config": d["audio_config"], "audio_token_index": d["audio_token_index"],
+                                      "text_config": dict(d["text_config"], model_type="qwen2")})
+    m = Qwen2AudioPackedForConditionalGeneration(cfg)
+    missing, unexpected = m.load_state_dict(_state(g), strict=False)
+    assert not unexpected and not missing, (missing, unexpected)
+    return m, lambda mod, b: mod(input_ids=b["input_ids"], input_features=b["input_features"],
+                                 attention_mask=b["attention_mask"], feature_attention_mask=b["feature_attention_mask"],
+                                 shift_labels=b["labels"])
+
+
 def _compare(m, g, fwd, batch, device, logit_tol, logit_mean_tol, grad_tol, loss_tol):
     data = {k: v.to(device) for k, v in batch.items() if k != "num_sentence"}
     if "input_features" in data and device != "cpu":
@@ -88,7 +103,8 @@ def _compare(m, g, fwd, batch, device, logit_tol, logit_mean_tol, grad_tol, loss
 
 
 # ------------------------------------------------------------------------------------------------ CPU: pins the fixtures
-@pytest.mark.parametrize("name,build", [("tiny_llama_dev.npz", _llama), ("touch_audio_dev.npz", _touch_audio)])
+@pytest.mark.parametrize("name,build", [("tiny_llama_dev.npz", _llama), ("touch_audio_dev.npz", _touch_audio),
+                                        ("qwen2_audio_model_dev.npz", _qwen2_audio)])
 def test_dev_fixture_on_the_oracle_ops(golden, name, build):
     g = golden(name)
     m, fwd = build(g)
@@ -111,7 +127,8 @@ def test_kimi_audio_input_side_on_the_oracle_ops(golden):
 
 # ------------------------------------------------------------------------------------------------ MI355X
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,build", [("tiny_llama_dev.npz", _llama), ("touch_audio_dev.npz", _touch_audio)])
+@pytest.mark.parametrize("name,build", [("tiny_llama_dev.npz", _llama), ("touch_audio_dev.npz", _touch_audio),
+                                        ("qwen2_audio_model_dev.npz", _qwen2_audio)])
 def test_dev_fixture_on_the_device(golden, name, build):
     g = golden(name)
     m, fwd = build(g)

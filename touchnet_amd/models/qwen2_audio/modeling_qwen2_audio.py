@@ -233,7 +233,7 @@ class Qwen2AudioPackedForConditionalGeneration(nn.Module):
                 m.reset_parameters()
 
     def forward(self, input_ids=None, input_features=None, audio_output_lengths=None, audio_positions=None,
-                attention_mask=None, position_ids=None, audio_rows=None, **loss_kwargs):
+                attention_mask=None, position_ids=None, audio_rows=None, feature_attention_mask=None, **loss_kwargs):
         """input_ids [B, T] packed, AUDIO placeholder tokens where audio features go;
         input_features [n_audio, n_mels, Tm]; audio_output_lengths int64 [n_audio] (valid tokens per audio,
         `((L-1)//2+1-2)//2+1`, processing_qwen2_audio.py:79-82); audio_positions int64 [sum(lengths)] flat
@@ -243,6 +243,13 @@ class Qwen2AudioPackedForConditionalGeneration(nn.Module):
         `audio_rows[j]` of the tower's [n * Ta] output rows goes to position `audio_positions[j]`."""
         emb = self.language_model.model.embed_tokens(input_ids)
         B, T, H = emb.shape
+        loss_kwargs.pop("shift_labels", None)                # (a key of the reference batch for its liger path)
+        if feature_attention_mask is not None and audio_output_lengths is None:
+            # the reference's own (unpacked) batch, touchnet/models/qwen2_audio/processing_qwen2_audio.py:119-147: valid mel
+            # frames per clip -> audio tokens per clip (`_get_feat_extract_output_lengths`, __init__.py:184-186); its 0/1
+            # `attention_mask` already reads as document ids here (1 = the row's one document, 0 = padding)
+            frames = feature_attention_mask.sum(-1)
+            audio_output_lengths = (((frames - 1) // 2 + 1) - 2) // 2 + 1
         if input_features is not None:
             if audio_positions is None:                      # (costs a host sync: loaders should supply the positions)
                 audio_positions = (input_ids.reshape(-1) == self.config.audio_token_index).nonzero().squeeze(1)
@@ -266,6 +273,9 @@ class Qwen2AudioPackedForConditionalGeneration(nn.Module):
                 idx = torch.arange(total, device=feats.device)
                 clip = torch.searchsorted(ends, idx, right=True).clamp_(max=n - 1)
                 src = clip * Ta + (idx - (ends - audio_output_lengths)[clip])
+                # more AUDIO tokens than valid feature rows: the reference repeats the LAST valid row (__init__.py:215-219)
+                last = (n - 1) * Ta + audio_output_lengths[-1].to(torch.int64) - 1
+                src = torch.where(idx < ends[-1], src, last)
                 feats = feats.index_select(0, src.clamp_(0, n * Ta - 1))
             if feats.shape[0] != audio_positions.numel():
                 raise ValueError(f"audio features ({feats.shape[0]}) and audio tokens "
