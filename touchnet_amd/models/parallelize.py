@@ -88,18 +88,20 @@ def parallelize_packed(model: nn.Module, world_mesh, parallel_dims, job_config) 
     engine = getattr(job_config, "training_dp_engine", "fsdp2")
     if engine not in ("flat", "fsdp2"):
         raise ValueError(f"training_dp_engine: {engine!r} (flat | fsdp2)")
-    if (parallel_dims.dp_shard_enabled or parallel_dims.cp_enabled) and engine == "flat" and (
-            parallel_dims.tp_enabled or parallel_dims.dp_replicate_enabled):
-        warnings.warn("training_dp_engine=flat covers dp_shard x cp; tensor parallelism / HSDP compose with FSDP2 (used here)")
+    if (parallel_dims.dp_shard_enabled or parallel_dims.cp_enabled) and engine == "flat" and parallel_dims.tp_enabled:
+        warnings.warn("training_dp_engine=flat covers dp_replicate x dp_shard x cp; tensor parallelism composes with FSDP2 "
+                      "(used here)")
         engine = "fsdp2"
     if (parallel_dims.dp_shard_enabled or parallel_dims.cp_enabled) and engine == "flat":
         # utils/zero_dp.py: flat per-block buffers, one reduce-scatter / all-gather per block, optimizer state sharded,
         # bf16 parameters replicated (ZeRO-1).  The model is still on the meta device here (touchnet/bin/train.py:259):
         # it is marked, `build_optimizers_fn` builds the engine once the trainer has materialised the parameters.
         from touchnet_amd.utils.zero_dp import mark_flat_engine
+        # HSDP (dp_replicate > 1): the reduced gradient shards are additionally averaged over the replicas
         mark_flat_engine(model, world_mesh[("dp_shard_cp",)],
                          reduce_dtype=_DTYPES[getattr(job_config, "training_mixed_precision_reduce", "float32")],
-                         param_dtype=_DTYPES[getattr(job_config, "training_mixed_precision_param", "bfloat16")])
+                         param_dtype=_DTYPES[getattr(job_config, "training_mixed_precision_param", "bfloat16")],
+                         replicate_mesh=world_mesh[("dp_replicate",)] if parallel_dims.dp_replicate_enabled else None)
     elif parallel_dims.dp_shard_enabled or parallel_dims.cp_enabled:
         names = ("dp_replicate", "dp_shard_cp") if parallel_dims.dp_replicate_enabled else ("dp_shard_cp",)
         apply_fsdp(model, world_mesh[names],

@@ -115,8 +115,11 @@ class _Bucket:
 
 
 class FlatShardedDataParallel:
-    def __init__(self, model: nn.Module, mesh, reduce_dtype: torch.dtype = torch.float32):
-        """`mesh`: the 1-D device mesh gradients are averaged over (dp, or dp x cp flattened).  Buckets: one per
+    def __init__(self, model: nn.Module, mesh, reduce_dtype: torch.dtype = torch.float32, replicate_mesh=None):
+        """`mesh`: the 1-D device mesh gradients are averaged over (dp, or dp x cp flattened).  `replicate_mesh` (HSDP,
+        the reference's `dp_replicate` dimension, touchnet/utils/distributed.py:139-157): a second 1-D mesh over which
+        whole replicas of the sharded state exist — the reduced gradient shard of a bucket is all-reduced (AVG) over it
+        right behind the reduce-scatter, so every replica's optimizer sees the same shard.  Buckets: one per
         transformer block (models.helper_func.block_groups, the reference's FSDP units) + one per module that owns any of
         the remaining parameters.  Inside a bucket that does take part, a parameter without a gradient counts as a zero
         gradient (torch would skip it; no such parameter exists in the models of this path)."""
@@ -130,12 +133,16 @@ class FlatShardedDataParallel:
         else:
             self.group = mesh.get_group()
             self.world, self.rank = dist.get_world_size(self.group), dist.get_rank(self.group)
+        self.rep_group = None
+        if replicate_mesh is not None and replicate_mesh.size() > 1:
+            self.rep_group = replicate_mesh.get_group()
         self.reduce_dtype = reduce_dtype
         # One rank (TN_FORCE_FSDP=1 on a single GPU): reduce-scatter and all-gather are the identity, so the hooks write
         # straight into the persistent gradient shard and no collective is issued — RCCL would run its generic one-rank
         # kernel instead (oneRankReduce<PreMulSum>, measured 48.5 ms per step for 34 GB: 1.4 TB/s), which says nothing
         # about what a rank pays at N > 1.  TN_DP_FORCE_COLLECTIVES=1 issues them anyway (the 1-rank RCCL test).
-        self.identity = self.world == 1 and os.environ.get("TN_DP_FORCE_COLLECTIVES") != "1"
+        self.identity = (self.world == 1 and self.rep_group is None
+                         and os.environ.get("TN_DP_FORCE_COLLECTIVES") != "1")
         params = [p for p in model.parameters() if p.requires_grad]
         self.device = params[0].device
         self.cuda = self.device.type == "cuda"
@@ -166,6 +173,8 @@ class FlatShardedDataParallel:
         # every replica starts from rank 0's numbers (the seeds agree already; this makes it unconditional)
         for b in self.buckets:
             if not self.emulated:
+                if self.rep_group is not None:           # (replica 0's shard-rank-0 numbers reach everybody)
+                    dist.broadcast(b.flat_p, src=dist.get_global_rank(self.rep_group, 0), group=self.rep_group)
                 dist.broadcast(b.flat_p, src=dist.get_global_rank(self.group, 0), group=self.group)
         self.comm = torch.cuda.Stream(device=self.device) if self.cuda else None
         self._pool, self._pool_free_at = [], []          # staging buffers + the event after which each is reusable
@@ -286,6 +295,8 @@ class FlatShardedDataParallel:
                     b.gshard.copy_(b.stage[self.rank * b.S:(self.rank + 1) * b.S])
                 else:
                     dist.reduce_scatter_tensor(b.gshard, b.stage, op=self.avg, group=self.group)
+                    if self.rep_group is not None:
+                        dist.all_reduce(b.gshard, op=self.avg, group=self.rep_group)
                 b.reduced = torch.cuda.Event()
                 b.reduced.record()
             if b not in self.rest:
@@ -295,6 +306,8 @@ class FlatShardedDataParallel:
                 b.gshard.copy_(b.stage[self.rank * b.S:(self.rank + 1) * b.S])
             else:
                 dist.reduce_scatter_tensor(b.gshard, b.stage, op=self.avg, group=self.group)
+                if self.rep_group is not None:
+                    dist.all_reduce(b.gshard, op=self.avg, group=self.rep_group)
             if b not in self.rest:
                 self._pool_free_at[b._slot] = None
         b.launched = True
@@ -378,8 +391,10 @@ class FlatShardedDataParallel:
 # trainer's own clip_grad_norm_ computes 0 and scales nothing; norm, clip and the skip on a non-finite norm happen on
 # the device inside `step()` (utils/optimizer.FusedAdamW), whose result is kept in `last_grad_norm`.
 # ---------------------------------------------------------------------------------------------------------------------
-def mark_flat_engine(model: nn.Module, mesh, reduce_dtype: torch.dtype, param_dtype: torch.dtype) -> None:
-    model._tn_flat_dp = {"mesh": mesh, "reduce_dtype": reduce_dtype, "param_dtype": param_dtype}
+def mark_flat_engine(model: nn.Module, mesh, reduce_dtype: torch.dtype, param_dtype: torch.dtype,
+                     replicate_mesh=None) -> None:
+    model._tn_flat_dp = {"mesh": mesh, "reduce_dtype": reduce_dtype, "param_dtype": param_dtype,
+                         "replicate_mesh": replicate_mesh}
 
 
 class FlatEngineOptimizer:
@@ -427,7 +442,8 @@ def build_flat_engine_optimizer(model: nn.Module, make_optimizer):
             if p.requires_grad and p.is_floating_point() and p.dtype != pdt:
                 keep[id(p)] = p.data
                 p.data = p.data.to(pdt)
-    engine = FlatShardedDataParallel(model, mark["mesh"], reduce_dtype=mark["reduce_dtype"])
+    engine = FlatShardedDataParallel(model, mark["mesh"], reduce_dtype=mark["reduce_dtype"],
+                                     replicate_mesh=mark.get("replicate_mesh"))
     inner = make_optimizer(engine.named_shards(), mark["mesh"].get_group())
     masters = getattr(inner, "state", None)
     if keep and isinstance(masters, list) and len(masters) == len(engine.buckets):
