@@ -603,6 +603,78 @@ def test_tensor_parallel_two_ranks_equals_single_process(mode):
         assert results[r][3] == 4 * 10 + (1 if mode == "loss_parallel" else 0)
 
 
+def _tied_tp_worker(rank, world, port, ref_state, ref_loss, ref_grads, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    try:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import oracle.ops as oops
+        from torch.distributed.device_mesh import init_device_mesh
+        from touchnet_amd.data.synthetic import text_batch
+        from touchnet_amd.models.backend import use_ops
+        from touchnet_amd.models.llama import DecoderConfig, PackedCausalLM
+        from touchnet_amd.models.parallelize import parallelize_packed
+        from touchnet_amd.models.tensor_parallel import reduce_sequence_partial_grads
+        from touchnet_amd.utils.distributed import ParallelDims
+        mesh = init_device_mesh("cpu", (world,), mesh_dim_names=("tp",))
+        model = PackedCausalLM(DecoderConfig.from_dict(TINY))
+        model.load_state_dict(ref_state)
+        assert model.lm_head.weight is model.model.embed_tokens.weight
+        job = types.SimpleNamespace(training_activation_checkpoint_mode="none", training_compile=False,
+                                    training_enable_cpu_offload=False, training_tp_sequence_parallel=True)
+        model = parallelize_packed(model, mesh, ParallelDims(1, 1, 1, world, 1, world, True), job)
+        w = model.lm_head.weight
+        assert w is model.model.embed_tokens.weight and w.shape[0] == TINY["vocab_size"] // world      # still ONE weight
+        b = text_batch(16, 2, 32, seed=5, max_len=9)
+        with use_ops(oops):
+            out = model(input_ids=b["input_ids"], position_ids=b["position_ids"], attention_mask=b["attention_mask"],
+                        labels=b["labels"], sentence_lens=b["sentence_lens"], num_sentence=b["num_sentence"])
+            out.loss.backward()
+        reduce_sequence_partial_grads(model)
+        assert float(out.loss) == pytest.approx(ref_loss, rel=1e-5)
+        worst = 0.0
+        for n, p in model.named_parameters():
+            ref = ref_grads[n]
+            if n in model._tn_tp["sharded_names"]:
+                ref = ref.chunk(world, dim=1 if ("o_proj" in n or "down_proj" in n) else 0)[rank]
+            worst = max(worst, float((p.grad - ref).abs().max()))
+        assert "model.embed_tokens.weight" in model._tn_tp["sharded_names"] and worst < 2e-5, worst
+        ret[rank] = ("ok", worst)
+    except Exception as e:
+        import traceback
+        ret[rank] = ("fail", traceback.format_exc(), repr(e))
+    finally:
+        if dist.is_initialized():
+            dist.barrier()
+            dist.destroy_process_group()
+
+
+def test_tensor_parallel_with_tied_embeddings_and_loss_parallel():
+    """Llama-3.2-1B / the reference's tiny test config tie lm_head to the embedding; with loss parallel the ONE weight is
+    vocabulary-sharded and the embedding becomes vocabulary-parallel (the reference's RowwiseParallel on the embedding,
+    parallelize_llama.py:133-141): loss and every gradient — the tied weight's rows included, embedding + head
+    contributions — equal the single-process ones on 2 gloo ranks."""
+    import oracle.ops as oops
+    from touchnet_amd.data.synthetic import text_batch
+    from touchnet_amd.models.backend import use_ops
+    from touchnet_amd.models.llama import DecoderConfig, PackedCausalLM
+    torch.manual_seed(9)
+    ref = PackedCausalLM(DecoderConfig.from_dict(TINY))
+    ref.post_init()
+    b = text_batch(16, 2, 32, seed=5, max_len=9)
+    with use_ops(oops):
+        out = ref(input_ids=b["input_ids"], position_ids=b["position_ids"], attention_mask=b["attention_mask"],
+                  labels=b["labels"], sentence_lens=b["sentence_lens"], num_sentence=b["num_sentence"])
+        out.loss.backward()
+    state = {k: v.detach().clone() for k, v in ref.state_dict().items()}
+    grads = {n: p.grad.clone() for n, p in ref.named_parameters()}
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_tied_tp_worker, args=(2, _free_port(), state, float(out.loss), grads, ret), nprocs=2, join=True)
+        results = dict(ret)
+    for r in range(2):
+        assert results[r][0] == "ok", results[r][1]
+
+
 def _group_mesh_worker(rank, world, port, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     try:

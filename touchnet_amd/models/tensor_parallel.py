@@ -209,6 +209,17 @@ def _wrap(module: nn.Module, group, sequence_parallel: bool = False) -> None:
     module.forward = forward
 
 
+def _vocab_parallel(emb: nn.Embedding, group, rank: int) -> None:
+    def forward(ids):
+        vp = emb.weight.shape[0]
+        local = ids - rank * vp
+        outside = (local < 0) | (local >= vp)
+        out = torch.nn.functional.embedding(local.clamp(0, vp - 1), emb.weight)
+        out = out.masked_fill(outside.unsqueeze(-1), 0)
+        return _ReduceFromTP.apply(out, group)              # forward: sum over tp; backward: every rank keeps the gradient
+    emb.forward = forward
+
+
 def _decoder_stacks(model: nn.Module):
     """the modules that own an embedding -> layers -> final norm loop (DecoderModel / KimiDecoderModel)"""
     lm = getattr(model, "language_model", model)
@@ -218,10 +229,10 @@ def _decoder_stacks(model: nn.Module):
 def apply_tp(model: nn.Module, tp_mesh, loss_parallel: bool = False, sequence_parallel: bool = False) -> nn.Module:
     group, tp, rank = tp_mesh.get_group(), tp_mesh.size(), tp_mesh.get_local_rank()
     lm = getattr(model, "language_model", model)
+    tied = bool(getattr(lm.config, "tie_word_embeddings", False)) and hasattr(lm, "lm_head") and any(
+        getattr(st, "embed_tokens", None) is not None and st.embed_tokens.weight is lm.lm_head.weight
+        for st in _decoder_stacks(model))
     if loss_parallel:
-        if getattr(lm.config, "tie_word_embeddings", False):
-            raise NotImplementedError("loss parallel with tied embeddings: the embedding would have to be vocabulary-"
-                                      "parallel as well")
         if lm.lm_head.weight.shape[0] % tp:
             raise ValueError(f"vocabulary {lm.lm_head.weight.shape[0]} is not divisible by tp = {tp}")
         if not sequence_parallel:
@@ -260,12 +271,57 @@ def apply_tp(model: nn.Module, tp_mesh, loss_parallel: bool = False, sequence_pa
         lm.lm_head.weight = _shard(lm.lm_head.weight, 0, rank, tp)
         sharded.append(lm.lm_head.weight)
         lm._tn_loss_parallel = (group, rank, tp)
+        if tied:
+            # Tied embeddings (Llama-3.2-1B, the reference's tiny test config): the ONE weight is vocabulary-sharded, so the
+            # embedding becomes vocabulary-parallel as in the reference's plan (RowwiseParallel on `tok_embeddings`,
+            # parallelize_llama.py:133-141): every rank looks up the ids of its own V/tp rows, the other rows are zero,
+            # the sum over the tp ranks is the embedding.  (The sum is an all-reduce here, the sequence-parallel scatter
+            # follows as for a replicated embedding: callers that add audio rows to the embedding output see a full tensor.)
+            for st in _decoder_stacks(model):
+                emb = st.embed_tokens
+                emb.weight = lm.lm_head.weight
+                emb.num_embeddings = emb.weight.shape[0]
+                _vocab_parallel(emb, group, rank)
     ids, pids = {id(p) for p in sharded}, {id(p) for p in seq_partial}
     model._tn_tp = {"group": group, "size": tp, "rank": rank, "sequence_parallel": sequence_parallel,
                     "loss_parallel": loss_parallel,
                     "sharded_names": {n for n, p in model.named_parameters() if id(p) in ids},
                     "seq_partial_names": {n for n, p in model.named_parameters() if id(p) in pids}}
+    _checkpoint_view(model, tp_mesh)
     return model
+
+
+def _row_parallel(name: str) -> bool:
+    return "o_proj" in name or "down_proj" in name
+
+
+def _checkpoint_view(model: nn.Module, tp_mesh) -> None:
+    """`state_dict()` hands the tensor-parallel shards out as DTensors on the tp mesh (Shard(1) for the row-parallel
+    o_proj / down_proj weights, Shard(0) for everything else that is sharded), sharing storage with the parameters — what
+    the reference's DTensor-based plan gives torch.distributed.checkpoint: an unsharded checkpoint loads into the shards,
+    a sharded one reloads anywhere (the reference's tests/touchnet/models/test_llama.py).  Only for a real DeviceMesh and
+    plain (not FSDP2-wrapped) parameters: under tp x FSDP2 the dim-0 shards would need a strided 2-D placement."""
+    try:
+        from torch.distributed.device_mesh import DeviceMesh
+        from torch.distributed.tensor import DTensor, Shard
+    except Exception:                                        # pragma: no cover
+        return
+    if not isinstance(tp_mesh, DeviceMesh):
+        return
+
+    def hook(module, state_dict, prefix, local_metadata):
+        names = module._tn_tp["sharded_names"]
+        params = dict(module.named_parameters(remove_duplicate=False))
+        shared = {id(params[n]) for n in names if n in params}
+        for key in list(state_dict.keys()):
+            n = key[len(prefix):]
+            p = params.get(n)
+            t = state_dict[key]
+            if p is None or id(p) not in shared or isinstance(t, DTensor) or not isinstance(t, torch.Tensor) or t.is_meta:
+                continue
+            state_dict[key] = DTensor.from_local(t, tp_mesh, [Shard(1 if _row_parallel(n) else 0)], run_check=False)
+        return state_dict
+    model._register_state_dict_hook(hook)
 
 
 @torch.no_grad()
