@@ -3,8 +3,8 @@ model under each (dp, cp, tp) mesh of the reference's parametrisation, the ranks
 into their shards and save it back sharded, one process reloads the sharded checkpoint — and gives the logits of the model
 the first checkpoint was written from (abs 1e-6; same batch shape: 8 x 8 random ids, plain positions).  Same tiny
 configuration as the reference's tests/assets/config/tiny_llama.json (d = 64); the CPU runs the oracle op set behind the
-product modules, the sharding machinery (ParallelDims mesh, tensor-parallel plan, FSDP2 over dp_shard x cp, DTensor state
-dicts) is the product's."""
+product modules, the sharding machinery (ParallelDims mesh, tensor-parallel plan incl. the vocabulary-parallel tied embedding,
+FSDP2 over dp_shard x cp, the DTensor state_dict views of the tp shards — strided 2-D under tp x FSDP2) is the product's."""
 import os
 import socket
 
@@ -71,15 +71,8 @@ def _tiny_eval(rank, world, port, dims_kw, folder, shard_folder, ret):
         dist.destroy_process_group()
 
 
-_TP_FSDP_GAP = pytest.mark.xfail(strict=True, reason=(
-    "tp x FSDP2: the tensor-parallel shards are plain local tensors (models/tensor_parallel.py) that FSDP2 then shards over "
-    "dp — a column-parallel weight is split on dim 0 TWICE, tp-major, which needs a strided 2-D DTensor placement to be "
-    "described to torch.distributed.checkpoint; the state_dict view exists for tp alone (first case).  Checkpointing is "
-    "outside the hot path (SURVEY 2.1); stated as a gap in DESIGN.md"))
-
-
 @pytest.mark.parametrize("world,dp,cp,tp", [(2, 1, 1, 2), (8, 8, 1, 1), (8, 2, 4, 1), (8, 4, 2, 1),
-                                           pytest.param(8, 2, 2, 2, marks=_TP_FSDP_GAP)])
+                                           (8, 2, 2, 2)])
 def test_llama_reshards_through_parallelize_fn(tmp_path, world, dp, cp, tp):
     import oracle.ops as oops
     from touchnet_amd.models.backend import use_ops

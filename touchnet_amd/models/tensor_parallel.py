@@ -309,17 +309,55 @@ def _checkpoint_view(model: nn.Module, tp_mesh) -> None:
     if not isinstance(tp_mesh, DeviceMesh):
         return
 
+    tp = tp_mesh.size()
+    cache = {}
+
+    def spmd_mesh(dp_mesh):
+        """the 2-D (dp, tp) mesh a tp shard that FSDP2 sharded again lives on: rows = this tp column's dp ranks"""
+        key = tuple(dp_mesh.mesh_dim_names or ())
+        if key not in cache:
+            root = tp_mesh._get_root_mesh() if hasattr(tp_mesh, "_get_root_mesh") else None
+            try:
+                cache[key] = root[key + ("tp",)]
+            except Exception:
+                cache[key] = None
+        return cache[key]
+
     def hook(module, state_dict, prefix, local_metadata):
         names = module._tn_tp["sharded_names"]
-        params = dict(module.named_parameters(remove_duplicate=False))
+        plain = lambda n: n.replace("_checkpoint_wrapped_module.", "")
+        params = {plain(n): p for n, p in module.named_parameters(remove_duplicate=False)}
         shared = {id(params[n]) for n in names if n in params}
         for key in list(state_dict.keys()):
-            n = key[len(prefix):]
+            n = plain(key[len(prefix):])
             p = params.get(n)
             t = state_dict[key]
-            if p is None or id(p) not in shared or isinstance(t, DTensor) or not isinstance(t, torch.Tensor) or t.is_meta:
+            if p is None or id(p) not in shared or not isinstance(t, torch.Tensor) or t.is_meta:
                 continue
-            state_dict[key] = DTensor.from_local(t, tp_mesh, [Shard(1 if _row_parallel(n) else 0)], run_check=False)
+            row = _row_parallel(n)
+            if not isinstance(t, DTensor):
+                state_dict[key] = DTensor.from_local(t, tp_mesh, [Shard(1 if row else 0)], run_check=False)
+                continue
+            # tp x FSDP2: FSDP2 sharded the tp-local tensor on dim 0 over its own (dp) mesh.  A row-parallel weight is
+            # then Shard(0) over dp x Shard(1) over tp; a column-parallel one is split on dim 0 TWICE, tp-major — torch's
+            # FSDP + TP convention for that is a strided shard on the dp dimension
+            if len(t.placements) != 1 or not t.placements[0].is_shard(0) or t.shape[0] % t.device_mesh.size():
+                continue
+            mesh2d = spmd_mesh(t.device_mesh)
+            if mesh2d is None:
+                continue
+            try:
+                from torch.distributed.tensor.placement_types import _StridedShard
+            except Exception:                                # pragma: no cover
+                continue
+            shape = list(t.shape)
+            shape[1 if row else 0] *= tp
+            placements = [Shard(0), Shard(1)] if row else [_StridedShard(0, split_factor=tp), Shard(0)]
+            stride = [1] * len(shape)
+            for d in range(len(shape) - 2, -1, -1):
+                stride[d] = stride[d + 1] * shape[d + 1]
+            state_dict[key] = DTensor.from_local(t.to_local(), mesh2d, placements, run_check=False,
+                                                 shape=torch.Size(shape), stride=tuple(stride))
         return state_dict
     model._register_state_dict_hook(hook)
 
