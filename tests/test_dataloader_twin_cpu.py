@@ -1,6 +1,6 @@
 """Twin of the reference's tests/touchnet/data/test_dataloader.py:37-118 for the product's LowLevelTouchDatapipe: fake
-`texttoken` shards (one per rank of nnodes x nproc_per_node, `max_epoch` one-token documents each, written here in the
-reference's .idx / .bin format), sharded over dp ranks, then over dataloader workers, with a mid-epoch resume.
+`texttoken` shards (one per rank of nnodes x nproc_per_node, `max_epoch` one-token documents each, written with the
+product's DataBuilder twin, touchnet_amd/data/builder.py), sharded over dp ranks, then over dataloader workers, with a mid-epoch resume.
   * num_workers = 0: the datapipe itself, broken at `break_point` and resumed from its own state_dict — the state the
     loader persists; as in the reference, the sample in flight at the break is yielded again (the counter moves behind the
     yield).
@@ -9,7 +9,6 @@ reference's .idx / .bin format), sharded over dp ranks, then over dataloader wor
     (Its three one-worker resume cases snapshot worker state through torchdata's StatefulDataLoader, which is not in
     this image; the product's own loader runs the datapipe on a thread of the trainer process, tests/test_boundary.py.)"""
 import os
-import struct
 import types
 
 import numpy as np
@@ -20,19 +19,14 @@ from touchnet_amd.data.datapipe import LowLevelTouchDatapipe
 
 
 def _write_texttoken_shard(prefix, docs):
-    """.idx := magic | u64 version | u8 dtype code (8 = uint16) | u64 N | u64 M | i32 len[N] | i64 ptr[N] | i64 doc[M]"""
+    """build_fake_data of the reference's test (:13-33) with the product's DataBuilder: one-sentence documents"""
+    from touchnet_amd.data.builder import DataBuilder
     os.makedirs(prefix, exist_ok=True)
-    seqs = [np.asarray(d, dtype=np.uint16) for d in docs]
-    with open(f"{prefix}/texttoken.bin", "wb") as f:
-        for s in seqs:
-            f.write(s.tobytes())
-    lens = np.array([len(s) for s in seqs], dtype="<i4")
-    ptrs = np.concatenate([[0], np.cumsum(lens[:-1].astype(np.int64) * 2)]).astype("<i8")
-    doc_idx = np.arange(len(seqs) + 1, dtype="<i8")
-    with open(f"{prefix}/texttoken.idx", "wb") as f:
-        f.write(b"MMIDIDX\x00\x00" + struct.pack("<Q", 1) + struct.pack("<B", 8))
-        f.write(struct.pack("<Q", len(seqs)) + struct.pack("<Q", len(doc_idx)))
-        f.write(lens.tobytes() + ptrs.tobytes() + doc_idx.tobytes())
+    b = DataBuilder(f"{prefix}/texttoken.bin", np.uint16)
+    for d in docs:
+        b.add_item(torch.IntTensor(d))
+        b.end_document()
+    b.finalize(f"{prefix}/texttoken.idx")
 
 
 def _fake_data(root, nnodes, nproc_per_node, max_epoch):

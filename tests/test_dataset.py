@@ -58,6 +58,51 @@ def test_fixture_md5_equals_reference_test_constants():
         assert got == want, layout
 
 
+def _layout_md5(root):
+    sums = []
+    for dirpath, _, files in os.walk(root):
+        for f in files:
+            if f.endswith((".idx", ".bin")):
+                p = os.path.join(dirpath, f)
+                sums.append((hashlib.md5(open(p, "rb").read()).hexdigest(), p))
+    lines = sorted(f"{h}  {p}" for h, p in sums)
+    return hashlib.md5("".join(ln.split(" ")[0] + "\n" for ln in lines).encode()).hexdigest()
+
+
+def test_writer_reproduces_the_reference_tests_md5_constants(tmp_path):
+    """touchnet_amd/data/builder.py (the role of make_data.py's DataBuilder + IndexWriter): the two reference test
+    utterances — read back from the fixture shards with the product reader — written again with the product writer, one
+    and two per shard, give the md5s the reference's own test pins (tests/touchnet/bin/test_make_data.py:25-28), and every
+    file equals the fixture's byte for byte."""
+    import json
+    from touchnet_amd.data.builder import DataBuilder, write_audio_shards
+    from touchnet_amd.data.dataset import TouchDataset
+    samples = []
+    for shard in ("000000000", "000000001"):
+        ds = TouchDataset(os.path.join(ROOT, "1sample_per_shard", shard), True, "audio+metainfo")
+        meta = json.loads(ds.get(0, "metainfo").tobytes().decode("utf-8"))
+        assert meta.pop("sample_rate") == 16000
+        samples.append((meta, np.array(ds.get(0, "audio"))))
+    expect = {1: "05fe272d67459992748bbf5720c5a92e", 2: "93245372eca0dce2013c1e5bd393f17f"}
+    for per, want in expect.items():
+        out = str(tmp_path / f"{per}sample_per_shard")
+        shards = write_audio_shards(samples, out, per)
+        assert _layout_md5(out) == want
+        for d in shards:
+            for f in os.listdir(d):
+                ref = os.path.join(ROOT, f"{per}sample_per_shard", os.path.basename(d), f)
+                assert open(os.path.join(d, f), "rb").read() == open(ref, "rb").read(), (per, d, f)
+    # add_document: several sequences of one document in one call, read back by the product reader
+    b = DataBuilder(str(tmp_path / "texttoken.bin"), np.uint16)
+    b.add_document(np.arange(7), [3, 4])
+    b.add_item(np.array([9, 8]))
+    b.end_document()
+    b.finalize(str(tmp_path / "texttoken.idx"))
+    ds = TouchDataset(str(tmp_path), True, "texttoken")
+    assert len(ds) == 3 and ds.get(1, "texttoken").tolist() == [3, 4, 5, 6] and ds.get(2, "texttoken").tolist() == [9, 8]
+    assert ds.index["texttoken"].document_indices.tolist() == [0, 2, 3]
+
+
 def test_reader_random_access(golden):
     g = golden("touchdataset.npz")
     ds = TouchDataset(TWO[0], True, "audio+metainfo")
