@@ -96,6 +96,46 @@ def asr_cases():
     save("packing_asr.npz", **out)
 
 
+def unpacked_asr_cases():
+    """processing_touch_audio.py:217-428 run here: the two UNPACKED batchers (`batch_pairaudio_pairtext`, `batch_audio`) on
+    seeded streams with a sample that is too long in the middle (it still moves the running maximum of the flush rule),
+    drop_last on and off; `batch_audio` with a stand-in for the BEST-RQ tokenizer's `tokenize`."""
+    from touchnet.models.touch_audio.processing_touch_audio import batch_audio as ref_batch_audio
+    from touchnet.models.touch_audio.processing_touch_audio import batch_pairaudio_pairtext as ref_batch_pairs
+    rng = np.random.RandomState(11)
+    F = 5
+    out = {}
+
+    class Codes:
+        def tokenize(self, feat):
+            return [int(v) for v in (feat.sum(1) * 7.0).abs().long() % 50]
+    for name, (B, T, drop, n) in {"mixed": (2, 24, False, 15), "droplast": (3, 20, True, 11), "tight": (1, 16, False, 9)}.items():
+        alens = [int(x) for x in rng.randint(2, 13, size=n)]
+        tlens = [int(x) for x in rng.randint(1, 6, size=n)]
+        alens[4] = T + 9                      # longer than a row: skipped, but widens the running maximum
+        feats = [rng.randn(a, F).astype(np.float32) for a in alens]
+        ids = [[int(v) for v in rng.randint(3, 16, size=t)] for t in tlens]
+        cfg = types.SimpleNamespace(dataset_batchsize=B, dataset_text_seqlen=T, dataset_audio_seqlen=T,
+                                    dataloader_drop_last_batch=drop)
+        out[f"{name}/meta"] = np.array([B, T, int(drop), F])
+        out[f"{name}/alens"], out[f"{name}/tlens"] = np.array(alens), np.array(tlens)
+        out[f"{name}/feats"] = np.concatenate(feats, axis=0)
+        out[f"{name}/tokens"] = np.concatenate([np.array(s) for s in ids])
+        for kind, fn, tok in (("pairs", ref_batch_pairs, TOK), ("audio", ref_batch_audio, Codes())):
+            data = ({"audiofeat": torch.from_numpy(f), "input_ids": i} for f, i in zip(feats, ids))
+            batches = list(fn(data, cfg, tok))
+            out[f"{name}/{kind}/n"] = np.array(len(batches))
+            for i, b in enumerate(batches):
+                for k, v in b.items():
+                    if k == "num_sentence":
+                        out[f"{name}/{kind}/b{i}/{k}"] = np.array(v)
+                    elif v is None:
+                        out[f"{name}/{kind}/b{i}/{k}/none"] = np.array(1)
+                    else:
+                        out[f"{name}/{kind}/b{i}/{k}"] = npy(v)
+    save("unpacked_asr.npz", **out)
+
+
 # ------------------------------------------------------------------ loss
 def ce_cases():
     out = {}
@@ -1239,7 +1279,7 @@ def speed_perturb_draws_case():
 
 if __name__ == "__main__":
     only = set(sys.argv[1:])
-    for fn in (text_cases, asr_cases, ce_cases, docmask_cases, rope_cases, tiny_llama_case,
+    for fn in (text_cases, asr_cases, unpacked_asr_cases, ce_cases, docmask_cases, rope_cases, tiny_llama_case,
                touch_audio_case, qwen2_audio_tower_case, frontend_cases, fbank_cases, bestrq_cases, touchdataset_case,
                boundary_case, qwen2_audio_data_case, kimi_decoder_case, tiny_llama_dev_case, touch_audio_dev_case,
                qwen2_audio_tower_dev_case, kimi_decoder_dev_case, kimi_audio_input_case,

@@ -57,6 +57,41 @@ def test_batch_asr(golden, case):
         assert b["shift_labels"] is b["labels"]
 
 
+@pytest.mark.parametrize("case", ["mixed", "droplast", "tight"])
+def test_unpacked_touch_audio_batchers_equal_the_reference(golden, case):
+    """`batch_pairaudio_pairtext` / `batch_audio` (processing_touch_audio.py:217-428, `--dataset_enable_pack false`): batch
+    boundaries (the flush rule with its running maximum, which a skipped over-long sample still moves), padding values and
+    every tensor equal the reference run; keys the reference leaves `None` are `None`."""
+    import types
+    from touchnet_amd.models.touch_audio.processing_touch_audio import batch_audio, batch_pairaudio_pairtext
+    g = golden("unpacked_asr.npz")
+    B, T, drop, F = [int(v) for v in g[f"{case}/meta"]]
+    alens, tlens = g[f"{case}/alens"], g[f"{case}/tlens"]
+    feats = np.split(g[f"{case}/feats"], np.cumsum(alens)[:-1])
+    ids = [[int(v) for v in t] for t in np.split(g[f"{case}/tokens"], np.cumsum(tlens)[:-1])]
+    cfg = types.SimpleNamespace(dataset_batchsize=B, dataset_text_seqlen=T, dataset_audio_seqlen=T,
+                                dataloader_drop_last_batch=bool(drop))
+
+    class Codes:
+        def tokenize(self, feat):
+            return [int(v) for v in (feat.sum(1) * 7.0).abs().long() % 50]
+    for kind, fn, tok in (("pairs", batch_pairaudio_pairtext, TOK), ("audio", batch_audio, Codes())):
+        data = ({"audiofeat": torch.from_numpy(f.copy()), "input_ids": i} for f, i in zip(feats, ids))
+        batches = list(fn(data, cfg, tok))
+        assert len(batches) == int(g[f"{case}/{kind}/n"]) and len(batches) >= 1, (kind, len(batches))
+        for i, b in enumerate(batches):
+            for k in ("input_ids", "input_features", "labels", "shift_labels", "position_ids", "attention_mask",
+                      "sentence_lens", "num_sentence"):
+                key = f"{case}/{kind}/b{i}/{k}"
+                if key + "/none" in g.files:
+                    assert b[k] is None, (kind, i, k)
+                elif k == "num_sentence":
+                    assert int(b[k]) == int(g[key])
+                else:
+                    got = b[k].numpy()
+                    assert got.dtype == g[key].dtype and np.array_equal(got, g[key]), (kind, i, k)
+
+
 def test_empty_input_yields_nothing():
     cfg = types.SimpleNamespace(dataset_batchsize=2, dataset_text_seqlen=8, dataloader_drop_last_batch=False)
     assert list(batch_text(iter([]), cfg, TOK)) == []

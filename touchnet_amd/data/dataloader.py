@@ -192,9 +192,13 @@ def build_datapipe(cfg, tokenizer, dp_rank: int, dp_world_size: int):
             pipe = stage(functions.audiofeat_augment, cfg)
         pipe = stage(functions.audiofeat_stack, cfg)
         if labels_from_audio:
+            if not cfg.dataset_enable_pack:
+                from touchnet_amd.models.touch_audio.processing_touch_audio import batch_audio
+                return stage(batch_audio, cfg, tokenizer)
             return stage(batch_audio_packed, cfg, tokenizer)
-        if not cfg.dataset_enable_pack:
-            raise NotImplementedError("the MI355X path trains on PACKED batches (dataset_enable_pack=True)")
+        if not cfg.dataset_enable_pack:                   # one sample per row, right-padded (processing_touch_audio.py:485-487)
+            from touchnet_amd.models.touch_audio.processing_touch_audio import batch_pairaudio_pairtext
+            return stage(batch_pairaudio_pairtext, cfg, tokenizer)
         return stage(batch_pairaudio_pairtext_packed, cfg, tokenizer)
     if kind == "qwen2_audio":
         from touchnet_amd.models.qwen2_audio.processing_qwen2_audio import batch_qwen2_audio_packed

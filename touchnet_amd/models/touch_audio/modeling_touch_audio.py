@@ -55,6 +55,13 @@ class TouchAudioForCausalLM(nn.Module):
 
     def forward(self, input_ids=None, input_features=None, attention_mask=None, position_ids=None,
                 inputs_embeds=None, **loss_kwargs):   # loss_kwargs: labels / sentence_lens / num_sentence / context_parallel
+        loss_kwargs.pop("shift_labels", None)                                   # (a key of the reference's batches)
+        if inputs_embeds is None and input_ids is None and input_features is not None:
+            # audio pretraining from the UNPACKED batcher (`batch_audio`, processing_touch_audio.py:260): no token ids at
+            # all — the frames alone are the input (the reference's forward has no branch for it)
+            B, T, _ = input_features.shape
+            w = self.projector.weight
+            inputs_embeds = (input_features.to(w.dtype).reshape(B * T, -1) @ w.t()).view(B, T, -1)
         if inputs_embeds is None:
             emb = self.language_model.model.embed_tokens(input_ids)             # [B, T, H]
             B, T, H = emb.shape

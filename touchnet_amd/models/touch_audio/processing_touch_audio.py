@@ -133,3 +133,102 @@ def batch_audio_packed(data, config, tokenizer):
         codes.append(cd.to(torch.int64))
     if (not config.dataloader_drop_last_batch) and buf.dirty:
         yield _emit_audio(buf, feats, codes, F)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The UNPACKED forms (`--dataset_enable_pack false`): one sample per row, rows right-padded to the longest of the batch,
+# dynamic batch size.  processing_touch_audio.py:217-306 (`batch_audio`) and :309-428 (`batch_pairaudio_pairtext`).
+# The flush rule is the reference's, including its order of operations: the running maximum is updated BEFORE a sample
+# that is too long is skipped (such a sample still widens the budget test until the next flush), a flush happens when
+# (samples held + 1) x running maximum exceeds batchsize x seqlen, the new sample opens the next batch.
+# ---------------------------------------------------------------------------------------------------------------------
+class _DynamicRows:
+    def __init__(self, budget: int, limit: int):
+        self.budget, self.limit, self.longest, self.rows = int(budget), int(limit), 0, []
+
+    def offer(self, length: int, row):
+        """-> the rows to emit now (or None); `row` joins the batch that is open afterwards.  `row = None`: only the
+        running maximum moves (a skipped sample)."""
+        self.longest = max(self.longest, length)
+        if length > self.limit or row is None:
+            return None
+        out = None
+        if (len(self.rows) + 1) * self.longest > self.budget:
+            out, self.rows, self.longest = self.rows, [], length
+        self.rows.append(row)
+        return out
+
+
+def _pad_rows(seqs, value, dtype):
+    n = max(len(s) for s in seqs)
+    out = np.full((len(seqs), n), value, dtype=dtype)
+    for i, s in enumerate(seqs):
+        out[i, :len(s)] = s
+    return torch.from_numpy(out)
+
+
+def _pad_feats(feats):
+    n, dim, dev = max(f.shape[0] for f in feats), feats[0].shape[1], feats[0].device
+    out = torch.zeros(len(feats), n, dim, dtype=torch.float32, device=dev)     # a device-side frontend keeps features in HBM
+    for i, f in enumerate(feats):
+        out[i, :f.shape[0]] = f
+    return out
+
+
+def _emit_pairs(rows, pad):
+    labels = _pad_rows([r["labels"] for r in rows], -100, np.int64)
+    return {"input_ids": _pad_rows([r["input_ids"] for r in rows], pad, np.int64),
+            "input_features": _pad_feats([r["feats"] for r in rows]),
+            "labels": labels, "shift_labels": labels, "position_ids": None,
+            "attention_mask": _pad_rows([np.ones(len(r["labels"]), np.int64) for r in rows], 0, np.int64),
+            "sentence_lens": _pad_rows([np.full(len(r["labels"]), r["slen"], np.int64) for r in rows], 1, np.int64),
+            "num_sentence": len(rows),
+            "labelled_rows_max": int(sum(r["slen"] + 1 for r in rows))}
+
+
+def batch_pairaudio_pairtext(data, config, tokenizer):
+    """processing_touch_audio.py:309-428.  Row = `audio_len` feature frames, then bos + ids; labels ids + eos on the text
+    slots; `sentence_lens` = the text length over the whole row."""
+    assert config.dataset_audio_seqlen == config.dataset_text_seqlen
+    acc = _DynamicRows(config.dataset_batchsize * config.dataset_audio_seqlen, config.dataset_audio_seqlen)
+    for sample in data:
+        feat, ids = sample["audiofeat"], list(sample["input_ids"])
+        alen, total = feat.shape[0], feat.shape[0] + len(ids) + 1
+        row = None
+        if total <= acc.limit:
+            full = torch.zeros(total, feat.shape[1], dtype=torch.float32, device=feat.device)
+            full[:alen] = feat
+            row = {"feats": full, "slen": len(ids),
+                   "input_ids": np.concatenate([np.full(alen, tokenizer.pad), [tokenizer.bos], ids]).astype(np.int64),
+                   "labels": np.concatenate([np.full(alen, -100), ids, [tokenizer.eos]]).astype(np.int64)}
+        out = acc.offer(total, row)
+        if out:
+            yield _emit_pairs(out, tokenizer.pad)
+    if not config.dataloader_drop_last_batch and acc.rows:
+        yield _emit_pairs(acc.rows, tokenizer.pad)
+
+
+def _emit_audio_rows(rows):
+    labels = _pad_rows([r["labels"] for r in rows], -100, np.int64)
+    return {"input_ids": None, "input_features": _pad_feats([r["feats"] for r in rows]), "labels": labels,
+            "shift_labels": labels, "position_ids": None, "attention_mask": None,
+            "sentence_lens": _pad_rows([np.full(len(r["labels"]), len(r["labels"]), np.int64) for r in rows], 1, np.int64),
+            "num_sentence": len(rows)}
+
+
+def batch_audio(data, config, tokenizer):
+    """processing_touch_audio.py:217-306 (audio pretraining, unpacked): labels = the BEST-RQ codes shifted by one, the last
+    frame unlabelled; no token ids, no mask (the reference leaves both to the model)."""
+    acc = _DynamicRows(config.dataset_batchsize * config.dataset_audio_seqlen, config.dataset_audio_seqlen)
+    for sample in data:
+        feat = sample["audiofeat"]
+        n, row = feat.shape[0], None
+        if n <= acc.limit:
+            codes = list(tokenizer.tokenize(feat))
+            assert len(codes) == n
+            row = {"feats": feat, "labels": np.asarray(codes[1:] + [-100], dtype=np.int64)}
+        out = acc.offer(n, row)
+        if out:
+            yield _emit_audio_rows(out)
+    if not config.dataloader_drop_last_batch and acc.rows:
+        yield _emit_audio_rows(acc.rows)
