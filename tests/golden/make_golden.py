@@ -736,6 +736,21 @@ def qwen2_audio_data_case():
     out["wave_seed"] = np.array(11)
     out["durations"] = np.array(durs)
     out["texts"] = np.array(texts)
+    # the stream through the reference's dynamic batching (:114-147): a budget that closes batches after 1-3 samples
+    lens = [len(out[f"s{i}/input_ids"]) for i in range(len(samples))]
+    for name, (bs, seqlen, drop) in {"dyn_a": (2, max(lens), False), "dyn_b": (1, 2 * sorted(lens)[2] + 1, True)}.items():
+        cfg2 = types.SimpleNamespace(**{**vars(cfg), "dataset_batchsize": bs, "dataset_text_seqlen": seqlen,
+                                        "dataloader_drop_last_batch": drop})
+        batches = list(mod.dynamic_batch(iter([dict(s) for s in samples]), cfg2, proc))
+        out[f"{name}/cfg"] = np.array([bs, seqlen, int(drop)])
+        out[f"{name}/n"] = np.array(len(batches))
+        for j, b in enumerate(batches):
+            for k in ("input_ids", "attention_mask", "labels", "shift_labels", "sentence_lens", "feature_attention_mask"):
+                out[f"{name}/b{j}/{k}"] = npy(b[k])
+            out[f"{name}/b{j}/num_sentence"] = np.array(b["num_sentence"])
+            feat = npy(b["input_features"])                          # [B, 128, frames]
+            out[f"{name}/b{j}/feat_shape"] = np.array(feat.shape)
+            out[f"{name}/b{j}/feat_strided"] = feat[:, ::8, ::97].astype(np.float32)
     save("qwen2_audio_data.npz", **out)
 
 # ------------------------------------------------------------------ Kimi-Audio decoder (config E) — the reference's own module

@@ -283,3 +283,32 @@ def test_qwen2_audio_packed_batcher_holds_the_references_samples(golden):
                 si += 1
         assert off == apos.numel() and clip == b["input_features"].shape[0] == b["num_sentence"]
     assert si == len(samples)
+
+
+@pytest.mark.parametrize("name", ["dyn_a", "dyn_b"])
+def test_qwen2_audio_dynamic_batch_equals_the_reference(golden, name):
+    """`dynamic_batch` (the reference's own unpacked batcher, processing_qwen2_audio.py:17-199): batch boundaries of the
+    flush rule, padding values and every integer tensor equal the reference run on the same stream (one clip longer than
+    30 s, a custom instruction, drop_last on / off); mel features from the oracle's log-mel at the reference's tolerance."""
+    from touchnet_amd.models.qwen2_audio.processing_qwen2_audio import dynamic_batch
+    g = golden("qwen2_audio_data.npz")
+    rng = np.random.RandomState(int(g["wave_seed"]))
+    samples = []
+    for d, tx in zip(g["durations"], g["texts"]):
+        samples.append({"waveform": torch.from_numpy((rng.randn(1, int(d * 16000)) * 0.05).astype(np.float32)),
+                        "txt": str(tx), "sample_rate": 16000})
+    samples[2]["instruct"] = "Translate:"
+    bs, seqlen, drop = [int(v) for v in g[f"{name}/cfg"]]
+    cfg = types.SimpleNamespace(dataset_batchsize=bs, dataset_text_seqlen=seqlen, dataloader_drop_last_batch=bool(drop),
+                                audio_max_length_in_ms_for_filter=40000, text_min_length_in_tokens_for_filter=1,
+                                text_max_length_in_tokens_for_filter=100000, audiofeat_num_mel_bins=128)
+    with use_ops(oracle_ops):
+        batches = list(dynamic_batch(iter(samples), cfg, types.SimpleNamespace(tokenizer=_QwenTok())))
+    assert len(batches) == int(g[f"{name}/n"]) >= 2
+    for j, b in enumerate(batches):
+        for k in ("input_ids", "attention_mask", "labels", "shift_labels", "sentence_lens", "feature_attention_mask"):
+            want = g[f"{name}/b{j}/{k}"]
+            assert b[k].dtype == torch.int64 and np.array_equal(b[k].numpy(), want), (name, j, k)
+        assert int(b["num_sentence"]) == int(g[f"{name}/b{j}/num_sentence"])
+        assert tuple(b["input_features"].shape) == tuple(int(v) for v in g[f"{name}/b{j}/feat_shape"])
+        np.testing.assert_allclose(b["input_features"].numpy()[:, ::8, ::97], g[f"{name}/b{j}/feat_strided"], atol=2e-3)

@@ -201,7 +201,9 @@ def build_datapipe(cfg, tokenizer, dp_rank: int, dp_world_size: int):
             return stage(batch_pairaudio_pairtext, cfg, tokenizer)
         return stage(batch_pairaudio_pairtext_packed, cfg, tokenizer)
     if kind == "qwen2_audio":
-        from touchnet_amd.models.qwen2_audio.processing_qwen2_audio import batch_qwen2_audio_packed
+        from touchnet_amd.models.qwen2_audio.processing_qwen2_audio import batch_qwen2_audio_packed, dynamic_batch
+        if not getattr(cfg, "dataset_enable_pack", True):     # the reference's own form: one sample per row, padded
+            return stage(dynamic_batch, cfg, tokenizer)
         return stage(batch_qwen2_audio_packed, cfg, tokenizer)
     if kind == "kimi_audio":
         # kimi_audio_datapipe (processing_kimi_audio.py:227-241): the reference's batcher takes (processor, tokenizer);

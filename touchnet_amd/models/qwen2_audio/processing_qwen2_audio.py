@@ -78,16 +78,9 @@ def _emit(buf: PackBuffer, segs, mels, valid, pad_id: int, audio_token: int):
             "labelled_rows_max": int(sum(len(r) + 1 for _, r, _ in segs))}           # response + eos (host int: no sync)
 
 
-def batch_qwen2_audio_packed(data, config, processor):
-    """Datapipe stage `f(data, config, processor)`; `processor` = HF Qwen2AudioProcessor (its `.tokenizer` is used) or
-    a bare HF tokenizer.  Audio-token id: `tokenizer.convert_tokens_to_ids("<|AUDIO|>")`."""
-    tokenizer = getattr(processor, "tokenizer", processor)
-    audio_token = int(tokenizer.convert_tokens_to_ids("<|AUDIO|>"))
-    eos, pad = int(tokenizer.eos_token_id), int(tokenizer.pad_token_id)
-    n_mels = getattr(config, "audiofeat_num_mel_bins", 128)
-    T = config.dataset_text_seqlen
-    buf = PackBuffer(config.dataset_batchsize, T)
-    segs, mels, valid = [], [], []
+def _samples(data, config, tokenizer, n_mels: int, limit: int = None):
+    """What both batchers need of a sample, in the reference's order of checks (:37-112): (prompt ids, response ids,
+    mel [frames, n_mels] on the device, valid frames).  `limit`: drop samples with more tokens than a row (packed form)."""
     for sample in data:
         if "response" not in sample:
             if "txt" not in sample:
@@ -108,21 +101,90 @@ def batch_qwen2_audio_packed(data, config, processor):
         tot = len(prompt) + len(response)
         if not (config.text_min_length_in_tokens_for_filter <= tot <= config.text_max_length_in_tokens_for_filter):
             continue                                                       # :106-112
-        if tot > T:
+        if limit is not None and tot > limit:
             continue
+
+        def mel(wav=wav, n=n, total=total):
+            w = wav.reshape(-1)
+            if not w.is_cuda and torch.cuda.is_available():
+                w = w.to(torch.device("cuda", torch.cuda.current_device()), non_blocking=True)
+            if w.dtype == torch.int16:
+                w = ops().pcm16_to_float(w)
+            return ops().log_mel_spectrogram(w, n_mels, padding=max(0, WHISPER_FRAMES * HOP - n))[:total]   # [total, n_mels]
+        yield prompt, response, mel, L, total
+
+
+def batch_qwen2_audio_packed(data, config, processor):
+    """Datapipe stage `f(data, config, processor)`; `processor` = HF Qwen2AudioProcessor (its `.tokenizer` is used) or
+    a bare HF tokenizer.  Audio-token id: `tokenizer.convert_tokens_to_ids("<|AUDIO|>")`."""
+    tokenizer = getattr(processor, "tokenizer", processor)
+    audio_token = int(tokenizer.convert_tokens_to_ids("<|AUDIO|>"))
+    eos, pad = int(tokenizer.eos_token_id), int(tokenizer.pad_token_id)
+    n_mels = getattr(config, "audiofeat_num_mel_bins", 128)
+    T = config.dataset_text_seqlen
+    buf = PackBuffer(config.dataset_batchsize, T)
+    segs, mels, valid = [], [], []
+    for prompt, response, mel, L, _ in _samples(data, config, tokenizer, n_mels, limit=T):
+        tot = len(prompt) + len(response)
         if buf.place(tot):
             yield _emit(buf, segs, mels, valid, pad, audio_token)
             buf.reset()
             segs, mels, valid = [], [], []
             buf.place(tot)
-        w = wav.reshape(-1)
-        if not w.is_cuda and torch.cuda.is_available():
-            w = w.to(torch.device("cuda", torch.cuda.current_device()), non_blocking=True)
-        if w.dtype == torch.int16:
-            w = ops().pcm16_to_float(w)
-        mel = ops().log_mel_spectrogram(w, n_mels, padding=max(0, WHISPER_FRAMES * HOP - n))   # [total, n_mels]
         segs.append((prompt, response, eos))
-        mels.append(mel[:total])
+        mels.append(mel())
         valid.append(L)
     if (not config.dataloader_drop_last_batch) and buf.dirty:
         yield _emit(buf, segs, mels, valid, pad, audio_token)
+
+
+def _emit_rows(rows, pad: int, eos: int):
+    """the reference's padded batch (:119-147): one sample per row, right-padded; features [B, n_mels, frames]"""
+    n = max(len(p) + len(r) for p, r, _, _, _ in rows)
+    B = len(rows)
+    input_ids = np.full((B, n), pad, dtype=np.int64)
+    labels = np.full((B, n), -100, dtype=np.int64)
+    mask = np.zeros((B, n), dtype=np.int64)
+    slen = np.ones((B, n), dtype=np.int64)
+    for i, (p, r, _, _, _) in enumerate(rows):
+        k = len(p) + len(r)
+        input_ids[i, :k] = p + r
+        labels[i, :k] = [-100] * (len(p) - 1) + r + [eos]
+        mask[i, :k] = 1
+        slen[i, :k] = len(r) + 1
+    mels = [m() for _, _, m, _, _ in rows]
+    frames = max(m.shape[0] for m in mels)
+    feats = torch.zeros(B, mels[0].shape[1], frames, dtype=torch.float32, device=mels[0].device)
+    fmask = torch.zeros(B, frames, dtype=torch.int64)
+    for i, (m, (_, _, _, L, total)) in enumerate(zip(mels, rows)):
+        feats[i, :, :m.shape[0]] = m.t()
+        fmask[i, :(L if total == WHISPER_FRAMES else total)] = 1          # (:66-72: all ones for audio longer than 30 s)
+    lab = torch.from_numpy(labels)
+    return {"input_ids": torch.from_numpy(input_ids), "attention_mask": torch.from_numpy(mask), "labels": lab,
+            "shift_labels": lab, "input_features": feats, "feature_attention_mask": fmask, "num_sentence": B,
+            "sentence_lens": torch.from_numpy(slen),
+            "labelled_rows_max": int(sum(len(r) + 1 for _, r, _, _, _ in rows))}
+
+
+def dynamic_batch(data, config, processor):
+    """The reference's OWN (unpacked) batcher, processing_qwen2_audio.py:17-199 — what `--dataset_enable_pack false` gives:
+    one sample per row, right-padded to the longest of the batch, a batch closed when (rows + 1) x longest exceeds
+    batchsize x seqlen (:114-116; the new sample opens the next one).  Same keys as the reference's batch
+    (`feature_attention_mask`, 0 / 1 `attention_mask`); the product model takes them as they are
+    (modeling_qwen2_audio.py).  The mel features come from the device kernel."""
+    tokenizer = getattr(processor, "tokenizer", processor)
+    eos, pad = int(tokenizer.eos_token_id), int(tokenizer.pad_token_id)
+    n_mels = getattr(config, "audiofeat_num_mel_bins", 128)
+    budget = config.dataset_batchsize * config.dataset_text_seqlen
+    rows, longest = [], 0
+    for item in _samples(data, config, tokenizer, n_mels):
+        tot = len(item[0]) + len(item[1])
+        longest = max(longest, tot)
+        if longest * (len(rows) + 1) > budget:
+            if rows:
+                yield _emit_rows(rows, pad, eos)
+            rows, longest = [item], tot
+        else:
+            rows.append(item)
+    if (not config.dataloader_drop_last_batch) and rows:
+        yield _emit_rows(rows, pad, eos)
