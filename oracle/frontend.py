@@ -69,12 +69,15 @@ def speed_perturb(x, speed, zeros=32, rolloff=0.95, beta=14.769656459379492):
     W = zeros / c
     half = int(math.ceil(W)) + 1
     y = np.zeros(n_out, dtype=np.float64)
-    for n in range(n_out):
+    i0b = np.i0(beta)
+    for lo in range(0, n_out, 8192):                       # (blocks of outputs: the same sum, evaluated as arrays)
+        n = np.arange(lo, min(lo + 8192, n_out), dtype=np.int64)
         pos = n * fr.numerator / fr.denominator
-        k = np.arange(max(0, int(math.floor(pos)) - half), min(x.size, int(math.floor(pos)) + half + 1))
-        t = pos - k
-        w = np.where(np.abs(t) < W, np.i0(beta * np.sqrt(np.clip(1.0 - (t / W) ** 2, 0.0, None))) / np.i0(beta), 0.0)
-        y[n] = np.dot(x[k], c * np.sinc(c * t) * w)
+        k = np.floor(pos).astype(np.int64)[:, None] + np.arange(-half, half + 1, dtype=np.int64)[None, :]
+        t = pos[:, None] - k
+        w = np.where(np.abs(t) < W, np.i0(beta * np.sqrt(np.clip(1.0 - (t / W) ** 2, 0.0, None))) / i0b, 0.0)
+        inside = (k >= 0) & (k < x.size)
+        y[lo:lo + n.size] = (np.where(inside, x[np.clip(k, 0, x.size - 1)], 0.0) * (c * np.sinc(c * t) * w)).sum(1)
     return y.astype(np.float32)
 
 

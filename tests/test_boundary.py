@@ -214,6 +214,51 @@ def test_build_dataloader_fn_keywords_iteration_state_and_resume(tmp_path):
         assert 0 < len(dev) <= len(full)
 
 
+_RECIPE_AUG = dict(audio_speed_perturb=True, audio_speed_perturb_speeds=[0.9, 1.0, 1.1], audio_resample_rate=16000,
+                   audiofeat_spec_aug=True, audiofeat_spec_aug_num_t_mask=2, audiofeat_spec_aug_num_f_mask=2,
+                   audiofeat_spec_aug_max_t=50, audiofeat_spec_aug_max_f=10, audiofeat_spec_sub=True,
+                   audiofeat_spec_sub_num_t_sub=3, audiofeat_spec_sub_max_t=30, audiofeat_spec_trim=False,
+                   audiofeat_spec_trim_max_t=20)          # examples/audio/sft/asr/wenetspeech/run.sh:258-270
+
+
+@pytest.mark.parametrize("pack", [True, False])
+def test_dataloader_with_the_asr_recipes_augmentation_chain(tmp_path, pack):
+    """The reference's ASR recipe chain end to end behind `build_dataloader_fn`: resample (identity) -> speed perturbation
+    -> fbank -> spec_aug -> spec_sub -> stack -> batcher (packed, or the unpacked form with `dataset_enable_pack=False`).
+    The stages draw from the global `random` stream: the same seed gives the same batches, another seed different ones;
+    perturbed utterances change length by 1 / speed; the augmented features differ from the plain chain's."""
+    import random
+    import touchnet_amd.specs  # noqa: F401
+    from touchnet_amd.utils.train_spec import get_train_spec
+    dirs = [os.path.join(ROOT, "synthetic", f"00000000{i}") for i in (0, 1)] +            [os.path.join(ROOT, "1sample_per_shard", f"00000000{i}") for i in (0, 1)]
+    spec = get_train_spec("touch_audio_mi355")
+
+    def run(seed, **over):
+        cfg = _data_cfg(tmp_path, dirs, "audio+metainfo", datalist_epoch=1, dataset_enable_pack=pack,
+                        dataset_batchsize=2, **over)
+        random.seed(seed)
+        with use_ops(oracle_ops):
+            loader = spec.build_dataloader_fn(tokenizer=_CharTok(), data_config=cfg, dp_rank=0, dp_world_size=1, split="train")
+            out = list(loader)
+            loader.shutdown()
+        return out
+    plain = run(0)
+    a, b, c = run(1, **_RECIPE_AUG), run(1, **_RECIPE_AUG), run(2, **_RECIPE_AUG)
+    assert len(a) == len(b) >= 1 and sum(int(x["num_sentence"]) for x in a) == sum(int(x["num_sentence"]) for x in plain)
+    for x, y in zip(a, b):
+        assert torch.equal(x["input_features"], y["input_features"]) and torch.equal(x["labels"], y["labels"])
+    same = len(a) == len(c) and all(x["input_features"].shape == y["input_features"].shape and
+                                   torch.equal(x["input_features"], y["input_features"]) for x, y in zip(a, c))
+    assert not same                                              # another seed: other speeds / stripes
+    assert not (len(a) == len(plain) and all(x["input_features"].shape == y["input_features"].shape and
+                                             torch.equal(x["input_features"], y["input_features"])
+                                             for x, y in zip(a, plain)))
+    for x in a:
+        assert torch.isfinite(x["input_features"]).all()
+        if not pack:
+            assert x["position_ids"] is None and set(x["attention_mask"].unique().tolist()) <= {0, 1}
+
+
 # ------------------------------------------------------------------------------------------------ Qwen2-Audio samples
 class _QwenTok:
     """== make_golden.py::_CharTokenizer (the stand-in the reference was run with)."""
