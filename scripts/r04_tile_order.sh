@@ -1,4 +1,6 @@
 #!/bin/bash
+# (the TN_GEMM_TILE_ORDER variant this script built and timed is recorded in profiles/r04f_gemm_tile_order_xcd_round_robin_neutral.log;
+#  the macro is not in csrc/gemm.hip: measured neutral, not kept)
 out=gpurun_out/r04t; mkdir -p $out
 V=$(pwd)/touchnet_amd/_lib/variants
 timeout 600 env TN_AMD_LIB=$V/order1/libtouchnet_amd.so python -m pytest tests/test_kernels_gpu.py -x -q -k "gemm" 2>&1 | tail -2
