@@ -443,6 +443,33 @@ def kernel_rooflines(workload: "Workload"):
     return out, allowed
 
 
+def self_launch(gpus: int, argv=None) -> None:
+    """`python bench.py --gpus N` (N > 1) WITHOUT a launcher: re-execute this command line under
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...`
+    (one rank per GPU over RCCL) and exit with its status.  A no-op when a launcher already set WORLD_SIZE or N == 1.
+    Fewer GPUs than ranks: refused, unless TN_DIST_BACKEND=gloo (ranks share GPUs, device buffers staged through the host:
+    the one-GPU development path, see touchnet_amd/utils/distributed.py)."""
+    if gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < gpus and os.environ.get("TN_DIST_BACKEND") != "gloo":
+        raise SystemExit(f"bench.py --gpus {gpus}: {have} GPU(s) visible (RCCL needs one device per rank; "
+                         f"TN_DIST_BACKEND=gloo lets ranks share a GPU for functional runs)")
+    import socket
+    import subprocess
+    port = os.environ.get("MASTER_PORT")
+    if port is None:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = str(sk.getsockname()[1])
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.pop("MASTER_PORT", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__),
+           *(sys.argv[1:] if argv is None else argv)]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -483,6 +510,7 @@ def main():
                          "optimizer state; fsdp2 = torch fully_shard as the reference applies it (TN_DP_ENGINE)")
     args = ap.parse_args()
     layout = parallel_layout(args.gpus, args.cp, args.tp, args.emulate_rank)
+    self_launch(args.gpus)
     if args.linear_gemm:
         import touchnet_amd.functional as _F
         _F.LINEAR_GEMM = args.linear_gemm

@@ -660,7 +660,25 @@ def boundary_case():
     setup_seq = calls_in(init_fn, ("train_spec.parallelize_fn", "model.to_empty", "model.post_init",
                                    "train_spec.additional_post_init_fn", "model.train", "model.to",
                                    "train_spec.build_optimizers_fn", "train_spec.build_lr_schedulers_fn"))
-    out = {"train_spec_fields": fields, "train_spec_required": required, "train_py_calls": calls,
+    # the job config a reference run hands to the hooks: TrainConfig's field names with their literal defaults
+    # (touchnet/bin/__init__.py:65-642).  What is NOT in this set cannot be set from the reference's command line
+    # (HfArgumentParser rejects unknown flags) — e.g. there is no data-parallel engine switch.
+    cfg_cls = klass(tree("touchnet/bin/__init__.py"), "TrainConfig")
+    cfg_fields = {}
+    for n in cfg_cls.body:
+        if not isinstance(n, ast.AnnAssign) or n.target.id.startswith("_"):
+            continue
+        default = None
+        if isinstance(n.value, ast.Call):
+            for k in n.value.keywords:
+                if k.arg == "default":
+                    try:
+                        default = ast.literal_eval(k.value)
+                    except ValueError:
+                        default = None
+        cfg_fields[n.target.id] = default
+    out = {"train_config_fields": cfg_fields,
+           "train_spec_fields": fields, "train_spec_required": required, "train_py_calls": calls,
            "train_step_sequence": step_seq, "model_setup_sequence": setup_seq,
            "parallel_dims": {"fields": [n.target.id for n in dims.body if isinstance(n, ast.AnnAssign)],
                              "properties": sorted(f.name for f in dims.body if isinstance(f, ast.FunctionDef)

@@ -44,3 +44,32 @@ def test_bench_two_ranks_on_one_gpu(extra, label):
     per_rank = 1 * 512
     dp = 2 if not extra else 1
     assert abs(line["value"] * line["ms_per_step"] / 1e3 - per_rank * dp) / (per_rank * dp) < 0.02
+
+
+def test_plain_command_line_launches_its_own_ranks():
+    """`python bench.py --gpus 2 ...` with NO launcher re-executes itself under
+    torch.distributed.run (bench.self_launch) and rank 0 prints the one JSON line — the route the driver's
+    multi-GPU scaling run takes if it starts the plain command."""
+    env = dict(os.environ, TN_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "TN_FORCE_FSDP"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--workload", "tiny", "--no-cpu-baseline", "--no-kernel-rooflines"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{") and '"metric"' in l]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and "dp2" in line["config"]["parallelism"]
+
+
+def test_more_ranks_than_gpus_is_refused_without_the_gloo_switch():
+    """RCCL needs one device per rank: the plain command line says so instead of hanging in the rendezvous"""
+    import torch
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "TN_DIST_BACKEND"):
+        env.pop(k, None)
+    n = torch.cuda.device_count() + 1          # (>= 2 on a GPU box)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--workload", "tiny"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode != 0 and "GPU(s) visible" in (r.stdout + r.stderr)

@@ -84,6 +84,35 @@ def test_parallel_layout_of_the_bench_flags():
             bench.parallel_layout(bad.pop("world"), **bad)
 
 
+def test_bench_launches_its_own_ranks_when_started_without_a_launcher(monkeypatch):
+    """`python bench.py --gpus N` with no WORLD_SIZE re-executes under torch.distributed.run on 127.0.0.1 with the same
+    arguments (bench.self_launch); under a launcher, or for N = 1, it does nothing; more ranks than GPUs is refused
+    unless the gloo switch is on."""
+    import subprocess
+    import bench
+    seen = {}
+    monkeypatch.setattr(subprocess, "call", lambda cmd, env=None: seen.update(cmd=cmd, env=env) or 0)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.delenv("MASTER_PORT", raising=False)
+    monkeypatch.setenv("TN_DIST_BACKEND", "gloo")
+    assert bench.self_launch(1, ["--gpus", "1"]) is None and not seen
+    with pytest.raises(SystemExit) as e:
+        bench.self_launch(8, ["--gpus", "8", "--steps", "5", "--warmup", "2"])
+    assert e.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=8" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-7].endswith("bench.py") and cmd[-6:] == ["--gpus", "8", "--steps", "5", "--warmup", "2"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    monkeypatch.setenv("WORLD_SIZE", "8")                      # under a launcher: nothing to do
+    assert bench.self_launch(8, ["--gpus", "8"]) is None
+    monkeypatch.delenv("WORLD_SIZE")
+    monkeypatch.delenv("TN_DIST_BACKEND")
+    with pytest.raises(SystemExit) as e:                       # (no GPU here: 0 devices for 2 ranks)
+        bench.self_launch(torch.cuda.device_count() + 2, [])
+    assert "GPU(s) visible" in str(e.value.code)
+
+
 def test_synthetic_plans_of_configs_d_and_e():
     from touchnet_amd.data.synthetic import kimi_audio_plan, qwen2_audio_long_plan
     tok, n = qwen2_audio_long_plan(156032, 151646, 1, 65536, 2025)
@@ -418,6 +447,67 @@ def _tp_fsdp_worker(rank, world, port, ref_state, ref_grads, ref_losses, ret, lo
             dist.destroy_process_group()
 
 
+def _tp_only_dev_worker(rank, world, port, ref_state, ref_loss, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import oracle.ops as oops
+    import touchnet_amd.specs  # noqa: F401
+    from touchnet_amd.bin.train import TrainConfig, Trainer
+    from touchnet_amd.models.backend import use_ops
+    from touchnet_amd.models.kimi_audio import KimiAudioConfig
+    from touchnet_amd.utils.distributed import ParallelDims, init_distributed
+    try:
+        init_distributed("cpu")
+        mesh = ParallelDims(dp_replicate=1, dp_shard=1, cp=1, tp=world, pp=1, world_size=world).build_mesh("cpu")
+        tp_rank = mesh["tp"].get_local_rank()
+        job = TrainConfig(training_model_name="kimi_audio_mi355", training_enable_fused_ce=True,
+                          training_mixed_precision_param="float32")
+        with use_ops(oops):
+            tr = Trainer(job, KimiAudioConfig(**KIMI_TINY), torch.device("cpu"), tp_mesh=mesh["tp"],
+                         optimizer_factory=lambda ps: TorchAdamW(ps))
+            assert tr.dp_cp_group is None                                  # tp only: nobody to reduce metrics over
+            sharded = tr.model._tn_tp["sharded_names"]
+            with torch.no_grad():
+                for name, p in tr.model.named_parameters():
+                    full = ref_state[name]
+                    if name in sharded:
+                        full = full.chunk(world, dim=1 if ("o_proj" in name or "down_proj" in name) else 0)[tp_rank]
+                    p.copy_(full)
+            batch = _tp_fsdp_batches(1)[0]
+            out = tr.dev([batch, batch])
+            # the tp ranks hold the SAME full loss: it must come back as it is, not multiplied by tp
+            assert float(out["global_avg_loss_per_sample"]) == pytest.approx(ref_loss, rel=1e-5, abs=1e-6)
+            assert out["batches"] == 2 and 0.0 <= float(out["global_avg_acc"]) <= 1.0
+            assert float(out["global_max_loss_per_token"]) == pytest.approx(float(out["global_avg_loss_per_token"]), rel=1e-6)
+        ret[rank] = ("ok",)
+    except Exception as e:
+        import traceback
+        ret[rank] = ("fail", traceback.format_exc(), repr(e))
+    finally:
+        if dist.is_initialized():
+            dist.barrier()
+            dist.destroy_process_group()
+
+
+def test_dev_metrics_under_tensor_parallelism_only_are_not_summed_over_the_tp_ranks():
+    """`reduce_metrics` handed `dp_cp_group = None` to the reduction helpers, which read None as WORLD —
+    a tp-only job summed the identical losses of its tp ranks.  The reference reduces over dp_cp only when dp or cp is
+    enabled (touchnet/bin/train.py:485-494)."""
+    import oracle.ops as oops
+    from touchnet_amd.models.backend import use_ops
+    ref = _tp_model()
+    with use_ops(oops), torch.no_grad():
+        ref.eval()
+        loss = float(ref(**_tp_fsdp_batches(1)[0]).loss)
+    ref_state = {k: v.detach().clone() for k, v in ref.state_dict().items()}
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_tp_only_dev_worker, args=(2, _free_port(), ref_state, loss, ret), nprocs=2, join=True)
+        results = dict(ret)
+    for r in range(2):
+        assert results[r][0] == "ok", results[r][1]
+
+
 @pytest.mark.parametrize("loss_parallel", [False, True])
 def test_tensor_parallel_times_fsdp2_on_a_2d_mesh_of_four_ranks(loss_parallel):
     """Config E's layout (TP x FSDP2, here 2 x 2 over gloo) through the Trainer and the reference's ParallelDims mesh:
@@ -573,7 +663,8 @@ def test_flat_data_parallel_engine_trains_like_one_process(world):
                              "rest.lm_head"]
 
 
-def _reference_hooks_worker(rank, world, port, cfg_dict, ref_state, batches, ref_after, ref_norm, ret, rep=1):
+def _reference_hooks_worker(rank, world, port, cfg_dict, ref_state, batches, ref_after, ref_norm, ret, rep=1,
+                            reference_job=False):
     """The flat engine driven ONLY through the TrainSpec hooks, in the order touchnet/bin/train.py calls them
     (tests/golden/boundary.json: `model_setup_sequence` :259-297, `train_step_sequence` :396-474)."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
@@ -594,6 +685,20 @@ def _reference_hooks_worker(rank, world, port, cfg_dict, ref_state, batches, ref
         spec = get_train_spec("llama_mi355")
         job = TrainConfig(training_model_name="llama_mi355", training_enable_fused_ce=False,
                           training_mixed_precision_param="float32", training_dp_engine="flat")
+        if reference_job:
+            # the job config of an UNCHANGED reference run: exactly the reference TrainConfig's fields with their defaults
+            # (tests/golden/boundary.json `train_config_fields`, touchnet/bin/__init__.py:65-642) — no engine field exists,
+            # the flat engine is selected by TN_DP_ENGINE (models/parallelize.py)
+            import types
+            fields = dict(fixture["train_config_fields"])
+            assert "training_dp_engine" not in fields
+            fields.update(training_model_name="llama_mi355", training_mixed_precision_param="float32",
+                          training_activation_checkpoint_mode="none", lr_scheduler_lr=job.lr_scheduler_lr,
+                          lr_scheduler_warmup_steps=job.lr_scheduler_warmup_steps,
+                          lr_scheduler_steps=job.lr_scheduler_steps, optimizer_weight_decay=job.optimizer_weight_decay,
+                          training_max_norm=job.training_max_norm)
+            job = types.SimpleNamespace(**fields)
+            os.environ["TN_DP_ENGINE"] = "flat"
         dims = ParallelDims(dp_replicate=rep, dp_shard=world // rep, cp=1, tp=1, pp=1, world_size=world,
                             enable_loss_parallel=False)
         # HSDP (rep > 1): the reference's 2-D world mesh (touchnet/utils/distributed.py:139-157) with its flattened views
@@ -698,6 +803,44 @@ def test_flat_engine_behind_the_reference_hooks_in_the_reference_call_order():
         results = dict(ret)
     for r in range(world):
         assert results[r][0] == "ok", results[r][1]
+
+
+def test_unchanged_reference_job_selects_the_flat_engine_through_the_environment():
+    """the reference's TrainConfig has no `training_dp_engine` and its argument parser rejects unknown
+    flags; with TN_DP_ENGINE=flat in the environment `parallelize_fn` picks the flat engine for a job config that holds the
+    reference's field set ONLY, and the hooks — replayed in the reference's call order — train like one process."""
+    from touchnet_amd.data.synthetic import text_batch
+    from touchnet_amd.models.llama import DecoderConfig, PackedCausalLM
+    world = 2
+    cfg_dict = dict(TINY, num_hidden_layers=2, tie_word_embeddings=False)
+    batches = [[text_batch(16, 2, 32, seed=300 + 10 * s + r, max_len=9) for r in range(world)] for s in range(2)]
+    fwd = lambda m, b, ns: m(input_ids=b["input_ids"], position_ids=b["position_ids"], attention_mask=b["attention_mask"],
+                             labels=b["labels"], sentence_lens=b["sentence_lens"], num_sentence=ns)
+    state, after, norms = _flat_reference(PackedCausalLM, DecoderConfig.from_dict(cfg_dict), batches, world, fwd)
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_reference_hooks_worker, args=(world, _free_port(), cfg_dict, state, batches, after, norms, ret, 1, True),
+                 nprocs=world, join=True)
+        results = dict(ret)
+    for r in range(world):
+        assert results[r][0] == "ok", results[r][1]
+
+
+def test_parallelize_fn_defaults_to_fsdp2_without_the_switch(monkeypatch):
+    """no attribute and no TN_DP_ENGINE: the reference's behaviour (FSDP2); a bad value is refused loudly"""
+    import types
+    from touchnet_amd.models import parallelize as P
+    seen = {}
+    monkeypatch.setattr(P, "apply_fsdp", lambda model, mesh, **kw: seen.setdefault("fsdp", mesh))
+    dims = types.SimpleNamespace(pp_enabled=False, tp_enabled=False, dp_shard_enabled=True, cp_enabled=False,
+                                 dp_replicate_enabled=False, loss_parallel_enabled=False)
+    job = types.SimpleNamespace(training_activation_checkpoint_mode="none")
+    monkeypatch.delenv("TN_DP_ENGINE", raising=False)
+    P.parallelize_packed(torch.nn.Linear(2, 2), {("dp_shard_cp",): "mesh"}, dims, job)
+    assert seen == {"fsdp": "mesh"}
+    monkeypatch.setenv("TN_DP_ENGINE", "zero9")
+    with pytest.raises(ValueError):
+        P.parallelize_packed(torch.nn.Linear(2, 2), {("dp_shard_cp",): "mesh"}, dims, job)
 
 
 def test_flat_engine_hsdp_two_replicas_of_two_shards_behind_the_hooks():

@@ -309,6 +309,12 @@ class Trainer:
         g = self.dp_cp_group
         ls, lt = loss_per_sample.detach(), loss_per_token.detach()
         zero = torch.zeros((), device=ls.device)
+        if g is None:
+            # no dp / cp peers (single process, or tensor parallelism only: the tp ranks hold the SAME full loss, and the
+            # helpers would treat group=None as WORLD and sum over them) — the reference reduces over dp_cp only when dp or
+            # cp is enabled (train.py:485-494)
+            a = acc.detach() if acc is not None else zero
+            return (ls, lt, lt, a, a)
         return (dist_sum(ls, g), dist_mean(lt, g), dist_max(lt, g),
                 dist_mean(acc.detach(), g) if acc is not None else zero,
                 dist_min(acc.detach(), g) if acc is not None else zero)

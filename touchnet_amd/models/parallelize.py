@@ -13,6 +13,7 @@ siblings): tensor parallel -> activation checkpointing -> (compile) -> FSDP2 ove
 """
 from __future__ import annotations
 
+import os
 import warnings
 
 import torch
@@ -85,7 +86,10 @@ def parallelize_packed(model: nn.Module, world_mesh, parallel_dims, job_config) 
         warnings.warn("training_compile ignored: the MI355X blocks are hand-written kernels (nothing to compile)")
     if getattr(job_config, "training_enable_cpu_offload", False):
         raise NotImplementedError("CPU offload is not supported by the MI355X path (288 GB of HBM per GPU)")
-    engine = getattr(job_config, "training_dp_engine", "fsdp2")
+    # the reference's TrainConfig (touchnet/bin/__init__.py:65-642) has no engine field and its HfArgumentParser rejects
+    # unknown flags: an UNCHANGED reference job selects the flat engine through the environment (TN_DP_ENGINE=flat), as the
+    # repo's own driver does (bin/train.py); a `training_dp_engine` attribute on the job config wins when it exists
+    engine = getattr(job_config, "training_dp_engine", None) or os.environ.get("TN_DP_ENGINE", "fsdp2")
     if engine not in ("flat", "fsdp2"):
         raise ValueError(f"training_dp_engine: {engine!r} (flat | fsdp2)")
     if (parallel_dims.dp_shard_enabled or parallel_dims.cp_enabled) and engine == "flat" and parallel_dims.tp_enabled:
