@@ -274,6 +274,42 @@ int tn_gemm_bf16_splitk(const void* A, const void* B, long long lda, long long l
 int tn_gemm_bf16_wgrad_f32(const void* A, const void* B, long long lda, long long ldb, int K, float* C, int M, int N,
                            long long ldc, int accumulate, int splitk, void* workspace, long long workspace_bytes,
                            void* stream);
+/*      Weight gradient AND bias gradient of y = x W^T + b (nn.Linear with bias: Qwen2's q/k/v projections,
+ *      transformers' Qwen2Attention behind touchnet/models/qwen2_audio/__init__.py; every Whisper-tower layer) in ONE launch:
+ *      C[M, N] (bf16; float with ldc in floats when c_f32; += when accumulate) = A[K, M]^T . B[K, N], bias_grad[M] (bf16)
+ *      = column sums of A (A = dY [tokens, M], B = x [tokens, N] as stored).  The sums are taken from the dY fragments
+ *      the matrix pipe reads anyway: the separate column-sum pass (tn_colsum_bf16, one more trip of dY through HBM) is
+ *      not needed.  splitk >= 2: split-K, `workspace` >= (splitk * tiles * 65536 + splitk * ceil(M / 256) * 256) * 4 bytes.
+ *      -22 as for tn_gemm_bf16 with both operands contraction-major; bias_grad must not be NULL. */
+int tn_gemm_bf16_wgrad_bias(const void* A, const void* B, long long lda, long long ldb, int K, void* C, void* bias_grad,
+                            int M, int N, long long ldc, int accumulate, int c_f32, int splitk, void* workspace,
+                            long long workspace_bytes, void* stream);
+/*      Several INDEPENDENT products of one operand mode as one persistent launch (ngrp = 1..3, weight-gradient mode
+ *      a_kmaj = b_kmaj = 1 only): C_g[M_g, N_g] (+= when accumulate) A_g[K_g, M_g]^T . B_g[K_g, N_g], bf16 outputs (ldc in
+ *      elements) or, c_f32 = 1, float outputs (ldc in floats).  The three weight gradients of transformers' LlamaMLP
+ *      (gate / up / down_proj, swapped at touchnet/models/llama/__init__.py:11-15) are 688 output tiles each — 2.69
+ *      rounds on 256 CUs; as ONE tile list they are 8 whole rounds + 16 tiles, and that remainder (tiles mod CUs, when at
+ *      most half the CUs and every contraction >= 16 stages) runs split-K through `workspace`
+ *      (>= tn_gemm_grouped_workspace_bytes(M, N, K, ngrp) bytes, 16-byte aligned; NULL / too small: the remainder runs as
+ *      whole tiles).  -22: shapes as for tn_gemm_bf16 with both operands contraction-major. */
+long long tn_gemm_grouped_workspace_bytes(const int* M, const int* N, const int* K, int ngrp);
+int tn_gemm_bf16_grouped(const void* const* A, const void* const* B, const long long* lda, const long long* ldb,
+                         const int* K, void* const* C, const long long* ldc, const int* M, const int* N, int ngrp,
+                         int a_kmaj, int b_kmaj, int accumulate, int c_f32, void* workspace, long long workspace_bytes,
+                         void* stream);
+/*      The MLP's gate and up products with SwiGLU in the epilogue (LlamaMLP.forward: down(silu(gate(x)) * up(x));
+ *      the reference swaps in liger's fused SwiGLU at touchnet/models/llama/__init__.py:11-15): one launch computes
+ *      gate[M, I] = x Wg^T, up[M, I] = x Wu^T and act = silu(gate) * up (all bf16, row pitch ldc; gate and up are kept
+ *      for the backward) from x [M, K] (pitch ldx) and Wg, Wu [I, K] (pitch ldw) — an output tile is 256 rows x (128 gate
+ *      + 128 up columns), no separate SwiGLU pass.  Arithmetic = tn_swiglu_fwd on the bf16-rounded products (bit-identical).
+ *      -22 unless K % 64 == 0, I % 8 == 0, pitches % 8 == 0, 16-byte aligned bases. */
+int tn_gemm_bf16_swiglu_fwd(const void* x, const void* wg, const void* wu, void* gate, void* up, void* act, int M, int I,
+                            int K, long long ldx, long long ldw, long long ldc, void* stream);
+/*      Its backward counterpart: d(act) = dY W_down (dY [M, H], pitch lddy; W_down [H, I] read contraction-major, pitch
+ *      ldw) stays in the accumulators; the epilogue reads gate / up [M, I] and writes d(gate), d(up) (pitch ld) =
+ *      tn_swiglu_bwd on the bf16-rounded d(act) (bit-identical).  -22 unless H % 64 == 0, I % 8 == 0, pitches % 8 == 0. */
+int tn_gemm_bf16_swiglu_bwd(const void* dy, const void* wd, const void* gate, const void* up, void* dgate, void* dup,
+                            int M, int I, int H, long long lddy, long long ldw, long long ld, void* stream);
 /*      Single segment, both operands contraction-contiguous (the round-2 entry point): */
 int tn_gemm_bf16_tn(const void* A, const void* B, void* C, void* Ct, const void* bias, int M, int N, int K,
                     long long lda, long long ldb, long long ldc, long long ldct, int accumulate, void* stream);

@@ -884,6 +884,9 @@ def test_linear_layers_on_the_hand_written_gemm_match_the_library(monkeypatch):
         monkeypatch.setattr(F, "_OWN_MIN_TILES", 1)        # (test sizes have a handful of tiles)
         calls = []
         monkeypatch.setattr(F, "gemm", lambda *a, **k: (calls.append((len(a[0]), a[1:], tuple(k))), _orig(*a, **k))[1])
+        for name in fused:      # the round-5 launches: SwiGLU epilogues (fwd, bwd) and the grouped weight gradients
+            monkeypatch.setattr(F, name, (lambda o, nm: lambda *a, **k: (calls.append((nm, (), ())), o(*a, **k))[1])(
+                fused[name], name))
         tr = []
         monkeypatch.setattr(F, "transpose_2d", lambda *a, **k: (tr.append(1), _orig_t(*a, **k))[1])
         xx = x.clone().requires_grad_()
@@ -898,13 +901,15 @@ def test_linear_layers_on_the_hand_written_gemm_match_the_library(monkeypatch):
         return [r.float() for r in res], calls, len(tr)
 
     _orig, _orig_t = F.gemm, F.transpose_2d
+    fused = {n: getattr(F, n) for n in ("gemm_swiglu_fwd", "gemm_swiglu_bwd", "gemm_grouped_wgrad")}
     lib, c_lib, t_lib = run("lib")
     own, c_own, t_own = run("own")
-    # MLP: 3 forward, dW_down, d(act), dX (one launch over the gate / up pair), dW_gate, dW_up; group: 3 forward, dX (ONE
-    # launch with three segments), 3 dW.  And not a single transposed copy.
+    # MLP (round 5): gate + up + SwiGLU as ONE launch, down; d(act) + SwiGLU backward as ONE launch, dX (one launch over
+    # the gate / up pair), the three weight gradients as ONE grouped launch = 5 launches (round 4: 8 + 2 SwiGLU kernels);
+    # group: 3 forward, dX (ONE launch with three segments), 3 dW.  And not a single transposed copy.
     assert len(c_lib) == 0 and t_lib > 0
-    assert len(c_own) == 8 + 7 and t_own == 0, (len(c_own), t_own)
-    assert sorted(n for n, _, _ in c_own) == [1] * 13 + [2, 3]
+    assert len(c_own) == 5 + 7 and t_own == 0, (len(c_own), t_own)
+    assert sorted(str(n) for n, _, _ in c_own) == sorted(["1"] * 7 + ["2", "3"] + list(fused))
     for i, (a, b) in enumerate(zip(own, lib)):
         scale = float(b.abs().max())
         assert float((a - b).abs().max()) <= 1.6e-2 * scale + 1e-6, (i, float((a - b).abs().max()), scale)

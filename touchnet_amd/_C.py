@@ -75,11 +75,17 @@ PROTOTYPES = {
     "tn_gemm_bf16_wgrad_f32": [_vp, _vp, _ll, _ll, _i, _vp, _i, _i, _ll, _i, _i, _vp, _ll, _vp],
     "tn_gemm_bf16": [C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_ll), C.POINTER(_ll), C.POINTER(_i), _i, _i, _i, _vp, _vp,
                      _vp, _i, _i, _ll, _ll, _i, _vp],
+    "tn_gemm_grouped_workspace_bytes": [C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), _i],
+    "tn_gemm_bf16_grouped": [C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_ll), C.POINTER(_ll), C.POINTER(_i), C.POINTER(_vp),
+                             C.POINTER(_ll), C.POINTER(_i), C.POINTER(_i), _i, _i, _i, _i, _i, _vp, _ll, _vp],
+    "tn_gemm_bf16_wgrad_bias": [_vp, _vp, _ll, _ll, _i, _vp, _vp, _i, _i, _ll, _i, _i, _i, _vp, _ll, _vp],
+    "tn_gemm_bf16_swiglu_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _ll, _ll, _ll, _vp],
+    "tn_gemm_bf16_swiglu_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _ll, _ll, _ll, _vp],
     "tn_gemm_set_persistent": [_i],
     "tn_gemm_get_persistent": [],
 }
 _RESTYPE = {"tn_gemm_set_persistent": None, "tn_version": C.c_char_p, "tn_sumsq_multi_chunk": C.c_longlong, "tn_adamw_multi_chunk": C.c_longlong,
-            "tn_colsum_workspace_floats": C.c_longlong}
+            "tn_colsum_workspace_floats": C.c_longlong, "tn_gemm_grouped_workspace_bytes": C.c_longlong}
 
 # kernel-development entry points: exported by the library, deliberately NOT part of the C ABI (include/touchnet_amd.h)
 DEV_PROTOTYPES = {

@@ -32,6 +32,10 @@ __device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16
 // denormal fix-up sequence libm's exp2f adds
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// 1 / (1 + e^-x) with v_exp_f32 + v_rcp_f32 (1 ulp each; no IEEE division sequence): ONE definition for the SwiGLU row
+// kernels (norm_act.hip) and the fused SwiGLU epilogues of the GEMM (gemm.hip), which must agree bit for bit
+__device__ __forceinline__ float sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
   bf16x2_t v = {(__bf16)lo, (__bf16)hi};
   return __builtin_bit_cast(uint32_t, v);

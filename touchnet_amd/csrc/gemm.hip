@@ -63,6 +63,32 @@ struct Seg {
   int pad_;
 };
 
+struct Grp {
+  bf16_t* C;
+  long long ldc;
+  int M, N, nbm, nbn;
+  int start;           // index of the product's first tile in the launch's tile list (a multiple of 8: XCD affinity)
+  int stages;          // ceil(K / 64)
+};
+
+// What the epilogue does with a finished tile:
+//   EPI_PLAIN       C = acc (+ bias) (+ C), optional transposed copy
+//   EPI_GROUPED     the same per product of a grouped launch (no bias / transposed copy)
+//   EPI_SWIGLU_FWD  the MLP's gate and up products as ONE launch: an output tile is 256 rows x (128 gate columns + 128 up
+//                   columns), the B stage image interleaves 32-row runs of gate_proj and up_proj so that every wave holds
+//                   gate (block j = 0) and up (j = 1) of the SAME 32 columns in the same lanes; it writes gate, up (the
+//                   backward needs both) and act = silu(gate) * up — the separate SwiGLU pass (3 tensors through HBM) is gone
+//   EPI_SWIGLU_BWD  the product is d(act) = dY W_down; the epilogue reads the gate / up tiles through the park and writes
+//                   d(gate), d(up): d(act) never exists in HBM and the separate backward pass (5 tensors) is gone
+// (transformers' LlamaMLP.forward behind touchnet/models/llama/__init__.py:11-15, where the reference swaps in liger's
+//  fused SwiGLU)
+//   EPI_BIASG       EPI_PLAIN for a weight gradient dW = dY^T x that ALSO returns the bias gradient: the column sums of
+//                   dY (the A operand, contraction-major) are taken from the A fragments the MFMAs read anyway — wave
+//                   (wr, wc) of the tiles in output column 0 sums its A block wc over the whole contraction (16 VALU
+//                   adds per 8 MFMAs) — so the separate column-sum pass over dY (one more trip of dY through HBM per
+//                   biased layer: 258 launches per Qwen2-Audio step) is gone
+constexpr int EPI_PLAIN = 0, EPI_GROUPED = 1, EPI_SWIGLU_FWD = 2, EPI_SWIGLU_BWD = 3, EPI_BIASG = 4;
+
 struct Params {
   Seg seg[MAXSEG];
   int nseg;
@@ -86,6 +112,21 @@ struct Params {
   // fp32 output (weight gradients written straight into the data-parallel engine's fp32 staging buffers, utils/zero_dp.py):
   // C is a float matrix (ldc in floats), no bias, no transposed copy; accumulate adds to what is there
   int c_f32;
+  // EPI_GROUPED: several independent products of one operand mode in ONE persistent launch — product g = seg[g] (one
+  // segment each) with its own output; the launch walks the concatenation of their tile lists (tile0 / ntiles index it)
+  Grp grp[MAXSEG];
+  int ngrp;
+  // EPI_SWIGLU_FWD (B = rows of gate_proj AND up_proj, seg[0].B / seg[1].B): C = gate, C2 = up, C3 = silu(gate) * up
+  // EPI_SWIGLU_BWD (product = d(act)): E1 = gate, E2 = up (row pitch lde) are read, C = d(gate), C2 = d(up) are written
+  bf16_t* C2;
+  bf16_t* C3;
+  const bf16_t* E1;
+  const bf16_t* E2;
+  long long lde;
+  // EPI_BIASG: bias_out[M] (bf16) = column sums of A; under split-K the units leave fp32 partial sums in
+  // bias_ws[split][nbm * 256] and the reduce kernel adds them up
+  bf16_t* bias_out;
+  float* bias_ws;
 };
 
 // XCD-aware, bijective workgroup -> tile map
@@ -169,7 +210,7 @@ struct Stream {
   __device__ __forceinline__ void open(const bf16_t* X, long long ld, int K, int R, int origin, int wave, int lane) {
     ld2 = (int)(ld * 2);
     if constexpr (!KMAJ) {
-      const long long bytes = (long long)(R - origin) * ld2;
+      const long long bytes = max((long long)(R - origin) * ld2, 0LL);     // (origin >= R: nothing to read, all zeros)
       rs = __builtin_amdgcn_make_buffer_rsrc((void*)(X + (long long)origin * ld), 0, (int)min(bytes, 0x7fffffffLL),
                                              0x00020000);
       step = 128;
@@ -213,8 +254,21 @@ __device__ __forceinline__ u32x4_t ds_b128(uint32_t addr) {
   return r;
 }
 
-template <bool AK, bool BK, int PLACE, int ASYM, int ILV, bool HAS_CT, bool SPLITK = false, bool OUT_F32 = false>
+template <bool AK, bool BK, int PLACE, int ASYM, int ILV, bool HAS_CT, bool SPLITK = false, bool OUT_F32 = false,
+          int EPI = EPI_PLAIN>
 struct Kernel {
+  static_assert(EPI == EPI_PLAIN || EPI == EPI_BIASG || (!HAS_CT && !SPLITK), "fused epilogues: whole tiles, no transposed copy");
+  static_assert(EPI != EPI_BIASG || (AK && BK && !HAS_CT), "bias gradient: weight-gradient mode");
+  static_assert(EPI != EPI_SWIGLU_FWD || (!AK && !BK && !OUT_F32), "SwiGLU forward: x W^T layout");
+  static_assert(EPI != EPI_SWIGLU_BWD || (!AK && BK && !OUT_F32), "SwiGLU backward: dY W layout");
+  static constexpr int BN_EFF = EPI == EPI_SWIGLU_FWD ? 128 : BN;   // output columns per tile (per matrix)
+  // DMA wave w of the SwiGLU forward fetches rows [32 (w >> 1), + 32) of its matrix's 128-row panel: per-lane offsets as
+  // for wave 0 (the bank swizzle only involves row bits below 32)
+  struct Out {
+    bf16_t* C;
+    long long ldc;
+    int M, N;
+  };
   // ---- per-lane LDS read offsets ------------------------------------------------------------------------------------------
   //  ROW : xr[q] = (row0 + l31) * 128 + (((2 q + hi) ^ ((l31 >> 1) & 7)) << 4); block b at + b * 4096
   //  KMAJ: xk[b] = (8 hi + j) * 512 + half * 32 + w * 8 + (((blk0 + b) ^ j) << 6); quarter q, half e at + (16 q + 4 e) * 512
@@ -291,12 +345,24 @@ struct Kernel {
     const int bid = blockIdx.x, G = gridDim.x;
     const int tiles = p.ntiles;
     const int mine = ((SPLITK ? tiles * p.splitk : tiles) - bid + G - 1) / G;
-    auto origin = [&](int k, int& m0, int& n0) {
+    auto origin_g = [&](int k, int& m0, int& n0, int& g) {
       int tm, tn, u = bid + k * G;
       if constexpr (SPLITK) u -= (u / tiles) * tiles;
-      tile_of_block(p.tile0 + u, p.nbm, p.nbn, tm, tn);
+      u += p.tile0;
+      g = 0;
+      if constexpr (EPI == EPI_GROUPED) {
+        if (p.ngrp > 1 && u >= p.grp[1].start) g = 1;
+        if (p.ngrp > 2 && u >= p.grp[2].start) g = 2;
+        tile_of_block(u - p.grp[g].start, p.grp[g].nbm, p.grp[g].nbn, tm, tn);
+      } else {
+        tile_of_block(u, p.nbm, p.nbn, tm, tn);
+      }
       m0 = tm * BM;
-      n0 = tn * BN;
+      n0 = tn * BN_EFF;
+    };
+    auto origin = [&](int k, int& m0, int& n0) {
+      int g;
+      origin_g(k, m0, n0, g);
     };
     auto split_of = [&](int k) { return (bid + k * G) / tiles; };
 
@@ -314,6 +380,10 @@ struct Kernel {
                               m0, wave, lane);
         else sA.kill(p.C);
         sA.left = p.kchunk;
+      } else if constexpr (EPI == EPI_GROUPED) {
+        int g;
+        origin_g(ka, m0, n0, g);
+        sA.open(p.seg[g].A, p.seg[g].lda, p.seg[g].K, p.grp[g].M, m0, wave, lane);
       } else {
         sA.open(p.seg[s].A, p.seg[s].lda, p.seg[s].K, p.M, m0, wave, lane);
       }
@@ -328,6 +398,13 @@ struct Kernel {
                               n0, wave, lane);
         else sB.kill(p.C);
         sB.left = p.kchunk;
+      } else if constexpr (EPI == EPI_GROUPED) {
+        int g;
+        origin_g(kb, m0, n0, g);
+        sB.open(p.seg[g].B, p.seg[g].ldb, p.seg[g].K, p.grp[g].N, n0, wave, lane);
+      } else if constexpr (EPI == EPI_SWIGLU_FWD) {
+        // LDS rows [32 w, 32 w + 32) of the B image = rows n0 + 32 (w >> 1) .. of gate_proj (w even) / up_proj (w odd)
+        sB.open((wave & 1) ? p.seg[1].B : p.seg[0].B, p.seg[0].ldb, p.seg[0].K, p.N, n0 + (wave >> 1) * 32, 0, lane);
       } else {
         sB.open(p.seg[s].B, p.seg[s].ldb, p.seg[s].K, p.N, n0, wave, lane);
       }
@@ -400,6 +477,24 @@ struct Kernel {
 #endif
     };
 
+    // EPI_BIASG: this wave's share of the A panel's column sums — block wc of the four A fragments (32 rows of dY^T), the
+    // 8 contraction slots of the lane, every quarter of every stage (rows and depths beyond the operand are zero-filled)
+    float bsum = 0.f;
+    bool bias_on = false;
+    auto bias_accum = [&](const Frags<AK, 4>& a) {
+      auto add = [&](const bf16x8_t& v) {
+        const u32x4_t w = __builtin_bit_cast(u32x4_t, v);
+        bsum += ((__uint_as_float(w.x << 16) + __uint_as_float(w.x & 0xffff0000u)) +
+                 (__uint_as_float(w.y << 16) + __uint_as_float(w.y & 0xffff0000u))) +
+                ((__uint_as_float(w.z << 16) + __uint_as_float(w.z & 0xffff0000u)) +
+                 (__uint_as_float(w.w << 16) + __uint_as_float(w.w & 0xffff0000u)));
+      };
+      if (wc == 0) add(a.v[0]);
+      else if (wc == 1) add(a.v[1]);
+      else if (wc == 2) add(a.v[2]);
+      else add(a.v[3]);
+    };
+
     // One quarter: the 8 MFMAs of (ca, cb); the fragments of quarter NQ of slots (nsa, nsb) are read into (na, nb) either
     // all in front (ILV = 0) or one behind each of the first six MFMAs (ILV = 1); the DMA pieces the placement table
     // puts at positions P0 .. P0 + 7 go behind their MFMA (P0 < 0: none).  dst_b / dst_a = slots the open piece set fills.
@@ -408,6 +503,10 @@ struct Kernel {
       constexpr int P0 = decltype(P0C)::value;
       if constexpr (ILV == 0 && TN_GEMM_ABLATE != 2) {
         read_all(NQC, nsa, nsb, na, nb);
+        TN_PIN();
+      }
+      if constexpr (EPI == EPI_BIASG) {
+        if (bias_on) bias_accum(ca);
         TN_PIN();
       }
       auto step = [&](auto MC) {
@@ -519,6 +618,9 @@ struct Kernel {
         wait_frags(ae, be);
         TN_PIN();
       } else {
+        if constexpr (EPI == EPI_BIASG) {
+          if (bias_on) bias_accum(ao);
+        }
 #pragma unroll
         for (int m = 0; m < 8; ++m) mma(ao, bo, m >> 1, m & 1);
         __builtin_amdgcn_s_setprio(0);
@@ -529,8 +631,20 @@ struct Kernel {
       sb = sb1;
     };
 
-    const int np = SPLITK ? p.kchunk : p.stages;
+    const int np_all = SPLITK ? p.kchunk : p.stages;
     for (int kc = 0; kc < mine; ++kc) {
+      int np = np_all;
+      if constexpr (EPI == EPI_BIASG) {
+        int m0_, n0_, g_;
+        origin_g(kc, m0_, n0_, g_);
+        bias_on = n0_ == 0;                                // the tiles of output column 0 carry the bias gradient
+        bsum = 0.f;
+      }
+      if constexpr (EPI == EPI_GROUPED) {                  // (the products of a group may differ in depth)
+        int m0_, n0_, g_;
+        origin_g(kc, m0_, n0_, g_);
+        np = p.grp[g_].stages;
+      }
       read_all(I0{}, sa, sb, ae, be);
       wait_frags(ae, be);
       TN_PIN();
@@ -538,16 +652,46 @@ struct Kernel {
       trip(std::true_type{});
       // Epilogue.  The streams are already inside the next tile (its stage 0 and A(1) are in the other three slots);
       // the two slots the last barrier freed (now pb / pa) are the park, then they take their deferred pieces.
-      int m0, n0;
-      origin(kc, m0, n0);
+      int m0, n0, grp;
+      origin_g(kc, m0, n0, grp);
+      if constexpr (EPI == EPI_BIASG) {
+        if (bias_on) {
+          // the lane pair (l, l + 32) holds the two halves of every 16-deep slice of row l
+          const float tot = bsum + __shfl_xor(bsum, 32, 64);
+          const int m = m0 + wr * 128 + wc * 32 + (lane & 31);
+          if (lane < 32) {
+            if constexpr (SPLITK) {
+              p.bias_ws[(long long)split_of(kc) * (p.nbm * BM) + m] = tot;
+            } else if (m < p.M) {
+              p.bias_out[m] = f2bf(tot);
+            }
+          }
+        }
+      }
       if constexpr (SPLITK) {
         const int u = bid + kc * G, sp = u / tiles;
         epilogue_ws(p, acc, sp * tiles + (u - sp * tiles), wr * 128, wc * 64, lane);
       } else if constexpr (OUT_F32) {
-        epilogue_f32(p, acc, m0 + wr * 128, n0 + wc * 64, lane);
+        if constexpr (EPI == EPI_GROUPED) {
+          const Out o = {p.grp[grp].C, p.grp[grp].ldc, p.grp[grp].M, p.grp[grp].N};
+          epilogue_f32(p, o, acc, m0 + wr * 128, n0 + wc * 64, lane);
+        } else {
+          const Out o = {p.C, p.ldc, p.M, p.N};
+          epilogue_f32(p, o, acc, m0 + wr * 128, n0 + wc * 64, lane);
+        }
+      } else if constexpr (EPI == EPI_SWIGLU_FWD) {
+        epilogue_swiglu_fwd(p, acc, smem + (wave < 4 ? pb : pa) * SLOT + (wave & 3) * 8192, m0 + wr * 128, n0 + wc * 32,
+                            lane);
+      } else if constexpr (EPI == EPI_SWIGLU_BWD) {
+        epilogue_swiglu_bwd(p, acc, smem + (wave < 4 ? pb : pa) * SLOT + (wave & 3) * 8192, m0 + wr * 128, n0 + wc * 64,
+                            lane);
+      } else if constexpr (EPI == EPI_GROUPED) {
+        const Out o = {p.grp[grp].C, p.grp[grp].ldc, p.grp[grp].M, p.grp[grp].N};
+        epilogue(p, o, acc, smem + (wave < 4 ? pb : pa) * SLOT + (wave & 3) * 8192, m0 + wr * 128, n0 + wc * 64, lane);
+      } else if constexpr (TN_GEMM_ABLATE != 4) {
+        const Out o = {p.C, p.ldc, p.M, p.N};
+        epilogue(p, o, acc, smem + (wave < 4 ? pb : pa) * SLOT + (wave & 3) * 8192, m0 + wr * 128, n0 + wc * 64, lane);
       }
-      else if constexpr (TN_GEMM_ABLATE != 4)
-        epilogue(p, acc, smem + (wave < 4 ? pb : pa) * SLOT + (wave & 3) * 8192, m0 + wr * 128, n0 + wc * 64, lane);
       zero_acc();
       __builtin_amdgcn_s_waitcnt(0xc07f);               // my park reads are done ...
       __builtin_amdgcn_s_barrier();                     // ... and everybody's: the slots may be refilled
@@ -557,7 +701,7 @@ struct Kernel {
       ra = Reader<AK, 4>(lane, wr * 128);
       rb = Reader<BK, 2>(lane, wc * 64);
       sA.set_voff(wave, lane);
-      sB.set_voff(wave, lane);
+      sB.set_voff(EPI == EPI_SWIGLU_FWD ? 0 : wave, lane);
       early_pieces(pb, pa);
     }
   }
@@ -572,9 +716,9 @@ struct Kernel {
   }
 
   // fp32 output: the accumulators as they are, 16 bytes per lane and register quad (see epilogue_ws), clipped to M x N
-  static __device__ __forceinline__ void epilogue_f32(const Params& p, Acc& acc, int wm0, int wn0, int lane) {
+  static __device__ __forceinline__ void epilogue_f32(const Params& p, const Out& o, Acc& acc, int wm0, int wn0, int lane) {
     const int l31 = lane & 31, hi = lane >> 5;
-    float* C = reinterpret_cast<float*>(p.C);
+    float* C = reinterpret_cast<float*>(o.C);
     const bool add = p.accumulate != 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -584,8 +728,8 @@ struct Kernel {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int n = wn0 + j * 32 + 8 * g + 4 * hi;
-          if (m < p.M && n < p.N) {                          // N is a multiple of 8: the quad is inside or outside
-            f32x4_t* dst = reinterpret_cast<f32x4_t*>(C + (long long)m * p.ldc + n);
+          if (m < o.M && n < o.N) {                          // N is a multiple of 8: the quad is inside or outside
+            f32x4_t* dst = reinterpret_cast<f32x4_t*>(C + (long long)m * o.ldc + n);
             f32x4_t v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
             if (add) v += *dst;
             *dst = v;
@@ -614,9 +758,171 @@ struct Kernel {
     }
   }
 
+  // ---- fused SwiGLU epilogues ------------------------------------------------------------------------------------------
+  // Arithmetic = tn::swiglu_fwd_kernel / swiglu_bwd_kernel (csrc/norm_act.hip) on the bf16-ROUNDED products, as the
+  // separate passes saw them: silu(gate) rounded to bf16 before the product (what the eager path materialises), so the
+  // fused and the unfused MLP agree bit for bit.
+  static __device__ __forceinline__ float sigm(float x) { return sigmoid_fast(x); }
+  static __device__ __forceinline__ float lo16(uint32_t w) { return __uint_as_float(w << 16); }
+  static __device__ __forceinline__ float hi16(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+  static __device__ __forceinline__ float rbf(float v) { return __uint_as_float(((uint32_t)f2bf(v)) << 16); }
+
+  // Forward.  The wave holds gate (acc[i][0]) and up (acc[i][1]) of rows wm0 .. wm0 + 127, columns wn0 .. wn0 + 31.
+  // Three trips through its 8 KB park ([64 rows][64 columns] bf16, 128-byte rows, 16-byte chunk ^= row & 7):
+  //   1, 2  rows half * 64 ..: columns 0-31 = gate, 32-63 = up  -> 64-byte row segments of C (gate) and C2 (up)
+  //   3     act of ALL 128 rows: columns 0-31 = rows 0-63, columns 32-63 = rows 64-127 -> 64-byte row segments of C3
+  static __device__ __forceinline__ void epilogue_swiglu_fwd(const Params& p, Acc& acc, char* park, int wm0, int wn0,
+                                                             int lane) {
+    const int l31 = lane & 31, hi = lane >> 5;
+    // (the per-lane choice between the two outputs as integer arithmetic on pointers held in registers: written as
+    //  `c < 4 ? p.C : p.C2` hipcc selects between the two kernel-argument ADDRESSES and re-loads the pointer per store)
+    const uintptr_t c_gate = (uintptr_t)p.C, c_up = (uintptr_t)p.C2;
+    bf16_t* const gu_base = reinterpret_cast<bf16_t*>(c_gate + ((lane & 4) ? c_up - c_gate : (uintptr_t)0));
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii) {
+        const int i = half * 2 + ii;
+        const int row = ii * 32 + l31;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int chunk = (j * 4 + g) ^ (row & 7);
+            const u32x2_t pk = {pack2bf(acc[i][j][4 * g], acc[i][j][4 * g + 1]),
+                                pack2bf(acc[i][j][4 * g + 2], acc[i][j][4 * g + 3])};
+            *reinterpret_cast<u32x2_t*>(park + row * 128 + chunk * 16 + hi * 8) = pk;
+          }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll 4
+      for (int it = 0; it < 8; ++it) {
+        const int row = it * 8 + (lane >> 3), c = lane & 7;
+        const u32x4_t pv = *reinterpret_cast<const u32x4_t*>(park + row * 128 + ((c ^ (row & 7)) << 4));
+        const int m = wm0 + half * 64 + row, n = wn0 + (c & 3) * 8;
+        if (m < p.M && n < p.N)
+          *reinterpret_cast<uint4*>(gu_base + (long long)m * p.ldc + n) = make_uint4(pv.x, pv.y, pv.z, pv.w);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = (i & 1) * 32 + l31;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float h[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float gf = rbf(acc[i][0][4 * g + e]), uf = rbf(acc[i][1][4 * g + e]);
+          h[e] = rbf(gf * sigm(gf)) * uf;
+        }
+        const int chunk = ((i >> 1) * 4 + g) ^ (row & 7);
+        const u32x2_t pk = {pack2bf(h[0], h[1]), pack2bf(h[2], h[3])};
+        *reinterpret_cast<u32x2_t*>(park + row * 128 + chunk * 16 + hi * 8) = pk;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll 4
+    for (int it = 0; it < 8; ++it) {
+      const int row = it * 8 + (lane >> 3), c = lane & 7;
+      const u32x4_t pv = *reinterpret_cast<const u32x4_t*>(park + row * 128 + ((c ^ (row & 7)) << 4));
+      const int m = wm0 + (c >> 2) * 64 + row, n = wn0 + (c & 3) * 8;
+      if (m < p.M && n < p.N)
+        *reinterpret_cast<uint4*>(p.C3 + (long long)m * p.ldc + n) = make_uint4(pv.x, pv.y, pv.z, pv.w);
+    }
+  }
+
+  // Backward.  acc = d(act) of the wave's 128 x 64 tile.  Per 64-row half: the gate and up rows come in as full 128-byte
+  // lines (16 bytes per lane), go through the park into the accumulator layout (row = lane, 4 consecutive columns per
+  // register quad), d(gate) / d(up) are formed in registers and leave through the park like any other tile.
+  static __device__ __forceinline__ void epilogue_swiglu_bwd(const Params& p, Acc& acc, char* park, int wm0, int wn0,
+                                                             int lane) {
+    const int l31 = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      uint4 gv[8], uv[8];
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int row = it * 8 + (lane >> 3), c = lane & 7;
+        const int m = wm0 + half * 64 + row, n = wn0 + c * 8;
+        const bool in = m < p.M && n < p.N;
+        const long long off = (long long)m * p.lde + n;
+        gv[it] = in ? *reinterpret_cast<const uint4*>(p.E1 + off) : make_uint4(0, 0, 0, 0);
+        uv[it] = in ? *reinterpret_cast<const uint4*>(p.E2 + off) : make_uint4(0, 0, 0, 0);
+      }
+      u32x2_t gq[2][2][4], uq[2][2][4];
+      auto through_park = [&](const uint4 (&src)[8], u32x2_t (&dst)[2][2][4]) {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          const int row = it * 8 + (lane >> 3), c = lane & 7;
+          const u32x4_t v = {src[it].x, src[it].y, src[it].z, src[it].w};
+          *reinterpret_cast<u32x4_t*>(park + row * 128 + ((c ^ (row & 7)) << 4)) = v;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+          const int row = ii * 32 + l31;
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+              dst[ii][j][g] =
+                  *reinterpret_cast<const u32x2_t*>(park + row * 128 + (((j * 4 + g) ^ (row & 7)) << 4) + hi * 8);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      };
+      through_park(gv, gq);
+      through_park(uv, uq);
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii) {
+        const int i = half * 2 + ii;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            float dg[4], du[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const uint32_t wg = e < 2 ? gq[ii][j][g].x : gq[ii][j][g].y, wu = e < 2 ? uq[ii][j][g].x : uq[ii][j][g].y;
+              const float gf = (e & 1) ? hi16(wg) : lo16(wg), uf = (e & 1) ? hi16(wu) : lo16(wu);
+              const float d = rbf(acc[i][j][4 * g + e]);
+              const float sg = sigm(gf);
+              const float silu = gf * sg;
+              du[e] = d * silu;
+              dg[e] = d * uf * (sg + silu * (1.f - sg));
+            }
+            gq[ii][j][g] = u32x2_t{pack2bf(dg[0], dg[1]), pack2bf(dg[2], dg[3])};
+            uq[ii][j][g] = u32x2_t{pack2bf(du[0], du[1]), pack2bf(du[2], du[3])};
+          }
+      }
+      auto out_park = [&](const u32x2_t (&src)[2][2][4], bf16_t* C) {
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+          const int row = ii * 32 + l31;
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+              *reinterpret_cast<u32x2_t*>(park + row * 128 + (((j * 4 + g) ^ (row & 7)) << 4) + hi * 8) = src[ii][j][g];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll 4
+        for (int it = 0; it < 8; ++it) {
+          const int row = it * 8 + (lane >> 3), c = lane & 7;
+          const u32x4_t pv = *reinterpret_cast<const u32x4_t*>(park + row * 128 + ((c ^ (row & 7)) << 4));
+          const int m = wm0 + half * 64 + row, n = wn0 + c * 8;
+          if (m < p.M && n < p.N)
+            *reinterpret_cast<uint4*>(C + (long long)m * p.ldc + n) = make_uint4(pv.x, pv.y, pv.z, pv.w);
+        }
+      };
+      out_park(gq, p.C);
+      out_park(uq, p.C2);
+    }
+  }
+
   // Epilogue through LDS: the wave parks its 128 x 64 tile, 64 rows at a time, in its own XOR-swizzled 8 KB
   // ([64 rows][64 cols] bf16, 128-byte rows, chunk ^= row & 7) and writes full 128-byte lines.
-  static __device__ __forceinline__ void epilogue(const Params& p, Acc& acc, char* park, int wm0, int wn0, int lane) {
+  static __device__ __forceinline__ void epilogue(const Params& p, const Out& o, Acc& acc, char* park, int wm0, int wn0,
+                                                  int lane) {
     const int l31 = lane & 31, hi = lane >> 5;
     float bias_v[2][4][4];
     if (p.bias != nullptr) {
@@ -624,7 +930,7 @@ struct Kernel {
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const int n = min(wn0 + j * 32 + 8 * g + 4 * hi, p.N - 4);    // (columns >= N are never stored)
+          const int n = min(wn0 + j * 32 + 8 * g + 4 * hi, o.N - 4);    // (columns >= N are never stored)
           const uint2 w = *reinterpret_cast<const uint2*>(p.bias + n);
           bias_v[j][g][0] = __uint_as_float(w.x << 16);
           bias_v[j][g][1] = __uint_as_float(w.x & 0xffff0000u);
@@ -663,8 +969,8 @@ struct Kernel {
         const u32x4_t pv = *reinterpret_cast<const u32x4_t*>(park + row * 128 + ((c ^ (row & 7)) << 4));
         uint4 v = make_uint4(pv.x, pv.y, pv.z, pv.w);
         const int m = wm0 + half * 64 + row, n = wn0 + c * 8;
-        if (m < p.M && n < p.N) {                            // N is a multiple of 8 (checked by the host)
-          bf16_t* dst = p.C + (long long)m * p.ldc + n;
+        if (m < o.M && n < o.N) {                            // N is a multiple of 8 (checked by the host)
+          bf16_t* dst = o.C + (long long)m * o.ldc + n;
           if (acc_c) {
             Vec16<bf16_t> o, nw;
             o.load(dst);
@@ -701,7 +1007,7 @@ struct Kernel {
             w[e2] = lo | (hi16 << 16);
           }
           const int n = wn0 + n_l, m = wm0 + half * 64 + mg * 8;
-          if (n < p.N && m < p.M)     // M is a multiple of 8 when a transposed copy is requested (host check)
+          if (n < o.N && m < o.M)     // M is a multiple of 8 when a transposed copy is requested (host check)
             *reinterpret_cast<uint4*>(p.Ct + (long long)n * p.ldct + m) = make_uint4(w[0], w[1], w[2], w[3]);
         }
       }
@@ -709,10 +1015,11 @@ struct Kernel {
   }
 };
 
-template <bool AK, bool BK, int PLACE, int ASYM, int ILV, bool HAS_CT, bool SPLITK = false, bool OUT_F32 = false>
+template <bool AK, bool BK, int PLACE, int ASYM, int ILV, bool HAS_CT, bool SPLITK = false, bool OUT_F32 = false,
+          int EPI = EPI_PLAIN>
 __global__ __launch_bounds__(NT, 2) void gemm_kernel(const Params p) {
   __shared__ __attribute__((aligned(1024))) char smem[LDS_BYTES];
-  Kernel<AK, BK, PLACE, ASYM, ILV, HAS_CT, SPLITK, OUT_F32>::run(p, smem);
+  Kernel<AK, BK, PLACE, ASYM, ILV, HAS_CT, SPLITK, OUT_F32, EPI>::run(p, smem);
 }
 
 // ws[S][ntiles][256 x 256] fp32 partial sums -> C = bf16(sum_s ws[s] (+ bias) (+ C)) on the tiles [tile0, tile0 + ntiles);
@@ -720,7 +1027,9 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const Params p) {
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int S, int M, int N, int nbm,
                                                             int nbn, int tile0, int ntiles, bf16_t* __restrict__ C,
                                                             long long ldc, const bf16_t* __restrict__ bias,
-                                                            int accumulate, int out_f32) {
+                                                            int accumulate, int out_f32,
+                                                            const float* __restrict__ bias_ws,
+                                                            bf16_t* __restrict__ bias_out) {
   const int t = blockIdx.x >> 5, part = blockIdx.x & 31;
   int tm, tn;
   tile_of_block(tile0 + t, nbm, nbn, tm, tn);
@@ -728,6 +1037,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   const int lm = idx >> 5, ln = (idx & 31) * 8;
   const int m = tm * BM + lm, n = tn * BN + ln;
   if (m >= M || n >= N) return;
+  if (bias_out != nullptr && tn == 0 && ln == 0) {          // EPI_BIASG: the units' partial column sums of A, row m
+    float b = 0.f;
+    for (int sp = 0; sp < S; ++sp) b += bias_ws[(long long)sp * (nbm * BM) + m];
+    bias_out[m] = f2bf(b);
+  }
   float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const float* src = ws + (long long)t * (BM * BN) + lm * BN + ln;
   const long long slab = (long long)ntiles * (BM * BN);
@@ -829,11 +1143,27 @@ static int launch_variant(int variant, dim3 grid, hipStream_t st, Params p) {
 #else
   {
     p.stages = stages64;
-    if (p.splitk > 1) {
+    if (p.bias_out != nullptr) {                   // weight gradient + bias gradient (EPI_BIASG)
+      if constexpr (AK && BK && !HAS_CT) {
+        if (p.splitk > 1) {
+          hipLaunchKernelGGL((gemm_kernel<true, true, DPL, DAS, DIL, false, true, false, EPI_BIASG>), grid, dim3(NT), 0, st, p);
+          hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)p.ntiles * 32u), dim3(256), 0, st, p.ws, p.splitk, p.M,
+                             p.N, p.nbm, p.nbn, p.tile0, p.ntiles, p.C, p.ldc, p.bias, p.accumulate, p.c_f32,
+                             (const float*)p.bias_ws, p.bias_out);
+        } else if (p.c_f32) {
+          hipLaunchKernelGGL((gemm_kernel<true, true, DPL, DAS, DIL, false, false, true, EPI_BIASG>), grid, dim3(NT), 0, st, p);
+        } else {
+          hipLaunchKernelGGL((gemm_kernel<true, true, DPL, DAS, DIL, false, false, false, EPI_BIASG>), grid, dim3(NT), 0, st, p);
+        }
+      } else {
+        return -1;
+      }
+    } else if (p.splitk > 1) {
       if constexpr (!HAS_CT) {
         hipLaunchKernelGGL((gemm_kernel<AK, BK, DPL, DAS, DIL, false, true>), grid, dim3(NT), 0, st, p);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)p.ntiles * 32u), dim3(256), 0, st, p.ws, p.splitk, p.M,
-                           p.N, p.nbm, p.nbn, p.tile0, p.ntiles, p.C, p.ldc, p.bias, p.accumulate, p.c_f32);
+                           p.N, p.nbm, p.nbn, p.tile0, p.ntiles, p.C, p.ldc, p.bias, p.accumulate, p.c_f32,
+                           (const float*)nullptr, (bf16_t*)nullptr);
       } else {
         return -1;
       }
@@ -874,8 +1204,12 @@ int tn_gemm_get_persistent(void) { return g_persistent; }
 static int gemm_launch(const void* const* A, const void* const* B, const long long* lda, const long long* ldb,
                        const int* K, int nseg, int a_kmaj, int b_kmaj, void* C, void* Ct, const void* bias, int M, int N,
                        long long ldc, long long ldct, int accumulate, int splitk, int tail_only, void* workspace,
-                       long long workspace_bytes, void* stream, int c_f32 = 0) {
+                       long long workspace_bytes, void* stream, int c_f32 = 0, void* bias_grad = nullptr) {
   using namespace tn::gemm;
+  if (bias_grad != nullptr && (!(a_kmaj && b_kmaj) || nseg != 1 || Ct != nullptr || bias != nullptr || tail_only ||
+                               ((uintptr_t)bias_grad & 1) || TN_GEMM_DEFAULT_VARIANT >= 1000 ||
+                               getenv("TN_GEMM_VARIANT") != nullptr))
+    return TN_EINVAL;
   if (M <= 0 || N <= 0 || nseg < 1 || nseg > MAXSEG || (N % 8) != 0) return TN_EINVAL;
   if ((ldc % 8) || ldc < N || ((uintptr_t)C & 15)) return TN_EINVAL;
   if (c_f32 && (!(a_kmaj && b_kmaj) || nseg != 1 || Ct != nullptr || bias != nullptr || tail_only ||
@@ -883,6 +1217,7 @@ static int gemm_launch(const void* const* A, const void* const* B, const long lo
     return TN_EINVAL;
   if (a_kmaj && (M % 8)) return TN_EINVAL;
   Params p;
+  p = Params{};
   p.stages = 0;
   for (int s = 0; s < nseg; ++s) {
     const int k = K[s];
@@ -946,13 +1281,16 @@ static int gemm_launch(const void* const* A, const void* const* B, const long lo
       main_tiles = p.ntiles / ncu * ncu;
       if (main_tiles <= 0 || main_tiles >= p.ntiles) return TN_EINVAL;
     }
+    const long long slabs = (long long)splitk * (p.ntiles - main_tiles) * BM * BN;      // floats
     if (workspace == nullptr || ((uintptr_t)workspace & 15) ||
-        workspace_bytes < (long long)splitk * (p.ntiles - main_tiles) * BM * BN * (long long)sizeof(float))
+        workspace_bytes < (slabs + (bias_grad ? (long long)splitk * p.nbm * BM : 0)) * (long long)sizeof(float))
       return TN_EINVAL;
     p.splitk = splitk;
     p.kchunk = (p.stages + splitk - 1) / splitk;
     p.ws = (float*)workspace;
+    p.bias_ws = bias_grad ? (float*)workspace + slabs : nullptr;     // [splitk][nbm * 256] partial column sums
   }
+  p.bias_out = (tn::bf16_t*)bias_grad;
   const char* pe = getenv("TN_GEMM_PERSIST");        // (the environment wins: kernel-development A/B)
   const bool persist = pe ? atoi(pe) != 0 : g_persistent != 0;
   hipStream_t st = (hipStream_t)stream;
@@ -1016,6 +1354,242 @@ int tn_gemm_bf16_wgrad_f32(const void* A, const void* B, long long lda, long lon
                            void* stream) {
   return gemm_launch(&A, &B, &lda, &ldb, &K, 1, 1, 1, C, nullptr, nullptr, M, N, ldc, 0, accumulate,
                      splitk > 1 ? splitk : 1, 0, workspace, workspace_bytes, stream, 1);
+}
+
+namespace {
+
+constexpr int kDPL = (TN_GEMM_DEFAULT_VARIANT % 1000) / 100, kDAS = (TN_GEMM_DEFAULT_VARIANT / 10) % 10,
+              kDIL = TN_GEMM_DEFAULT_VARIANT % 10;
+
+int num_cus() {
+  static const int ncu = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n >= 8 ? n / 8 * 8 : 8;
+  }();
+  return ncu;
+}
+
+bool persistent_now() {
+  const char* pe = getenv("TN_GEMM_PERSIST");
+  return pe ? atoi(pe) != 0 : g_persistent != 0;
+}
+
+void clear_params(tn::gemm::Params& p) {
+  p = tn::gemm::Params{};
+  p.splitk = 1;
+  p.nseg = 1;
+}
+
+}  // namespace
+
+// Several independent products of ONE operand mode in one persistent launch (`ngrp` = 1..3; product g:
+// C_g[M_g, N_g] (+)= opA_g · opB_g^T, one segment each, no bias).  What it is for: the MLP's three weight gradients are 688
+// output tiles each = 2.69 rounds on 256 CUs, i.e. three launches idle a third of the chip in their last rounds; as one
+// tile list they are 2064 tiles = 8 whole rounds + 16.  That remainder (tiles mod CUs, when it is at most half the CUs and
+// the contraction is >= 16 stages deep) runs split-K — `workspace` >= tn_gemm_grouped_workspace_bytes(...) — so it costs
+// a fraction of a round instead of a whole one.  c_f32: fp32 outputs (ldc in floats; both operands contraction-major).
+long long tn_gemm_grouped_workspace_bytes(const int* M, const int* N, const int* K, int ngrp) {
+  using namespace tn::gemm;
+  if (ngrp < 1 || ngrp > MAXSEG) return -1;
+  long long tiles = 0;
+  int min_stages = 0x7fffffff;
+  for (int g = 0; g < ngrp; ++g) {
+    tiles += (long long)((M[g] + BM - 1) / BM) * ((N[g] + BN - 1) / BN);
+    min_stages = min(min_stages, (K[g] + 63) / 64);
+  }
+  const int ncu = num_cus();
+  const int r = (int)(tiles % ncu);
+  if (tiles <= ncu || r == 0 || r * 2 > ncu || min_stages < 16) return 0;
+  const int S = min(ncu / r, min_stages / 8);
+  return S > 1 ? (long long)S * r * BM * BN * (long long)sizeof(float) : 0;
+}
+
+int tn_gemm_bf16_grouped(const void* const* A, const void* const* B, const long long* lda, const long long* ldb,
+                         const int* K, void* const* C, const long long* ldc, const int* M, const int* N, int ngrp,
+                         int a_kmaj, int b_kmaj, int accumulate, int c_f32, void* workspace, long long workspace_bytes,
+                         void* stream) {
+  using namespace tn::gemm;
+  if (ngrp < 1 || ngrp > MAXSEG) return TN_EINVAL;
+  if (!(a_kmaj && b_kmaj)) return TN_EINVAL;               // (weight-gradient mode: the one caller)
+  if (TN_GEMM_DEFAULT_VARIANT >= 1000 || getenv("TN_GEMM_VARIANT") != nullptr) return TN_EINVAL;
+  Params p;
+  clear_params(p);
+  int total = 0, min_stages = 0x7fffffff;
+  for (int g = 0; g < ngrp; ++g) {
+    const int k = K[g], m = M[g], n = N[g];
+    if (m <= 0 || n <= 0 || k <= 0 || (n % 8) || (m % 8) || (lda[g] % 8) || (ldb[g] % 8) || (ldc[g] % (c_f32 ? 4 : 8)))
+      return TN_EINVAL;
+    if (lda[g] < m || ldb[g] <= 0 || ldc[g] < n) return TN_EINVAL;
+    if (((uintptr_t)A[g] | (uintptr_t)B[g] | (uintptr_t)C[g]) & 15) return TN_EINVAL;
+    if (((long long)(k - 1) * lda[g] + m) * 2 >= 0x7fffffffLL || ((long long)(k - 1) * ldb[g] + n) * 2 >= 0x7fffffffLL)
+      return TN_EINVAL;
+    p.seg[g].A = (const tn::bf16_t*)A[g];
+    p.seg[g].B = (const tn::bf16_t*)B[g];
+    p.seg[g].lda = lda[g];
+    p.seg[g].ldb = ldb[g];
+    p.seg[g].K = k;
+    p.grp[g].C = (tn::bf16_t*)C[g];
+    p.grp[g].ldc = ldc[g];
+    p.grp[g].M = m;
+    p.grp[g].N = n;
+    p.grp[g].nbm = (m + BM - 1) / BM;
+    p.grp[g].nbn = (n + BN - 1) / BN;
+    p.grp[g].start = total;
+    p.grp[g].stages = (k + 63) / 64;
+    min_stages = min(min_stages, p.grp[g].stages);
+    total += p.grp[g].nbm * p.grp[g].nbn;
+  }
+  for (int g = ngrp; g < MAXSEG; ++g) {
+    p.seg[g] = p.seg[0];
+    p.grp[g] = p.grp[0];
+    p.grp[g].start = 0x7fffffff;
+  }
+  p.ngrp = ngrp;
+  p.accumulate = accumulate;
+  p.c_f32 = c_f32;
+  const int ncu = num_cus();
+  const bool persist = persistent_now();
+  hipStream_t st = (hipStream_t)stream;
+  // the remainder of the tile list, split-K
+  int r = total % ncu, S = 1;
+  if (total > ncu && r > 0 && r * 2 <= ncu && min_stages >= 16) S = min(ncu / r, min_stages / 8);
+  if (S > 1 && (workspace == nullptr || ((uintptr_t)workspace & 15) ||
+                workspace_bytes < (long long)S * r * BM * BN * (long long)sizeof(float)))
+    S = 1;                                                  // (no workspace: the remainder runs as whole tiles)
+  const int main_tiles = S > 1 ? total - r : total;
+  p.tile0 = 0;
+  p.ntiles = main_tiles;
+  {
+    const dim3 grid(persist && main_tiles > ncu ? ncu : main_tiles);
+    if (c_f32)
+      hipLaunchKernelGGL((gemm_kernel<true, true, kDPL, kDAS, kDIL, false, false, true, EPI_GROUPED>), grid, dim3(NT), 0, st, p);
+    else
+      hipLaunchKernelGGL((gemm_kernel<true, true, kDPL, kDAS, kDIL, false, false, false, EPI_GROUPED>), grid, dim3(NT), 0, st, p);
+  }
+  if (S > 1) {
+    float* ws = (float*)workspace;
+    for (int g = 0; g < ngrp; ++g) {
+      const int end = p.grp[g].start + p.grp[g].nbm * p.grp[g].nbn;
+      const int lo = max(main_tiles, p.grp[g].start), hi = end;
+      if (lo >= hi) continue;
+      Params q;
+      clear_params(q);
+      q.seg[0] = p.seg[g];
+      q.seg[1] = q.seg[2] = q.seg[0];
+      q.M = p.grp[g].M;
+      q.N = p.grp[g].N;
+      q.C = p.grp[g].C;
+      q.ldc = p.grp[g].ldc;
+      q.accumulate = accumulate;
+      q.nbm = p.grp[g].nbm;
+      q.nbn = p.grp[g].nbn;
+      q.stages = p.grp[g].stages;
+      q.splitk = S;
+      q.kchunk = (q.stages + S - 1) / S;
+      q.ws = ws;
+      q.tile0 = lo - p.grp[g].start;
+      q.ntiles = hi - lo;
+      q.c_f32 = c_f32;
+      const int units = q.ntiles * S;
+      const dim3 grid(persist && units > ncu ? ncu : units);
+      hipLaunchKernelGGL((gemm_kernel<true, true, kDPL, kDAS, kDIL, false, true>), grid, dim3(NT), 0, st, q);
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)q.ntiles * 32u), dim3(256), 0, st, q.ws, q.splitk, q.M, q.N,
+                         q.nbm, q.nbn, q.tile0, q.ntiles, q.C, q.ldc, (const tn::bf16_t*)nullptr, q.accumulate, q.c_f32,
+                         (const float*)nullptr, (tn::bf16_t*)nullptr);
+      ws += (long long)S * q.ntiles * BM * BN;
+    }
+  }
+  TN_LAUNCH_CHECK();
+  return TN_OK;
+}
+
+// The MLP's gate and up products with the SwiGLU fused into the epilogue (transformers' LlamaMLP.forward; liger's fused
+// SwiGLU at touchnet/models/llama/__init__.py:11-15): gate[M, I] = x Wg^T, up[M, I] = x Wu^T, act = silu(gate) * up, all
+// bf16 with row pitch ldc; x [M, K] (pitch ldx), Wg / Wu [I, K] (pitch ldw).  -22 unless K % 64 == 0, I % 8 == 0, pitches % 8.
+int tn_gemm_bf16_swiglu_fwd(const void* x, const void* wg, const void* wu, void* gate, void* up, void* act, int M, int I,
+                            int K, long long ldx, long long ldw, long long ldc, void* stream) {
+  using namespace tn::gemm;
+  if (M <= 0 || I <= 0 || K <= 0 || (K % 64) || (I % 8) || (ldx % 8) || (ldw % 8) || (ldc % 8) || ldc < I) return TN_EINVAL;
+  if (((uintptr_t)x | (uintptr_t)wg | (uintptr_t)wu | (uintptr_t)gate | (uintptr_t)up | (uintptr_t)act) & 15) return TN_EINVAL;
+  if ((long long)288 * ldx * 2 >= 0x7fffffffLL || (long long)288 * ldw * 2 >= 0x7fffffffLL) return TN_EINVAL;
+  if (TN_GEMM_DEFAULT_VARIANT >= 1000 || getenv("TN_GEMM_VARIANT") != nullptr) return TN_EINVAL;
+  Params p;
+  clear_params(p);
+  p.seg[0].A = p.seg[1].A = (const tn::bf16_t*)x;
+  p.seg[0].B = (const tn::bf16_t*)wg;
+  p.seg[1].B = (const tn::bf16_t*)wu;
+  p.seg[0].lda = p.seg[1].lda = ldx;
+  p.seg[0].ldb = p.seg[1].ldb = ldw;
+  p.seg[0].K = p.seg[1].K = K;
+  p.seg[2] = p.seg[0];
+  p.stages = K / 64;
+  p.M = M;
+  p.N = I;
+  p.C = (tn::bf16_t*)gate;
+  p.C2 = (tn::bf16_t*)up;
+  p.C3 = (tn::bf16_t*)act;
+  p.ldc = ldc;
+  p.nbm = (M + BM - 1) / BM;
+  p.nbn = (I + 127) / 128;
+  p.ntiles = p.nbm * p.nbn;
+  const int ncu = num_cus();
+  const dim3 grid(persistent_now() && p.ntiles > ncu ? ncu : p.ntiles);
+  hipLaunchKernelGGL((gemm_kernel<false, false, kDPL, kDAS, kDIL, false, false, false, EPI_SWIGLU_FWD>), grid, dim3(NT), 0,
+                     (hipStream_t)stream, p);
+  TN_LAUNCH_CHECK();
+  return TN_OK;
+}
+
+// Its backward counterpart: d(act) = dY W_down (dY [M, H] pitch lddy, W_down [H, I] read contraction-major, pitch ldw) is
+// formed in the accumulators only; the epilogue reads gate / up [M, I] (pitch ld) and writes d(gate), d(up) (pitch ld).
+// -22 unless H % 64 == 0, I % 8 == 0, pitches % 8.
+int tn_gemm_bf16_swiglu_bwd(const void* dy, const void* wd, const void* gate, const void* up, void* dgate, void* dup,
+                            int M, int I, int H, long long lddy, long long ldw, long long ld, void* stream) {
+  using namespace tn::gemm;
+  if (M <= 0 || I <= 0 || H <= 0 || (H % 64) || (I % 8) || (lddy % 8) || (ldw % 8) || (ld % 8) || ld < I) return TN_EINVAL;
+  if (((uintptr_t)dy | (uintptr_t)wd | (uintptr_t)gate | (uintptr_t)up | (uintptr_t)dgate | (uintptr_t)dup) & 15)
+    return TN_EINVAL;
+  if ((long long)288 * lddy * 2 >= 0x7fffffffLL || ldw < I || ((long long)(H - 1) * ldw + I) * 2 >= 0x7fffffffLL)
+    return TN_EINVAL;
+  if (TN_GEMM_DEFAULT_VARIANT >= 1000 || getenv("TN_GEMM_VARIANT") != nullptr) return TN_EINVAL;
+  Params p;
+  clear_params(p);
+  p.seg[0].A = (const tn::bf16_t*)dy;
+  p.seg[0].B = (const tn::bf16_t*)wd;
+  p.seg[0].lda = lddy;
+  p.seg[0].ldb = ldw;
+  p.seg[0].K = H;
+  p.seg[1] = p.seg[2] = p.seg[0];
+  p.stages = H / 64;
+  p.M = M;
+  p.N = I;
+  p.C = (tn::bf16_t*)dgate;
+  p.C2 = (tn::bf16_t*)dup;
+  p.E1 = (const tn::bf16_t*)gate;
+  p.E2 = (const tn::bf16_t*)up;
+  p.ldc = p.lde = ld;
+  p.nbm = (M + BM - 1) / BM;
+  p.nbn = (I + BN - 1) / BN;
+  p.ntiles = p.nbm * p.nbn;
+  const int ncu = num_cus();
+  const dim3 grid(persistent_now() && p.ntiles > ncu ? ncu : p.ntiles);
+  hipLaunchKernelGGL((gemm_kernel<false, true, kDPL, kDAS, kDIL, false, false, false, EPI_SWIGLU_BWD>), grid, dim3(NT), 0,
+                     (hipStream_t)stream, p);
+  TN_LAUNCH_CHECK();
+  return TN_OK;
+}
+
+// Weight gradient AND bias gradient of a linear layer y = x W^T + b in one launch: C[M, N] (bf16, or float when c_f32;
+// += when accumulate) = A[K, M]^T . B[K, N] and bias_grad[M] (bf16) = column sums of A — A = dY [tokens, M], B = x [tokens, N]
+// as stored.  The sums come from the A fragments the matrix pipe reads anyway (EPI_BIASG above): no separate pass over dY.
+// splitk >= 2: split-K through `workspace` (>= (splitk * tiles * 65536 + splitk * ceil(M / 256) * 256) * 4 bytes).
+int tn_gemm_bf16_wgrad_bias(const void* A, const void* B, long long lda, long long ldb, int K, void* C, void* bias_grad,
+                            int M, int N, long long ldc, int accumulate, int c_f32, int splitk, void* workspace,
+                            long long workspace_bytes, void* stream) {
+  if (bias_grad == nullptr) return TN_EINVAL;
+  return gemm_launch(&A, &B, &lda, &ldb, &K, 1, 1, 1, C, nullptr, nullptr, M, N, ldc, 0, accumulate,
+                     splitk > 1 ? splitk : 1, 0, workspace, workspace_bytes, stream, c_f32, bias_grad);
 }
 
 // C[M,N] = A[M,K] · B[N,K]^T (+ bias) (+ C if accumulate); optional transposed copy Ct[N,M]: the round-2 entry point,

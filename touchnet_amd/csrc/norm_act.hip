@@ -417,7 +417,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
 // ------------------------------------------------------------------------------------------
 // Element-wise: SwiGLU and exact (erf) GELU, forward and backward, 16-byte vectors, grid-stride.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+__device__ __forceinline__ float sigmoidf_(float x) { return sigmoid_fast(x); }   // (common.h: shared with the GEMM epilogues)
 
 template <typename T>
 __global__ __launch_bounds__(256) void swiglu_fwd_kernel(const T* __restrict__ gate, const T* __restrict__ up,

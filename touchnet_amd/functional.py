@@ -436,7 +436,7 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = Non
 
 def gemm(segs, a_kmaj: bool = False, b_kmaj: bool = False, bias: Optional[torch.Tensor] = None,
          out: Optional[torch.Tensor] = None, accumulate: bool = False,
-         out_t: Optional[torch.Tensor] = None) -> torch.Tensor:
+         out_t: Optional[torch.Tensor] = None, bias_grad: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``out[M, N] = sum_s opA_s @ opB_s^T (+ bias) (+ out)`` on the hand-written MFMA kernel (csrc/gemm.hip), fp32
     accumulation over all segments, one rounding.  ``segs`` = 1..3 pairs ``(a, b)`` of bf16 device matrices with
     contiguous rows AS STORED: ``a`` is [M, K] (``a_kmaj=False``) or [K, M] (``a_kmaj=True``: the contraction index is the
@@ -444,7 +444,9 @@ def gemm(segs, a_kmaj: bool = False, b_kmaj: bool = False, bias: Optional[torch.
         forward          gemm([(x, W)])                          x [M, K], W [N, K]
         input gradient   gemm([(dy, W)], b_kmaj=True)            dy [M, N] · W [N, K]      (contraction over N)
         weight gradient  gemm([(dy, x)], True, True)             dy [M, N]^T · x [M, K]    (contraction over tokens)
-    — none of them needs a transposed copy of an operand."""
+    — none of them needs a transposed copy of an operand.
+    ``bias_grad`` (weight-gradient mode, one segment): a bf16 [M] vector that receives the column sums of ``a`` — the bias
+    gradient dY.sum(0) — from the same launch (tn_gemm_bf16_wgrad_bias): no separate pass over dY."""
     if not 1 <= len(segs) <= 3:
         raise _C.KernelError("gemm: 1..3 segments")
     for a, b in segs:
@@ -475,7 +477,15 @@ def gemm(segs, a_kmaj: bool = False, b_kmaj: bool = False, bias: Optional[torch.
         split = split_k(M, N, Ks[0], True, True) if SPLIT_K else 1
         ws = None
         if split > 1:
-            ws = torch.empty(split * ((M + 255) // 256) * ((N + 255) // 256) * 65536, dtype=torch.float32, device=a0.device)
+            ws = torch.empty(split * (((M + 255) // 256) * ((N + 255) // 256) * 65536 + (M + 255) // 256 * 256),
+                             dtype=torch.float32, device=a0.device)
+        if bias_grad is not None:
+            _check_bias_grad(bias_grad, M, a0)
+            _C.check(_C.lib().tn_gemm_bf16_wgrad_bias(_p(a0), _p(b0), a0.stride(0), b0.stride(0), Ks[0], _p(out), _p(bias_grad),
+                                                      M, N, out.stride(0), int(accumulate), 1, split, _p(ws),
+                                                      ws.numel() * 4 if ws is not None else 0, _cur()),
+                     "tn_gemm_bf16_wgrad_bias")
+            return out
         _C.check(_C.lib().tn_gemm_bf16_wgrad_f32(_p(a0), _p(b0), a0.stride(0), b0.stride(0), Ks[0], _p(out), M, N,
                                                  out.stride(0), int(accumulate), split, _p(ws),
                                                  ws.numel() * 4 if ws is not None else 0, _cur()), "tn_gemm_bf16_wgrad_f32")
@@ -488,6 +498,19 @@ def gemm(segs, a_kmaj: bool = False, b_kmaj: bool = False, bias: Optional[torch.
     if not a0.is_cuda:
         raise _C.KernelError("touchnet_amd kernels need device (HIP) tensors; got a CPU tensor")
     split, tail = 1, 0
+    if bias_grad is not None:
+        if not (a_kmaj and b_kmaj and n == 1 and bias is None and out_t is None):
+            raise _C.KernelError("gemm: bias_grad exists for the single-segment weight-gradient mode only")
+        _check_bias_grad(bias_grad, M, a0)
+        split = split_k(M, N, Ks[0], True, True) if SPLIT_K else 1
+        ws = None
+        if split > 1:
+            ws = torch.empty(split * (((M + 255) // 256) * ((N + 255) // 256) * 65536 + (M + 255) // 256 * 256),
+                             dtype=torch.float32, device=a0.device)
+        _C.check(_C.lib().tn_gemm_bf16_wgrad_bias(_p(a0), _p(b0), a0.stride(0), b0.stride(0), Ks[0], _p(out), _p(bias_grad), M,
+                                                  N, out.stride(0), int(accumulate), 0, split, _p(ws),
+                                                  ws.numel() * 4 if ws is not None else 0, _cur()), "tn_gemm_bf16_wgrad_bias")
+        return out
     if n == 1 and out_t is None and SPLIT_K:
         split = split_k(M, N, Ks[0], a_kmaj, b_kmaj)
         if split == 1 and TAIL_SPLIT:
@@ -511,6 +534,87 @@ def gemm(segs, a_kmaj: bool = False, b_kmaj: bool = False, bias: Optional[torch.
                                    _cur()), "tn_gemm_bf16")
     return out
 
+
+def _check_bias_grad(bias_grad, M, like):
+    if (bias_grad.dtype != torch.bfloat16 or bias_grad.dim() != 1 or bias_grad.numel() != M or not bias_grad.is_contiguous()
+            or bias_grad.device != like.device):
+        raise _C.KernelError("gemm: bias_grad must be a contiguous bf16 [M] device vector")
+
+
+def gemm_grouped_wgrad(pairs, outs=None, accumulate: bool = False):
+    """``out_g[M_g, N_g] (+)= a_g^T @ b_g`` for 1..3 independent pairs of bf16 device matrices stored [K_g, M_g] / [K_g, N_g]
+    (contraction-major: the weight gradients dY^T x of linear layers) as ONE persistent launch of the hand-written kernel
+    (tn_gemm_bf16_grouped): the tile lists of the products are concatenated, so that only the remainder of the WHOLE list
+    — not of every product — is left for a partial last round, and that remainder runs split-K.  ``outs``: bf16 or fp32
+    [M_g, N_g] matrices (all of one dtype) to write (or, ``accumulate``, to add to); default new bf16 tensors."""
+    import ctypes as C
+    n = len(pairs)
+    if not 1 <= n <= 3:
+        raise _C.KernelError("gemm_grouped_wgrad: 1..3 products")
+    for a, b in pairs:
+        if (a.dim() != 2 or b.dim() != 2 or a.dtype != torch.bfloat16 or b.dtype != torch.bfloat16 or a.stride(1) != 1
+                or b.stride(1) != 1 or a.shape[0] != b.shape[0] or not a.is_cuda):
+            raise _C.KernelError("gemm_grouped_wgrad: pairs of 2-D bf16 device matrices [K, M] / [K, N] with contiguous rows")
+    if outs is None:
+        if accumulate:
+            raise _C.KernelError("gemm_grouped_wgrad: accumulate needs `outs`")
+        outs = [torch.empty(a.shape[1], b.shape[1], dtype=torch.bfloat16, device=a.device) for a, b in pairs]
+    f32 = outs[0].dtype == torch.float32
+    for o, (a, b) in zip(outs, pairs):
+        if (o.dtype != outs[0].dtype or o.dtype not in (torch.float32, torch.bfloat16) or o.stride(1) != 1
+                or tuple(o.shape) != (a.shape[1], b.shape[1])):
+            raise _C.KernelError("gemm_grouped_wgrad: bad `outs`")
+    Ms = (C.c_int * n)(*[a.shape[1] for a, _ in pairs])
+    Ns = (C.c_int * n)(*[b.shape[1] for _, b in pairs])
+    Ks = (C.c_int * n)(*[a.shape[0] for a, _ in pairs])
+    need = int(_C.lib().tn_gemm_grouped_workspace_bytes(Ms, Ns, Ks, n))
+    ws = torch.empty(need // 4, dtype=torch.float32, device=outs[0].device) if need > 0 else None
+    Ap = (C.c_void_p * n)(*[a.data_ptr() for a, _ in pairs])
+    Bp = (C.c_void_p * n)(*[b.data_ptr() for _, b in pairs])
+    Cp = (C.c_void_p * n)(*[o.data_ptr() for o in outs])
+    la = (C.c_longlong * n)(*[a.stride(0) for a, _ in pairs])
+    lb = (C.c_longlong * n)(*[b.stride(0) for _, b in pairs])
+    lc = (C.c_longlong * n)(*[o.stride(0) for o in outs])
+    _C.check(_C.lib().tn_gemm_bf16_grouped(Ap, Bp, la, lb, Ks, Cp, lc, Ms, Ns, n, 1, 1, int(accumulate), int(f32), _p(ws),
+                                           need, _cur()), "tn_gemm_bf16_grouped")
+    return list(outs)
+
+
+def gemm_swiglu_fwd(x2: torch.Tensor, w_gate: torch.Tensor, w_up: torch.Tensor):
+    """``(gate, up, act)`` with gate = x2 @ w_gate^T, up = x2 @ w_up^T, act = silu(gate) * up from ONE launch of the
+    hand-written kernel whose epilogue applies the SwiGLU (tn_gemm_bf16_swiglu_fwd; bit-identical to the two products
+    followed by `swiglu`)."""
+    M, K = x2.shape
+    I = w_gate.shape[0]
+    if not _bf16_rows(x2, w_gate, w_up) or w_up.shape != w_gate.shape or w_gate.shape[1] != K or w_gate.stride(0) != w_up.stride(0):
+        raise _C.KernelError("gemm_swiglu_fwd: bf16 device matrices x [M, K], w_gate / w_up [I, K] of one row pitch")
+    gate, up, act = (torch.empty(M, I, dtype=torch.bfloat16, device=x2.device) for _ in range(3))
+    _C.check(_C.lib().tn_gemm_bf16_swiglu_fwd(_p(x2), _p(w_gate), _p(w_up), _p(gate), _p(up), _p(act), M, I, K, x2.stride(0),
+                                              w_gate.stride(0), I, _cur()), "tn_gemm_bf16_swiglu_fwd")
+    return gate, up, act
+
+
+def gemm_swiglu_bwd(dy2: torch.Tensor, w_down: torch.Tensor, gate: torch.Tensor, up: torch.Tensor):
+    """``(d_gate, d_up)`` of act = silu(gate) * up for d(act) = dy2 @ w_down (w_down [H, I] read contraction-major): one
+    launch, d(act) never reaches HBM (tn_gemm_bf16_swiglu_bwd; bit-identical to the product followed by `swiglu_bwd`)."""
+    M, H = dy2.shape
+    I = w_down.shape[1]
+    if (not _bf16_rows(dy2, w_down, gate, up) or w_down.shape[0] != H or tuple(gate.shape) != (M, I) or gate.shape != up.shape
+            or gate.stride(0) != up.stride(0)):
+        raise _C.KernelError("gemm_swiglu_bwd: bf16 device matrices dy [M, H], w_down [H, I], gate / up [M, I]")
+    dgate = torch.empty(M, I, dtype=torch.bfloat16, device=dy2.device)
+    dup = torch.empty(M, I, dtype=torch.bfloat16, device=dy2.device)
+    if gate.stride(0) != I:
+        raise _C.KernelError("gemm_swiglu_bwd: gate / up must be dense [M, I]")
+    _C.check(_C.lib().tn_gemm_bf16_swiglu_bwd(_p(dy2), _p(w_down), _p(gate), _p(up), _p(dgate), _p(dup), M, I, H,
+                                              dy2.stride(0), w_down.stride(0), I, _cur()), "tn_gemm_bf16_swiglu_bwd")
+    return dgate, dup
+
+
+# A/B switches of the round-5 fusions (measurements; both default on): SwiGLU inside the gate/up and down-dgrad epilogues,
+# the MLP's three weight gradients as one grouped launch
+MLP_EPILOGUE = os.environ.get("TN_MLP_EPILOGUE", "1") != "0"
+GROUPED_WGRAD = os.environ.get("TN_GROUPED_WGRAD", "1") != "0"
 
 SPLIT_K = os.environ.get("TN_GEMM_SPLITK", "1") != "0"      # (A/B switch)
 # Tail split (only the last partial round of tiles is split): measured NEUTRAL-TO-NEGATIVE on the step (747.9 / 751.9 ms with,
@@ -629,13 +733,17 @@ def _dgrad(dys, ws) -> Optional[torch.Tensor]:
     return dx
 
 
-def _wgrad(dy, x2) -> Optional[torch.Tensor]:
+# bias gradients dY.sum(0) from the weight-gradient launch itself (EPI_BIASG, csrc/gemm.hip) instead of a column-sum pass
+BIAS_IN_WGRAD = os.environ.get("TN_BIAS_IN_WGRAD", "1") != "0"          # (A/B switch)
+
+
+def _wgrad(dy, x2, bias_grad=None) -> Optional[torch.Tensor]:
     """dY^T x [N, K] on the hand-written kernel (both operands contraction-major: the contraction runs over tokens),
-    or None."""
+    or None.  ``bias_grad`` [N] bf16: filled with dY.sum(0) by the same launch."""
     M, N = dy.shape
     if not (_own(N, x2.shape[1], (M,), True, True) and _bf16_rows(dy, x2)):
         return None
-    return gemm([(dy, x2)], True, True)
+    return gemm([(dy, x2)], True, True, bias_grad=bias_grad)
 
 
 # Weight-gradient GEMMs on a side stream.  Nothing in the backward consumes a weight gradient, so these products can
@@ -698,7 +806,7 @@ def _beside(inputs, fn):
 GRAD_SINKS = {}          # id(weight) -> weakref to the engine (a dead engine's entries are ignored)
 
 
-def _sink_wgrad(w, dy, x2) -> bool:
+def _sink_wgrad(w, dy, x2, bias_grad=None) -> bool:
     ref = GRAD_SINKS.get(id(w))
     sink = ref() if ref is not None else None
     if sink is None or not sink.owns(w):
@@ -707,9 +815,41 @@ def _sink_wgrad(w, dy, x2) -> bool:
     if not (_own(N, x2.shape[1], (M,), True, True) and _bf16_rows(dy, x2)):
         return False
     view, acc = sink.take(w)
-    gemm([(dy, x2)], True, True, out=view, accumulate=acc)
+    gemm([(dy, x2)], True, True, out=view, accumulate=acc, bias_grad=bias_grad)
     sink.done(w)
     return True
+
+
+def _wgrad_group(items):
+    """Weight gradients dY_i^T x_i of up to three layers ``items = [(w, dy, x2), ...]`` as ONE grouped launch
+    (gemm_grouped_wgrad).  With a data-parallel engine's gradient sinks registered for ALL of them (one dtype, one
+    accumulate state) the launch writes the engine's staging views and the result is [None, ...]; with none it returns new
+    bf16 tensors; a mixed state falls back to one product per layer."""
+    def single(w, dy, x2):
+        return None if _sink_wgrad(w, dy, x2) else gemm([(dy, x2)], True, True)
+    sinks = []
+    for w, _, _ in items:
+        ref = GRAD_SINKS.get(id(w))
+        sk = ref() if ref is not None else None
+        sinks.append(sk if (sk is not None and sk.owns(w)) else None)
+    ok = all(_own(dy.shape[1], x2.shape[1], (dy.shape[0],), True, True) and _bf16_rows(dy, x2) for _, dy, x2 in items)
+    if not ok or (any(sinks) and not all(sinks)):
+        return [single(*it) for it in items]
+    pairs = [(dy, x2) for _, dy, x2 in items]
+    if not any(sinks):
+        return gemm_grouped_wgrad(pairs)
+    taken = [sk.take(w) for sk, (w, _, _) in zip(sinks, items)]
+    if len({(v.dtype, bool(acc)) for v, acc in taken}) != 1:
+        outs = []
+        for (view, acc), (w, dy, x2), sk in zip(taken, items, sinks):     # (already taken: write each view by itself)
+            gemm([(dy, x2)], True, True, out=view, accumulate=acc)
+            sk.done(w)
+            outs.append(None)
+        return outs
+    gemm_grouped_wgrad(pairs, outs=[v for v, _ in taken], accumulate=bool(taken[0][1]))
+    for sk, (w, _, _) in zip(sinks, items):
+        sk.done(w)
+    return [None] * len(items)
 
 
 def _stacked_view(ts):
@@ -784,15 +924,23 @@ class _LinearGroup(torch.autograd.Function):
                     dx.addmm_(d, w)
             dx = dx.view(x.shape)
         dws = [None] * n
+        need_b = [hb and ctx.needs_input_grad[4 + n + i] for i, hb in enumerate(ctx.has_bias)]
+        dbs = [None] * n
         if any(need_w):
             sunk = set()
             if own:
                 x2c = _c(x2)
                 for i, (d, nw) in enumerate(zip(dys, need_w)):
-                    if nw and _beside((d, x2c), lambda: _sink_wgrad(ws[i], d, x2c)):
+                    # the bias gradient rides on the weight-gradient launch (column sums of the dY fragments it reads anyway)
+                    bg = (torch.empty(Ns[i], dtype=x.dtype, device=x.device)
+                          if (nw and need_b[i] and BIAS_IN_WGRAD and not os.environ.get("TN_GEMM_VARIANT")) else None)
+                    if nw and _beside((d, x2c), lambda: _sink_wgrad(ws[i], d, x2c, bg)):
                         sunk.add(i)
+                        dbs[i] = bg
                     elif nw:
-                        dws[i] = _beside((d, x2c), lambda: _wgrad(d, x2c))
+                        dws[i] = _beside((d, x2c), lambda: _wgrad(d, x2c, bg))
+                        if dws[i] is not None:
+                            dbs[i] = bg
             todo = [i for i in range(n) if need_w[i] and dws[i] is None and i not in sunk]
             if not todo:
                 pass
@@ -817,8 +965,7 @@ class _LinearGroup(torch.autograd.Function):
             else:
                 dws = [torch.mm(d.t(), x2) for d in dys]
             dws = [g if nw else None for g, nw in zip(dws, need_w)]
-        dbs = [column_sum(d) if (hb and ctx.needs_input_grad[4 + n + i]) else None
-               for i, (d, hb) in enumerate(zip(dys, ctx.has_bias))]
+        dbs = [b if (b is not None or not nb) else column_sum(d) for b, nb, d in zip(dbs, need_b, dys)]
         return (dx, None, None, None, *dws, *dbs)
 
 
@@ -848,15 +995,23 @@ class _SwiGLUMLP(torch.autograd.Function):
         x2 = _c(x.reshape(-1, K))
         M = x2.shape[0]
         own = _own(M, I, (K,)) and _own(M, K, (I,)) and _own(I, K, (M,), True, True) and _own(K, I, (M,), True, True)
-        gate, up = _mm_tn(x2, _c(wg)), _mm_tn(x2, _c(wu))
-        if own:
+        fused = (own and MLP_EPILOGUE and K % 64 == 0 and _bf16_rows(x2, wg, wu, wd) and wg.stride(0) == wu.stride(0)
+                 and not os.environ.get("TN_GEMM_VARIANT"))
+        if fused:
+            gate, up, act = gemm_swiglu_fwd(x2, wg, wu)       # SwiGLU in the epilogue of ONE gate + up launch
+            kept = act
+        else:
+            gate, up = _mm_tn(x2, _c(wg)), _mm_tn(x2, _c(wu))
+        if fused:
+            pass
+        elif own:
             act = L.swiglu_fwd(gate, up)
             kept = act
         else:
             act, kept = L.swiglu_fwd_t(gate, up)                       # kept = act^T
         y = _mm_tn(act, _c(wd))
         ctx.save_for_backward(x2, gate, up, kept, wg, wu, wd)
-        ctx.xshape, ctx.own = x.shape, own
+        ctx.xshape, ctx.own, ctx.fused = x.shape, own, fused
         return y.view(*x.shape[:-1], wd.shape[0])
 
     @staticmethod
@@ -867,12 +1022,22 @@ class _SwiGLUMLP(torch.autograd.Function):
         dy2 = _c(dy).reshape(M, H)
         nx, ng, nu, nd = ctx.needs_input_grad
         if ctx.own and LINEAR_GEMM == "own":
-            dwd = None if (not nd or _beside((dy2, kept), lambda: _sink_wgrad(wd, dy2, kept))) \
-                else _beside((dy2, kept), lambda: gemm([(dy2, kept)], True, True))                       # dY^T act  [H, I]
-            dact = gemm([(dy2, _c(wd))], b_kmaj=True)                                  # dY W_down [M, I]
-            dgate, dup = L.swiglu_bwd(dact, gate, up)
-            del dact
+            grouped = GROUPED_WGRAD and ng and nu and nd and not os.environ.get("TN_GEMM_VARIANT")
+            if not grouped:
+                dwd = None if (not nd or _beside((dy2, kept), lambda: _sink_wgrad(wd, dy2, kept))) \
+                    else _beside((dy2, kept), lambda: gemm([(dy2, kept)], True, True))                   # dY^T act  [H, I]
+            if ctx.fused and H % 64 == 0 and _bf16_rows(dy2, wd):
+                dgate, dup = gemm_swiglu_bwd(dy2, wd, gate, up)     # d(act) = dY W_down lives in the accumulators only
+            else:
+                dact = gemm([(dy2, _c(wd))], b_kmaj=True)                              # dY W_down [M, I]
+                dgate, dup = L.swiglu_bwd(dact, gate, up)
+                del dact
             dx = gemm([(dgate, _c(wg)), (dup, _c(wu))], b_kmaj=True).view(ctx.xshape) if nx else None
+            if grouped:
+                # ONE launch for the three weight gradients (3 x 688 tiles = 8 whole rounds + 16 tiles split-K)
+                dwg, dwu, dwd = _beside((dgate, dup, dy2, x2, kept), lambda: _wgrad_group(
+                    [(wg, dgate, x2), (wu, dup, x2), (wd, dy2, kept)]))
+                return dx, dwg, dwu, dwd
             dwg = None if (not ng or _beside((dgate, x2), lambda: _sink_wgrad(wg, dgate, x2))) \
                 else _beside((dgate, x2), lambda: gemm([(dgate, x2)], True, True))
             dwu = None if (not nu or _beside((dup, x2), lambda: _sink_wgrad(wu, dup, x2))) \

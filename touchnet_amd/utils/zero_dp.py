@@ -110,6 +110,7 @@ class _Bucket:
         self.arrived = [False] * len(params)
         self.pending = len(params)
         self.launched = False
+        self.opened = False                              # a staging buffer has been acquired for this step
         self.reduced = None                             # event: the reduce-scatter has finished
         self.params_ready = None                        # event: the all-gather of the updated slices has finished
 
@@ -249,7 +250,8 @@ class FlatShardedDataParallel:
         if b.launched:
             raise RuntimeError(f"gradient of a parameter of bucket {b.name} arrived after its reduce-scatter was issued "
                                "(gradient accumulation over several backward passes is not supported by this engine)")
-        if b.pending == len(b.params) and not any(b.arrived):
+        if not b.opened:                                # (several views may be taken before the first `done`: a grouped
+            b.opened = True                              #  weight-gradient launch writes three of them at once)
             b.stage = self._acquire(b)
             for a, e in b.gaps:                          # (stale numbers of the buffer's previous user)
                 b.stage[a:e].zero_()
@@ -332,10 +334,10 @@ class FlatShardedDataParallel:
 
     def zero_grad(self) -> None:
         for b in self.buckets:
-            if any(b.arrived) and not b.launched and not self.identity and b not in self.rest:
+            if b.opened and not b.launched and not self.identity and b not in self.rest:
                 self._pool_free_at[b._slot] = None        # (a step that died inside its backward: give the buffer back)
             b.arrived = [False] * len(b.params)
-            b.pending, b.launched = len(b.params), False
+            b.pending, b.launched, b.opened = len(b.params), False, False
             b.shard.grad = None
             for p in b.params:
                 p.grad = None
