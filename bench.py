@@ -352,12 +352,25 @@ def executed_flops_per_gpu(wl: "Workload", trainer, layout: dict, lm_head_rows: 
     return fl
 
 
+def decoder_rows(workload: "Workload") -> int:
+    """Rows the decoder's GEMMs and row kernels run on: the non-pad slots of the packed batch (the packers'
+    `valid_rows_max`, rounded up to the GEMM tile height) when the model drops the padding slots
+    (models/llama/modeling_llama.py DecoderModel._drop_pad_rows), else all B x T."""
+    import touchnet_amd.models.llama.modeling_llama as _ml
+    full = workload.B * workload.T
+    v = getattr(workload, "tokens", {}).get("valid_rows_max") if hasattr(workload, "tokens") else None
+    if v is None or not _ml.SKIP_PAD_ROWS or not workload.job.training_enable_fused_ce:
+        return full
+    mc = min((int(v) + 255) // 256 * 256, full)
+    return mc if mc + 256 <= full else full
+
+
 def kernel_rooflines(workload: "Workload"):
     """Live HIP-event timings (on torch's current stream = the stream the C ABI is given) of the hand-written
     kernels at this workload's shapes: achieved algorithmic bytes/flops per launch vs the roofline."""
     F, dev, cfg = workload.F, workload.device, workload.seq_cfg
     B, T = workload.B, workload.T
-    N, H, I, Nh, Nkv, D = (B * T, cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads,
+    N, H, I, Nh, Nkv, D = (decoder_rows(workload), cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads,
                            cfg.num_key_value_heads, cfg.head_dim)
     bf = torch.bfloat16
     out = []
@@ -392,7 +405,9 @@ def kernel_rooflines(workload: "Workload"):
     w = torch.ones(H, dtype=bf, device=dev)
     add("add+rmsnorm fwd", t_ms(lambda: F.rms_norm(x, w, 1e-5, residual=r)), bytes_=4 * N * H * 2, per_step=2 * L_)
     g_, u_ = torch.randn(N, I, dtype=bf, device=dev), torch.randn(N, I, dtype=bf, device=dev)
-    add("swiglu fwd", t_ms(lambda: F.swiglu(g_, u_)), bytes_=3 * N * I * 2, per_step=L_)
+    fused_mlp = F.LINEAR_GEMM == "own" and F.MLP_EPILOGUE
+    add("swiglu fwd (standalone kernel; in the step it is the epilogue of the gate+up launch)" if fused_mlp else "swiglu fwd",
+        t_ms(lambda: F.swiglu(g_, u_)), bytes_=3 * N * I * 2, per_step=0 if fused_mlp else L_)
     del g_, u_
     doc = workload.tokens["attention_mask"] if hasattr(workload, "tokens") else torch.ones(B, T, device=dev)
     mask = F.build_packed_mask(doc)
@@ -420,12 +435,25 @@ def kernel_rooflines(workload: "Workload"):
     dy = torch.randn(N, I, dtype=bf, device=dev)
     du = torch.randn(N, I, dtype=bf, device=dev)
     fl1 = 2.0 * N * H * I
+    fz = own and fused_mlp
     add(f"tn::gemm fwd gate_proj [{N}x{H}]x[{I}x{H}]^T (hand-written, csrc/gemm.hip)", t_ms(lambda: F.gemm([(x, wg)])),
-        flops=fl1, per_step=3 * L_ if own else 0)     # gate, up, down forward: same flops each
+        flops=fl1, per_step=(L_ if fz else 3 * L_) if own else 0)     # down_proj (same flops); unfused: gate, up, down
     add("tn::gemm dgrad gate+up: dX = dG Wg + dU Wu, ONE two-segment launch, W read contraction-major",
         t_ms(lambda: F.gemm([(dy, wg), (du, wu)], b_kmaj=True)), flops=2 * fl1, per_step=L_ if own else 0)
+    grouped = own and F.GROUPED_WGRAD
     add("tn::gemm wgrad gate_proj: dW = dG^T X, both operands contraction-major (no transposed copies)",
-        t_ms(lambda: F.gemm([(dy, x)], True, True)), flops=fl1, per_step=3 * L_ if own else 0)
+        t_ms(lambda: F.gemm([(dy, x)], True, True)), flops=fl1, per_step=(0 if grouped else 3 * L_) if own else 0)
+    if own:
+        # the round-5 launches of the MLP (csrc/gemm.hip EPI_SWIGLU_FWD / EPI_SWIGLU_BWD / EPI_GROUPED)
+        add("tn::gemm fwd gate+up with the SwiGLU epilogue: gate, up, act = silu(gate)*up from ONE launch",
+            t_ms(lambda: F.gemm_swiglu_fwd(x, wg, wu)), flops=2 * fl1, per_step=L_ if fz else 0)
+        wd = torch.randn(H, I, dtype=bf, device=dev)
+        dyh = torch.randn(N, H, dtype=bf, device=dev)
+        add("tn::gemm d(act) = dY Wd with the SwiGLU-backward epilogue: d(gate), d(up) from ONE launch, d(act) never in HBM",
+            t_ms(lambda: F.gemm_swiglu_bwd(dyh, wd, dy, du)), flops=fl1, per_step=L_ if fz else 0)
+        add("tn::gemm wgrad gate+up+down GROUPED: three weight gradients as ONE launch, remainder of the tile list split-K",
+            t_ms(lambda: F.gemm_grouped_wgrad([(dy, x), (du, x), (dyh, dy)])), flops=3 * fl1, per_step=L_ if grouped else 0)
+        del wd, dyh
     add(f"hipBLASLt GEMM fwd gate_proj, same shape", t_ms(lambda: torch.nn.functional.linear(x, wg)),
         flops=fl1, per_step=0 if own else 3 * L_)
     wgt = F.transpose_2d(wg)
@@ -657,13 +685,15 @@ def main():
                                            else "all B*T positions"),
                        "gemm_algorithms": "TunableOp replay (touchnet_amd/tuning)" if tuned else "library default",
                        "linear_layer_gemm": ("hand-written MFMA kernel (csrc/gemm.hip): forward, input-gradient and "
-                                             "weight-gradient products in native operand modes; hipBLASLt only for "
-                                             "outputs below 96 tiles (1280 x 1280 tower weight gradients, lm_head)"
+                                             "weight-gradient products in native operand modes, SwiGLU in the gate/up and "
+                                             "down-dgrad epilogues, grouped MLP weight gradients, bias gradients from the "
+                                             "weight-gradient launches; hipBLASLt only for outputs below 96 tiles (lm_head)"
                                              if __import__("touchnet_amd.functional", fromlist=["x"]).LINEAR_GEMM == "own"
                                              else "hipBLASLt (A/B mode)")},
             "step_mfu": round(mfu, 4),
             "mfu_convention": "6*N_wo_emb + 12*L*H*Dh*T per token (touchnet/models/*/__init__.py), no causal/packing "
-                              "discount, no recompute credit, tokens = all B*T slots incl. pad",
+                              "discount, no recompute credit, tokens = all B*T slots incl. pad (the reference's tps counts "
+                              "them, train.py:345) — `roofline.frac` counts only the FLOPs that are executed",
             "nonpad_tokens_per_step_rank0": nonpad,
             "loss_per_sample_last": round(loss, 5), "hip_event_ms_per_step_rank0": round(ev_ms, 2),
             "peak_mem_GB_rank0": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
@@ -715,6 +745,14 @@ def main():
                 c = wl.seq_cfg
                 dec_attn = 3.5 * 4.0 * c.head_dim * c.num_attention_heads * allowed_pairs * c.num_hidden_layers
                 executed = (fpt - 12 * c.num_hidden_layers * c.num_attention_heads * c.head_dim * wl.T) * wl.B * wl.T + dec_attn
+                rows_run = decoder_rows(wl)
+                if rows_run < wl.B * wl.T:
+                    # the decoder's linear layers run on the non-pad slots only (padding slots dropped from the row work)
+                    dec_layer = (c.hidden_size * c.num_attention_heads * c.head_dim * 2
+                                 + 2 * c.hidden_size * c.num_key_value_heads * c.head_dim + 3 * c.hidden_size * c.intermediate_size)
+                    executed -= 6.0 * dec_layer * c.num_hidden_layers * (wl.B * wl.T - rows_run)
+                    line["config"]["decoder_rows"] = (f"{rows_run} of {wl.B * wl.T}: the non-pad slots only (packer's count "
+                                                      f"{wl.tokens.get('valid_rows_max')} rounded up to 256)")
                 if wl.name == "qwen2_audio_7b":        # (the short-utterance workload reports the formula MFU only)
                     ac = wl.model_config.audio_config
                     tower_params = sum(p.numel() for p in trainer.model.audio_tower.parameters())
@@ -728,7 +766,7 @@ def main():
                     if _ml.LAST_LAYER_LABELLED_ROWS and 2 * rows <= wl.B * wl.T:
                         # ... and so does everything behind the LAST layer's attention core (o_proj + MLP)
                         executed -= 6.0 * (c.hidden_size * c.num_attention_heads * c.head_dim
-                                           + 3 * c.hidden_size * c.intermediate_size) * (wl.B * wl.T - rows)
+                                           + 3 * c.hidden_size * c.intermediate_size) * (rows_run - rows)
                 ex_frac = executed / (step_ms * 1e-3) / MFMA_PEAK
                 line["step_mfu_executed_flops"] = round(ex_frac, 4)
                 # the roofline's primary number is the utilisation on EXECUTED flops; the reference-formula value (which

@@ -401,3 +401,73 @@ def test_kimi_audio_decoder_matches_the_reference_module(golden):
     tl, al = onn.kimi_audio_forward(sd, kw, b["audio_input_ids"], b["text_input_ids"], b["attention_mask"], b["position_ids"])
     np.testing.assert_allclose(tl[valid].numpy(), g["text_logits"][valid.numpy()], atol=3e-5)
     np.testing.assert_allclose(al[valid].numpy(), g["audio_logits"][valid.numpy()], atol=3e-5)
+
+
+@pytest.mark.parametrize("labelled", [None, 64])
+@pytest.mark.parametrize("bound", ["exact", "too_small"])
+def test_padding_slots_are_dropped_from_the_decoders_row_work_without_changing_the_step(monkeypatch, labelled, bound):
+    """`valid_rows_max` (the packers' count of non-pad slots): the decoder gathers the non-pad positions of the packed batch
+    into ONE row (document ids made unique across batch rows, count rounded up to 256 with real padding slots) and runs
+    every layer on those rows only.  Loss, accuracy and EVERY gradient equal the full computation (fp32 oracle ops) — with
+    and without the labelled-rows shortcut of the last layer; a bound below the real count poisons loss and gradients."""
+    import touchnet_amd.models.llama.modeling_llama as ml
+    torch.manual_seed(0)
+    cfg = DecoderConfig.from_dict(dict(TINY, num_hidden_layers=3))
+    model = PackedCausalLM(cfg)
+    model.post_init()
+    B, T = 3, 512
+    g = torch.Generator().manual_seed(2)
+    ids = torch.randint(1, 16, (B, T), generator=g)
+    doc = torch.zeros(B, T, dtype=torch.int64)
+    pos = torch.zeros(B, T, dtype=torch.int64)
+    labels = torch.full((B, T), -100)
+    sl = torch.ones(B, T, dtype=torch.int64)
+    # documents of uneven length; every batch row ends in padding, row 2 is mostly padding; SAME ids in different rows
+    layout = {0: [(1, 0, 150), (2, 150, 330)], 1: [(1, 0, 90), (2, 90, 95), (3, 95, 400)], 2: [(1, 0, 37)]}
+    n_sent = 0
+    for b, docs in layout.items():
+        for d, s, e in docs:
+            doc[b, s:e] = d
+            pos[b, s:e] = torch.arange(e - s)
+            k = max(e - 11, s)
+            labels[b, k:e] = torch.randint(1, 16, (e - k,), generator=g)
+            sl[b, k:e] = e - k
+            n_sent += 1
+    n_valid = int((doc > 0).sum())
+    assert n_valid == 330 + 400 + 37 and (n_valid + 255) // 256 * 256 + 256 <= B * T
+    kw = dict(input_ids=ids, position_ids=pos, attention_mask=doc, labels=labels, sentence_lens=sl, num_sentence=n_sent)
+    if labelled is not None:
+        kw["labelled_rows_max"] = int((labels != -100).sum())
+    taken = []
+    inner = ml.DecoderModel._drop_pad_rows
+    monkeypatch.setattr(ml.DecoderModel, "_drop_pad_rows",
+                        staticmethod(lambda *a: (lambda r: (taken.append(r is not None), r)[1])(inner(*a))))
+
+    def run(vmax):
+        model.zero_grad()
+        with use_ops(oops):
+            out = model(**kw, valid_rows_max=vmax)
+            out.loss.backward()
+        return out, {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    full, gfull = run(None)
+    assert not taken
+    got, ggot = run(n_valid if bound == "exact" else 500)          # 500 -> 512 rows < 767 real tokens
+    assert taken == [True]
+    if bound != "exact":
+        assert torch.isnan(got.loss) and all(bool(torch.isnan(v).any()) for v in ggot.values())
+        return
+    assert float(got.loss) == pytest.approx(float(full.loss), rel=1e-6)
+    assert float(got.acc) == float(full.acc)
+    assert gfull.keys() == ggot.keys() and len(gfull) > 20
+    for n in gfull:
+        torch.testing.assert_close(ggot[n], gfull[n], rtol=1e-5, atol=1e-7, msg=lambda m: f"{n}: {m}")
+    # a caller that asks for logits gets every position computed (no compaction), whatever the batch carries
+    taken.clear()
+    with use_ops(oops), torch.no_grad():
+        lg = model(input_ids=ids, position_ids=pos, attention_mask=doc, valid_rows_max=n_valid).logits
+    assert lg.shape == (B, T, cfg.vocab_size) and not taken
+    # nothing to save (bound within one tile row of B*T): the batch is left as it is
+    with use_ops(oops):
+        model(**kw, valid_rows_max=B * T - 100)
+    assert taken == [False]

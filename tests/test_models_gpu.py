@@ -291,6 +291,60 @@ def test_last_layer_on_labelled_rows_only_matches_full_rows_on_device(monkeypatc
         assert float((grows[n] - gfull[n]).abs().max()) / scale < 4e-2, n
 
 
+@pytest.mark.parametrize("labelled", [False, True])
+def test_dropping_the_padding_slots_matches_the_full_batch_on_device(labelled):
+    """`valid_rows_max`: the decoder runs on the non-pad slots only (one row, unique document ids, rounded up to 256 with
+    padding slots) — through the HIP kernels the step equals the full-batch step up to bf16 summation order (the CPU test
+    holds them equal to 1e-6 in fp32): loss, accuracy, every gradient."""
+    import touchnet_amd.models.llama.modeling_llama as ml
+    from touchnet_amd.models.llama import DecoderConfig, PackedCausalLM
+    torch.manual_seed(0)
+    cfg = DecoderConfig.from_dict(dict(TEXT, num_hidden_layers=3, tie_word_embeddings=False))
+    model = PackedCausalLM(cfg)
+    model.post_init()
+    model = model.to(DEV, torch.bfloat16)
+    B, T = 3, 1024
+    g = torch.Generator().manual_seed(4)
+    ids = torch.randint(1, 500, (B, T), generator=g)
+    doc = torch.zeros(B, T, dtype=torch.int64)
+    pos = torch.zeros(B, T, dtype=torch.int64)
+    labels = torch.full((B, T), -100)
+    sl = torch.ones(B, T, dtype=torch.int64)
+    n_sent = 0
+    for b, docs in {0: [(1, 0, 300), (2, 300, 790)], 1: [(1, 0, 520), (2, 520, 530), (3, 530, 900)], 2: [(1, 0, 77)]}.items():
+        for d, s0, e in docs:
+            doc[b, s0:e] = d
+            pos[b, s0:e] = torch.arange(e - s0)
+            k = max(e - 25, s0)
+            labels[b, k:e] = torch.randint(1, 500, (e - k,), generator=g)
+            sl[b, k:e] = e - k
+            n_sent += 1
+    n_valid = int((doc > 0).sum())
+    kw = {k: v.to(DEV) for k, v in dict(input_ids=ids, position_ids=pos, attention_mask=doc, labels=labels,
+                                        sentence_lens=sl).items()}
+    if labelled:
+        kw["labelled_rows_max"] = int((labels != -100).sum())
+    seen = []
+    inner = ml.DecoderModel._drop_pad_rows
+    ml.DecoderModel._drop_pad_rows = staticmethod(lambda *a: (lambda r: (seen.append(None if r is None else r[0].shape[1]), r)[1])(inner(*a)))
+    try:
+        def run(vmax):
+            model.zero_grad()
+            out = model(**kw, num_sentence=n_sent, valid_rows_max=vmax)
+            out.loss.backward()
+            return out, {n: p.grad.float().clone() for n, p in model.named_parameters()}
+        full, gfull = run(None)
+        got, ggot = run(n_valid)
+    finally:
+        ml.DecoderModel._drop_pad_rows = staticmethod(inner)
+    assert seen == [(n_valid + 255) // 256 * 256] and seen[0] < B * T - 256
+    assert abs(float(got.loss) - float(full.loss)) / abs(float(full.loss)) < 2e-3
+    assert float(got.acc) == pytest.approx(float(full.acc), abs=1e-6)
+    for n in gfull:
+        scale = float(gfull[n].abs().max().clamp_min(1e-6))
+        assert float((ggot[n] - gfull[n]).abs().max()) / scale < 4e-2, n
+
+
 def test_fsdp2_single_rank_rccl_matches_unsharded():
     """The FSDP2 path on real hardware: a 1-rank RCCL mesh (TN_FORCE_FSDP=1) must train like the unsharded model —
     fully_shard hooks around the HIP autograd functions, DTensor parameters, the fused AdamW on local shards.

@@ -244,6 +244,7 @@ class Trainer:
             for k in ("input_ids", "labels", "position_ids", "sentence_lens", "input_features", "inputs_embeds"):
                 if isinstance(out.get(k), torch.Tensor) and not (k == "input_features" and "audio_rows" in out):
                     out[k] = self.cp.shard(out[k], dim=1)
+            out.pop("valid_rows_max", None)                             # (counts the whole rows; cp keeps the padding slots)
             out["context_parallel"] = self.cp                           # attention_mask (doc ids) stays global
         return out
 

@@ -138,7 +138,7 @@ def qwen2_audio_plan(vocab: int, audio_token: int, batchsize: int, seqlen: int, 
             "attention_mask": t(doc), "sentence_lens": t(sentence_lens), "num_sentence": n_sent,
             "audio_positions": t(np.concatenate(audio_pos)),
             "audio_output_lengths": torch.tensor(lengths, dtype=torch.int64),
-            "audio_samples": samples, "labelled_rows_max": n_lab}, n_sent
+            "audio_samples": samples, "labelled_rows_max": n_lab, "valid_rows_max": int((doc > 0).sum())}, n_sent
 
 
 def qwen2_audio_long_plan(vocab: int, audio_token: int, batchsize: int, seqlen: int, seed: int = 2025,
@@ -194,7 +194,7 @@ def qwen2_audio_long_plan(vocab: int, audio_token: int, batchsize: int, seqlen: 
             "attention_mask": t(doc), "sentence_lens": t(sentence_lens), "num_sentence": n_sent,
             "audio_positions": t(np.concatenate(audio_pos)),
             "audio_output_lengths": torch.tensor(lengths, dtype=torch.int64),
-            "labelled_rows_max": n_lab}, len(lengths)
+            "labelled_rows_max": n_lab, "valid_rows_max": int((doc > 0).sum())}, len(lengths)
 
 
 def kimi_audio_plan(vocab_text: int, audio_code_base: int, n_codes: int, batchsize: int, seqlen: int, seed: int = 2025,

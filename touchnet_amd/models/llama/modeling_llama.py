@@ -106,6 +106,10 @@ class Attention(nn.Module):
         return ops().linear_group(a.view(B, T, self.num_heads * self.head_dim), [(self.o_proj.weight, None)])[0]
 
 
+# TN_SKIP_PAD_ROWS=0: keep the padding slots of a packed batch in every row-wise kernel (what the reference computes).
+SKIP_PAD_ROWS = os.environ.get("TN_SKIP_PAD_ROWS", "1") != "0"
+
+
 # TN_LAST_LAYER_LABELLED_ROWS=0: select the labelled rows in front of lm_head only (the round-2a behaviour), not in front
 # of the last layer's output projection.
 LAST_LAYER_LABELLED_ROWS = os.environ.get("TN_LAST_LAYER_LABELLED_ROWS", "1") != "0"
@@ -156,8 +160,43 @@ class DecoderModel(nn.Module):
         self.norm = RMSNorm(config.hidden_size, config.rms_norm_eps)
         self.rotary_emb = RotaryEmbedding(config)
 
+    @staticmethod
+    def _drop_pad_rows(inputs_embeds, position_ids, doc, keep_rows, valid_rows_max):
+        """The packed batch without its padding slots, as ONE row: -> (embeds [1, Mc, H], position ids [1, Mc], document
+        ids [1, Mc], keep_rows in the new numbering, `rows` = the flat B*T position of every kept slot, overflow flag) or
+        None when nothing would be saved.
+
+        The packers fill rows greedily, so a batch ends every row with padding (Qwen2-Audio ASR: 3-4 % of B x T).  The
+        reference runs every layer on those slots and then ignores them: flex_attention gives them no key and no output
+        (document id 0), every other op acts per position, their labels are -100.  Here the non-pad slots are gathered
+        (batch rows one behind the other; document ids made unique across batch rows so that the document mask keeps them
+        apart), the row count is rounded up to the GEMM tile height with real padding slots (document id 0: same
+        semantics), and all GEMMs / row kernels / attention tiles of the decoder run on Mc < B*T rows.  Results on the
+        non-pad positions are what the full computation gives.  `valid_rows_max` is the packers' count of non-pad slots
+        (a host int: static shapes, no synchronisation); a bound that is too small is reported through the returned
+        flag and poisons the output."""
+        B, T, H = inputs_embeds.shape
+        Mc = min((int(valid_rows_max) + 255) // 256 * 256, B * T)
+        if Mc + 256 > B * T:
+            return None
+        flat = doc.reshape(-1)
+        is_pad = flat <= 0
+        # non-pad positions first (in their order), padding slots behind them: a permutation, so no index repeats
+        order = torch.sort(is_pad.to(torch.int8), stable=True).indices
+        rows = order[:Mc]
+        overflow = (~is_pad).sum() > Mc
+        uniq = doc.to(torch.int64) + (torch.arange(B, device=doc.device, dtype=torch.int64) * (T + 1))[:, None]
+        doc_c = torch.where(is_pad, torch.zeros_like(flat, dtype=torch.int64), uniq.reshape(-1)).index_select(0, rows)[None]
+        emb_c = inputs_embeds.reshape(B * T, H).index_select(0, rows)[None]
+        pos_c = position_ids.reshape(-1).index_select(0, rows)[None]
+        if keep_rows is not None:
+            inv = torch.zeros(B * T, dtype=torch.int64, device=rows.device)
+            inv[rows] = torch.arange(Mc, device=rows.device)
+            keep_rows = inv.index_select(0, keep_rows)
+        return emb_c, pos_c, doc_c, keep_rows, rows, overflow
+
     def forward(self, input_ids=None, inputs_embeds=None, position_ids=None, attention_mask=None,
-                context_parallel=None, keep_rows=None):
+                context_parallel=None, keep_rows=None, valid_rows_max=None):
         """With `context_parallel` (utils.context_parallel.ContextParallel): input_ids / inputs_embeds /
         position_ids are this rank's sequence shard [B, T/cp], `attention_mask` stays the GLOBAL [B, T]
         document-id tensor (it is tiny and every rank needs the tile metadata of the keys it attends to).
@@ -173,6 +212,16 @@ class DecoderModel(nn.Module):
         B, T, _ = inputs_embeds.shape
         if position_ids is None:
             position_ids = torch.arange(T, device=inputs_embeds.device).expand(B, T)
+        sp = getattr(self, "_tn_sp", None)
+        dropped = None
+        if (SKIP_PAD_ROWS and valid_rows_max is not None and context_parallel is None and sp is None
+                and isinstance(attention_mask, torch.Tensor) and attention_mask.dim() == 2
+                and not attention_mask.dtype.is_floating_point):
+            dropped = self._drop_pad_rows(inputs_embeds, position_ids, attention_mask, keep_rows, valid_rows_max)
+        if dropped is not None:
+            inputs_embeds, position_ids, attention_mask, keep_rows, kept, overflow = dropped
+            full_shape = (B, T)
+            B, T = 1, inputs_embeds.shape[1]
         cos, sin = self.rotary_emb(position_ids, inputs_embeds.dtype)
         mask = attention_mask
         if mask is None:                                   # plain causal (Qwen2-Audio training path)
@@ -183,7 +232,6 @@ class DecoderModel(nn.Module):
             mask.cp = context_parallel
         # tensor parallelism with sequence parallelism (models/tensor_parallel.py): the residual stream is this rank's
         # T/tp rows between the blocks; attention and MLP gather / reduce-scatter around their own bodies
-        sp = getattr(self, "_tn_sp", None)
         if sp is not None and keep_rows is not None:
             raise RuntimeError("keep_rows is not available under sequence parallelism")
         delta, residual = (inputs_embeds if sp is None else sp.scatter(inputs_embeds)), None
@@ -194,6 +242,12 @@ class DecoderModel(nn.Module):
             else:
                 delta, residual = layer(delta, residual, cos, sin, mask)
         h, _ = self.norm(delta, residual)
+        if dropped is not None:
+            # a bound below the real count dropped real tokens: NaN in every output (and through it every gradient)
+            h = h * torch.where(overflow, float("nan"), 1.0).to(h.dtype)
+            if keep_rows is None:                            # back to [B, T, H]; the dropped padding slots read 0
+                out = h.new_zeros(full_shape[0] * full_shape[1], h.shape[-1])
+                h = out.index_copy(0, kept, h[0]).view(*full_shape, -1)
         return h if sp is None else sp.gather(h)
 
 
@@ -232,7 +286,7 @@ class PackedCausalLM(nn.Module):
                 nn.init.ones_(m.weight)
 
     def _forward_labelled_rows(self, input_ids, inputs_embeds, position_ids, attention_mask, labels, sentence_lens,
-                               num_sentence, ce_chunk_tokens, rows_max, ignore_index=-100):
+                               num_sentence, ce_chunk_tokens, rows_max, ignore_index=-100, valid_rows_max=None):
         """Fused lm_head + CE when the packers supply an upper bound of the labelled positions: the rows are selected
         BEFORE the last layer's output projection instead of in front of lm_head (DecoderModel.forward, `keep_rows`).
         Static shapes, no host sync: the row list has round_up(rows_max, 256) entries, the filler entries repeat row 0
@@ -246,7 +300,7 @@ class PackedCausalLM(nn.Module):
         count = labelled.sum()
         valid = torch.arange(rows.numel(), device=lab.device) < count
         h = self.model(input_ids=input_ids, inputs_embeds=inputs_embeds, position_ids=position_ids,
-                       attention_mask=attention_mask, keep_rows=rows)                       # [1, R, H]
+                       attention_mask=attention_mask, keep_rows=rows, valid_rows_max=valid_rows_max)      # [1, R, H]
         lab_c = torch.where(valid, lab.index_select(0, rows), torch.full_like(rows, ignore_index))[None]
         sl_c = sentence_lens.reshape(-1).index_select(0, rows)[None]
         loss, per_token, acc = fused_linear_cross_entropy(h, self.lm_head.weight, lab_c, sl_c, num_sentence,
@@ -265,7 +319,7 @@ class PackedCausalLM(nn.Module):
     def forward(self, input_ids=None, inputs_embeds=None, position_ids=None, attention_mask=None,
                 labels=None, sentence_lens=None, num_sentence=None, shift_labels=None,
                 ce_chunk_tokens: int = 4096, ce_compact=False, labelled_rows_max=None, context_parallel=None,
-                **unused):
+                valid_rows_max=None, **unused):
         """Without `labels`: returns `.logits` (the reference's default path, loss_fn runs in the trainer).
         With `labels` (+ `sentence_lens`, `num_sentence`): lm_head and the packed CE run fused INSIDE the
         model — the role liger's fused-linear-CE plays in the reference (`pred.loss`, train.py:443-445), but
@@ -275,9 +329,13 @@ class PackedCausalLM(nn.Module):
                 and context_parallel is None and len(self.model.layers) > 1 and getattr(self.model, "_tn_sp", None) is None
                 and 2 * ((int(labelled_rows_max) + 255) // 256 * 256) <= labels.numel()):    # (pays for sparse labels only)
             return self._forward_labelled_rows(input_ids, inputs_embeds, position_ids, attention_mask, labels,
-                                               sentence_lens, num_sentence, ce_chunk_tokens, int(labelled_rows_max))
+                                               sentence_lens, num_sentence, ce_chunk_tokens, int(labelled_rows_max),
+                                               valid_rows_max=valid_rows_max)
+        # (the padding slots are only skipped when the loss is formed in here: a caller that asks for logits gets every
+        #  position computed as the reference computes it)
         h = self.model(input_ids=input_ids, inputs_embeds=inputs_embeds, position_ids=position_ids,
-                       attention_mask=attention_mask, context_parallel=context_parallel)
+                       attention_mask=attention_mask, context_parallel=context_parallel,
+                       valid_rows_max=valid_rows_max if (labels is not None or shift_labels is not None) else None)
         if labelled_rows_max is not None and ce_compact is not True:
             # the packers know how many positions carry a label: lm_head + CE run on those rows only, without a host
             # sync (functional._FusedLinearCE); rounded up so that the GEMM shapes repeat from step to step.  (Under

@@ -92,7 +92,9 @@ def _emit_text(buf: PackBuffer, sentences, bos, eos, pad):
     t = lambda a: torch.from_numpy(a.reshape(B, T))
     return {"input_ids": t(input_ids), "inputs_embeds": None, "labels": t(labels), "position_ids": t(position_ids),
             "attention_mask": t(attention_mask), "sentence_lens": t(sentence_lens), "num_sentence": len(buf),
-            "labelled_rows_max": int(sum(buf.lens))}          # every non-pad slot carries a label (host int: no sync)
+            "labelled_rows_max": int(sum(buf.lens)),          # every non-pad slot carries a label (host int: no sync)
+            # non-pad slots of the batch: the decoder drops the padding slots from its row-wise work (DecoderModel.forward)
+            "valid_rows_max": int(sum(buf.lens))}
 
 
 def batch_text(data, config, tokenizer):

@@ -75,7 +75,8 @@ def _emit(buf: PackBuffer, segs, mels, valid, pad_id: int, audio_token: int):
             "attention_mask": t(doc), "sentence_lens": t(sentence_lens), "num_sentence": len(buf),
             "input_features": feats, "audio_positions": torch.from_numpy(audio_positions),
             "audio_output_lengths": torch.tensor([audio_token_count(v) for v in valid], dtype=torch.int64),
-            "labelled_rows_max": int(sum(len(r) + 1 for _, r, _ in segs))}           # response + eos (host int: no sync)
+            "labelled_rows_max": int(sum(len(r) + 1 for _, r, _ in segs)),           # response + eos (host int: no sync)
+            "valid_rows_max": int((doc > 0).sum())}                                  # non-pad slots (host int: no sync)
 
 
 def _samples(data, config, tokenizer, n_mels: int, limit: int = None):
@@ -163,7 +164,7 @@ def _emit_rows(rows, pad: int, eos: int):
     return {"input_ids": torch.from_numpy(input_ids), "attention_mask": torch.from_numpy(mask), "labels": lab,
             "shift_labels": lab, "input_features": feats, "feature_attention_mask": fmask, "num_sentence": B,
             "sentence_lens": torch.from_numpy(slen),
-            "labelled_rows_max": int(sum(len(r) + 1 for _, r, _, _, _ in rows))}
+            "labelled_rows_max": int(sum(len(r) + 1 for _, r, _, _, _ in rows)), "valid_rows_max": int(mask.sum())}
 
 
 def dynamic_batch(data, config, processor):

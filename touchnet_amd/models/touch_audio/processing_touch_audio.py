@@ -53,7 +53,8 @@ def _emit_asr(buf: PackBuffer, feats, sentences, feat_dim, bos, eos, pad):
     return {"input_ids": t(input_ids), "input_features": input_features, "labels": lab_t,
             "position_ids": t(position_ids), "attention_mask": t(attention_mask),
             "sentence_lens": t(sentence_lens), "num_sentence": len(buf), "shift_labels": lab_t,
-            "labelled_rows_max": int(sum(len(s) + 1 for s in sentences))}       # text slots only (host int: no sync)
+            "labelled_rows_max": int(sum(len(s) + 1 for s in sentences)),       # text slots only (host int: no sync)
+            "valid_rows_max": int((attention_mask > 0).sum())}                  # non-pad slots
 
 
 def batch_pairaudio_pairtext_packed(data, config, tokenizer):
