@@ -30,7 +30,12 @@ def layer_norm(x, weight, bias, eps=1e-5, residual=None):
 swiglu = _nn.swiglu
 
 
-def swiglu_mlp(x, w_gate, w_up, w_down):
+def norm_source(h, norm_weight, eps):
+    """mirror of touchnet_amd.functional.norm_source (a memory hint for the HIP path's autograd nodes: no arithmetic)"""
+    return (h, norm_weight, float(eps))
+
+
+def swiglu_mlp(x, w_gate, w_up, w_down, norm_src=None):
     """mirror of touchnet_amd.functional.swiglu_mlp (modeling_llama.py:174-176)"""
     lin = torch.nn.functional.linear
     return lin(swiglu(lin(x, w_gate), lin(x, w_up)), w_down)
@@ -41,7 +46,7 @@ def pcm16_to_float(pcm):
     return pcm.to(torch.float32) / 32768.0
 
 
-def linear_group(x, layers, wgrad="tn", dgrad_tn=True):
+def linear_group(x, layers, wgrad="tn", dgrad_tn=True, norm_src=None):
     """mirror of touchnet_amd.functional.linear_group: plain nn.Linear math per layer"""
     return [torch.nn.functional.linear(x, w, b) for w, b in layers]
 

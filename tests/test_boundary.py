@@ -133,11 +133,19 @@ def test_activation_checkpointing_does_not_change_loss_or_gradients():
     from touchnet_amd.data.synthetic import text_batch
     res = {}
     with use_ops(oracle_ops):
-        for mode in ("none", "full"):
+        for mode in ("none", "full", "op"):
+            # "op" = the reference's op-level selective policy (helper_func.py:39-96): the hook marks the decoder blocks and
+            # their GEMM nodes are handed the norm's input (`norm_source`); on the oracle op set that is wiring only
             job = TrainConfig(training_model_name="llama_mi355", training_enable_fused_ce=False,
-                              training_activation_checkpoint_mode=mode)
+                              training_activation_checkpoint_mode="selective" if mode == "op" else mode,
+                              training_activation_checkpoint_selective_ac_option="op" if mode == "op" else "2")
             tr = Trainer(job, _tiny_cfg(), torch.device("cpu"),
                          optimizer_factory=lambda ps: torch.optim.SGD(ps, lr=0.0))
+            if mode == "op":
+                assert all(getattr(b, "_tn_recompute_rows", False) for b in tr.model.model.layers)
+                seen = []
+                inner = oracle_ops.norm_source
+                oracle_ops.norm_source = lambda *a: (seen.append(1), inner(*a))[1]
             tr.model.float()
             data = tr.next_batch(text_batch(32, 2, 32, seed=3))
             tr.optimizer.zero_grad()
@@ -145,9 +153,12 @@ def test_activation_checkpointing_does_not_change_loss_or_gradients():
             loss.backward()
             res[mode] = (float(loss), {n.replace("_checkpoint_wrapped_module.", ""): p.grad.clone()
                                        for n, p in tr.model.named_parameters()})
-    assert res["none"][0] == pytest.approx(res["full"][0], rel=1e-6)
-    for n, g in res["none"][1].items():
-        torch.testing.assert_close(res["full"][1][n], g, rtol=1e-5, atol=1e-7)
+    oracle_ops.norm_source = inner
+    assert len(seen) == 2 * len(tr.model.model.layers)                 # both norms of every block were announced
+    for mode in ("full", "op"):
+        assert res["none"][0] == pytest.approx(res[mode][0], rel=1e-6)
+        for n, g in res["none"][1].items():
+            torch.testing.assert_close(res[mode][1][n], g, rtol=1e-5, atol=1e-7)
 
 
 # ------------------------------------------------------------------------------------------------ dataloader hook

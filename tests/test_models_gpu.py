@@ -345,6 +345,56 @@ def test_dropping_the_padding_slots_matches_the_full_batch_on_device(labelled):
         assert float((ggot[n] - gfull[n]).abs().max()) / scale < 4e-2, n
 
 
+def test_op_level_selective_checkpointing_recomputes_row_kernels_bit_identically():
+    """The reference's selective AC option "op" (touchnet/models/helper_func.py:39-96: keep matmul / attention outputs,
+    recompute the rest) on this path's autograd nodes: blocks marked by `parallelize_fn` keep the residual stream instead
+    of the norm outputs and drop the SwiGLU product; both are recomputed by the same kernels from the same stored bits, so
+    loss and EVERY gradient are bit-identical to the unmarked model — and the step holds less memory."""
+    import types
+    from touchnet_amd.models.llama import DecoderConfig, PackedCausalLM
+    from touchnet_amd.models.parallelize import apply_ac
+    torch.manual_seed(0)
+    cfg = DecoderConfig.from_dict(dict(TEXT, hidden_size=1024, intermediate_size=2816, num_attention_heads=8,
+                                       num_key_value_heads=8, head_dim=128, num_hidden_layers=4, tie_word_embeddings=False))
+    model = PackedCausalLM(cfg)
+    model.post_init()
+    model = model.to(DEV, torch.bfloat16)
+    B, T = 4, 2048
+    g = torch.Generator().manual_seed(1)
+    ids = torch.randint(1, 500, (B, T), generator=g)
+    doc = torch.ones(B, T, dtype=torch.int64)
+    doc[:, 1000:] = 2
+    pos = torch.cat([torch.arange(1000), torch.arange(T - 1000)]).expand(B, T).clone()
+    labels = torch.randint(1, 500, (B, T), generator=g)
+    sl = torch.full((B, T), 8, dtype=torch.int64)
+    kw = {k: v.to(DEV) for k, v in dict(input_ids=ids, position_ids=pos, attention_mask=doc, labels=labels,
+                                        sentence_lens=sl).items()}
+
+    def run():
+        model.zero_grad(set_to_none=True)
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        out = model(**kw, num_sentence=B * T // 8)
+        held = torch.cuda.memory_allocated() - base                  # what the graph keeps alive for the backward
+        out.loss.backward()
+        return out.loss.detach().clone(), {n: p.grad.clone() for n, p in model.named_parameters()}, held
+
+    loss0, g0, held0 = run()
+    job = types.SimpleNamespace(training_activation_checkpoint_mode="selective",
+                                training_activation_checkpoint_selective_ac_option="op")
+    apply_ac(model, job)
+    assert all(getattr(blk, "_tn_recompute_rows", False) for blk in model.model.layers)
+    loss1, g1, held1 = run()
+    assert torch.equal(loss0, loss1)
+    for n in g0:
+        assert torch.equal(g0[n], g1[n]), n
+    # per block and row: 2 norm outputs (2 H) + the SwiGLU product (I) bf16 values fewer
+    saved = held0 - held1
+    expect = cfg.num_hidden_layers * B * T * (2 * cfg.hidden_size + cfg.intermediate_size) * 2
+    assert saved >= 0.9 * expect, (held0, held1, expect)
+
+
 def test_fsdp2_single_rank_rccl_matches_unsharded():
     """The FSDP2 path on real hardware: a 1-rank RCCL mesh (TN_FORCE_FSDP=1) must train like the unsharded model —
     fully_shard hooks around the HIP autograd functions, DTensor parameters, the fused AdamW on local shards.

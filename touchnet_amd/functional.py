@@ -885,7 +885,17 @@ class _LinearGroup(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, n, wgrad, dgrad_tn, *wb):
         ws, bs = wb[:n], wb[n:]
-        ctx.save_for_backward(x, *ws)
+        src = None
+        if isinstance(wgrad, tuple):                       # (wgrad, norm_src): op-level selective recomputation, see
+            wgrad, src = wgrad                             # `norm_source` below
+        if src is not None:
+            # x = RMSNorm(h) * w_norm is a ROW kernel's output: keep its input (which the norm's own backward saves
+            # anyway) and recompute x in the backward — bit-identical, the kernel norms the stored h
+            ctx.save_for_backward(src[0], *ws, src[1])
+            ctx.src_eps, ctx.xshape = float(src[2]), x.shape
+        else:
+            ctx.save_for_backward(x, *ws)
+            ctx.src_eps = None
         ctx.has_bias = [b is not None for b in bs]
         ctx.wgrad, ctx.dgrad_tn = wgrad, dgrad_tn
         if LINEAR_GEMM == "own" and x.is_cuda:
@@ -896,6 +906,9 @@ class _LinearGroup(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *dys):
         x, *ws = ctx.saved_tensors
+        if ctx.src_eps is not None:
+            norm_w = ws.pop()
+            x = L.rmsnorm_fwd(x, None, norm_w, ctx.src_eps)[0].view(ctx.xshape)
         n = len(ws)
         K = x.shape[-1]
         x2 = x.reshape(-1, K)
@@ -969,15 +982,28 @@ class _LinearGroup(torch.autograd.Function):
         return (dx, None, None, None, *dws, *dbs)
 
 
-def linear_group(x, layers, wgrad: str = "tn", dgrad_tn: bool = True):
-    """``layers``: list of (weight [N_i, K], bias [N_i] | None) sharing the input ``x`` -> list of outputs."""
+def norm_source(h, norm_weight, eps):
+    """`norm_src` argument of `linear_group` / `swiglu_mlp`: says that their input x IS ``rms_norm(h, norm_weight, eps)`` (h =
+    the residual stream the norm saw, i.e. its second output), so that the node may keep h instead of x and recompute x
+    in its backward.  This is the op-level selective activation checkpointing of the reference
+    (touchnet/models/helper_func.py:39-96: save the outputs of the compute ops — matmuls, attention — and recompute the
+    rest) on this path's own autograd nodes: GEMM and attention outputs stay, the ROW kernels' outputs (norm outputs,
+    the SwiGLU product) are recomputed."""
+    return (h.detach(), norm_weight.detach(), float(eps))
+
+
+def linear_group(x, layers, wgrad: str = "tn", dgrad_tn: bool = True, norm_src=None):
+    """``layers``: list of (weight [N_i, K], bias [N_i] | None) sharing the input ``x`` -> list of outputs.
+    ``norm_src``: see `norm_source`."""
     if wgrad not in ("tn", "nt", "nt_fused"):
         raise ValueError(f"linear_group: wgrad={wgrad!r}")
     if not (x.is_cuda or x.is_meta):
         raise _C.KernelError("linear_group: device tensors only (the product path has no CPU fallback)")
     ws = [w for w, _ in layers]
     bs = [b for _, b in layers]
-    return list(_LinearGroup.apply(x, len(ws), wgrad, dgrad_tn, *ws, *bs))
+    if norm_src is not None and (tuple(norm_src[0].shape) != tuple(x.shape) or norm_src[0].dtype != x.dtype):
+        raise _C.KernelError("linear_group: norm_src does not describe x")
+    return list(_LinearGroup.apply(x, len(ws), (wgrad, norm_src) if norm_src is not None else wgrad, dgrad_tn, *ws, *bs))
 
 
 class _SwiGLUMLP(torch.autograd.Function):
@@ -990,7 +1016,7 @@ class _SwiGLUMLP(torch.autograd.Function):
     tn_swiglu_bwd_t: one extra store each) instead of by separate transpose passes."""
 
     @staticmethod
-    def forward(ctx, x, wg, wu, wd):
+    def forward(ctx, x, wg, wu, wd, src=None):
         K, I = x.shape[-1], wg.shape[0]
         x2 = _c(x.reshape(-1, K))
         M = x2.shape[0]
@@ -1010,17 +1036,27 @@ class _SwiGLUMLP(torch.autograd.Function):
         else:
             act, kept = L.swiglu_fwd_t(gate, up)                       # kept = act^T
         y = _mm_tn(act, _c(wd))
-        ctx.save_for_backward(x2, gate, up, kept, wg, wu, wd)
+        if src is not None and own:
+            # op-level selective recomputation (`norm_source`): neither the norm output x nor act = silu(gate) * up is
+            # kept — both are row kernels' outputs, recomputed bit-identically in the backward from h and (gate, up)
+            ctx.save_for_backward(src[0].reshape(-1, K), gate, up, src[1], wg, wu, wd)
+            ctx.src_eps = float(src[2])
+        else:
+            ctx.save_for_backward(x2, gate, up, kept, wg, wu, wd)
+            ctx.src_eps = None
         ctx.xshape, ctx.own, ctx.fused = x.shape, own, fused
         return y.view(*x.shape[:-1], wd.shape[0])
 
     @staticmethod
     def backward(ctx, dy):
         x2, gate, up, kept, wg, wu, wd = ctx.saved_tensors
+        if ctx.src_eps is not None:
+            x2 = L.rmsnorm_fwd(x2, None, kept, ctx.src_eps)[0]           # (x2 held h, `kept` the norm weight)
+            kept = L.swiglu_fwd(gate, up)
         M, K = x2.shape
         I, H = wg.shape[0], wd.shape[0]
         dy2 = _c(dy).reshape(M, H)
-        nx, ng, nu, nd = ctx.needs_input_grad
+        nx, ng, nu, nd = ctx.needs_input_grad[:4]
         if ctx.own and LINEAR_GEMM == "own":
             grouped = GROUPED_WGRAD and ng and nu and nd and not os.environ.get("TN_GEMM_VARIANT")
             if not grouped:
@@ -1037,12 +1073,12 @@ class _SwiGLUMLP(torch.autograd.Function):
                 # ONE launch for the three weight gradients (3 x 688 tiles = 8 whole rounds + 16 tiles split-K)
                 dwg, dwu, dwd = _beside((dgate, dup, dy2, x2, kept), lambda: _wgrad_group(
                     [(wg, dgate, x2), (wu, dup, x2), (wd, dy2, kept)]))
-                return dx, dwg, dwu, dwd
+                return dx, dwg, dwu, dwd, None
             dwg = None if (not ng or _beside((dgate, x2), lambda: _sink_wgrad(wg, dgate, x2))) \
                 else _beside((dgate, x2), lambda: gemm([(dgate, x2)], True, True))
             dwu = None if (not nu or _beside((dup, x2), lambda: _sink_wgrad(wu, dup, x2))) \
                 else _beside((dup, x2), lambda: gemm([(dup, x2)], True, True))
-            return dx, dwg, dwu, dwd
+            return dx, dwg, dwu, dwd, None
         act_t = kept if not ctx.own else transpose_2d(kept)
         dwd = _mm_tn(transpose_2d(dy2), act_t) if nd else None                      # [H, I], forward layout
         dact = _mm_tn(dy2, transpose_2d(_c(wd)))                                    # [M, I]
@@ -1056,7 +1092,7 @@ class _SwiGLUMLP(torch.autograd.Function):
         dwg = dwu = None
         if ng or nu:
             dwg, dwu = torch.split(_mm_tn(dgu_t, transpose_2d(x2)), [I, I], dim=0)
-        return dx, dwg if ng else None, dwu if nu else None, dwd
+        return dx, dwg if ng else None, dwu if nu else None, dwd, None
 
 
 class _Conv1dK3(torch.autograd.Function):
@@ -1124,17 +1160,17 @@ def conv1d_k3(x, weight, bias, stride: int = 1, need_dx: bool = True):
 _MLP_FUSED = os.environ.get("TN_MLP_FUSED", "1") != "0"       # (A/B switch for measurements)
 
 
-def swiglu_mlp(x, w_gate, w_up, w_down):
+def swiglu_mlp(x, w_gate, w_up, w_down, norm_src=None):
     """Llama/Qwen2 MLP ``down(silu(gate(x)) * up(x))`` (bias-free).  bf16 device tensors with 8-aligned shapes take the
-    fused node above; anything else composes the individual ops (same maths)."""
+    fused node above; anything else composes the individual ops (same maths).  ``norm_src``: see `norm_source`."""
     if not (x.is_cuda or x.is_meta):
         raise _C.KernelError("swiglu_mlp: device tensors only (the product path has no CPU fallback)")
     M = x.numel() // x.shape[-1]
     if (_MLP_FUSED and x.dtype == torch.bfloat16
             and all(w.dtype == torch.bfloat16 for w in (w_gate, w_up, w_down))
             and _tn_ok(M, x.shape[-1], (w_gate.shape[0], w_down.shape[0]))):
-        return _SwiGLUMLP.apply(x, w_gate, w_up, w_down)
-    gate, up = linear_group(x, [(w_gate, None), (w_up, None)])
+        return _SwiGLUMLP.apply(x, w_gate, w_up, w_down, norm_src)
+    gate, up = linear_group(x, [(w_gate, None), (w_up, None)], norm_src=norm_src)
     return linear_group(swiglu(gate, up), [(w_down, None)])[0]
 
 # ------------------------------------------------------------------------------------ frontend

@@ -61,17 +61,19 @@ class Attention(nn.Module):
         self.o_proj = nn.Linear(self.num_heads * D, H, bias=False)
         self.scaling = D ** -0.5
 
-    def forward(self, x, cos, sin, mask, keep_rows=None):
+    def forward(self, x, cos, sin, mask, keep_rows=None, norm_src=None):
         """`keep_rows` (flat indices into B*T, last decoder layer only): the output projection runs on those rows only and
-        the result is [1, len(keep_rows), H] — see DecoderModel.forward."""
+        the result is [1, len(keep_rows), H] — see DecoderModel.forward.  `norm_src`: x is the RMSNorm of that tensor
+        (functional.norm_source; op-level selective activation checkpointing)."""
         B, T, _ = x.shape
         cp = getattr(mask, "cp", None)
         if cp is not None and cp.need is not None:
             return self._forward_context_parallel(x, cos, sin, mask, cp)
         # one autograd node for the three projections of x: their weight gradients run as ONE GEMM in the forward
         # layout (functional._LinearGroup); parameters keep the HF names and shapes
+        kw = {"norm_src": norm_src} if norm_src is not None else {}
         q, k, v = ops().linear_group(x, [(self.q_proj.weight, self.q_proj.bias), (self.k_proj.weight, self.k_proj.bias),
-                                         (self.v_proj.weight, self.v_proj.bias)])
+                                         (self.v_proj.weight, self.v_proj.bias)], **kw)
         q = q.view(B, T, self.num_heads, self.head_dim)
         k = k.view(B, T, self.num_kv_heads, self.head_dim)
         v = v.view(B, T, self.num_kv_heads, self.head_dim)
@@ -123,9 +125,10 @@ class MLP(nn.Module):
         self.up_proj = nn.Linear(H, I, bias=False)
         self.down_proj = nn.Linear(I, H, bias=False)
 
-    def forward(self, x):
-        # one autograd node: the SwiGLU kernels also emit the transposed operands of the weight-gradient GEMMs
-        return ops().swiglu_mlp(x, self.gate_proj.weight, self.up_proj.weight, self.down_proj.weight)
+    def forward(self, x, norm_src=None):
+        # one autograd node: gate + up + SwiGLU as one launch, down; the backward's five launches (functional._SwiGLUMLP)
+        kw = {"norm_src": norm_src} if norm_src is not None else {}
+        return ops().swiglu_mlp(x, self.gate_proj.weight, self.up_proj.weight, self.down_proj.weight, **kw)
 
 
 class DecoderLayer(nn.Module):
@@ -139,16 +142,23 @@ class DecoderLayer(nn.Module):
     def forward(self, delta, residual, cos, sin, mask, keep_rows=None):
         """`delta` is the previous sub-layer's output still to be added to the `residual` stream.
         `keep_rows`: everything behind the attention core (o_proj, residual, norm, MLP) runs on those rows only."""
+        # `_tn_recompute_rows` (set by parallelize.apply_ac for the reference's selective AC option "op"): the GEMM nodes
+        # keep the residual stream instead of the norm outputs and recompute the row kernels (norms, SwiGLU product) in
+        # their backward — functional.norm_source
+        sac = getattr(self, "_tn_recompute_rows", False) and torch.is_grad_enabled()
         if residual is None:
             residual = delta
             x = self.input_layernorm(delta)
         else:
             x, residual = self.input_layernorm(delta, residual)
-        a = self.self_attn(x, cos, sin, mask, keep_rows)
+        src = ops().norm_source(residual, self.input_layernorm.weight, self.input_layernorm.variance_epsilon) if sac else None
+        a = self.self_attn(x, cos, sin, mask, keep_rows, norm_src=src)
         if keep_rows is not None:
             residual = residual.reshape(-1, residual.shape[-1]).index_select(0, keep_rows)[None]
         x, residual = self.post_attention_layernorm(a, residual)
-        return self.mlp(x), residual
+        src = (ops().norm_source(residual, self.post_attention_layernorm.weight, self.post_attention_layernorm.variance_epsilon)
+               if sac else None)
+        return self.mlp(x, norm_src=src), residual
 
 
 class DecoderModel(nn.Module):
