@@ -761,7 +761,9 @@ WGRAD_RETURNS_NEED_SYNC = False
 
 def enable_wgrad_stream(on: bool = True) -> None:
     global WGRAD_STREAM
-    WGRAD_STREAM = torch.cuda.Stream() if on else None
+    # (a stream of another priority than the main one: streams of equal priority may share a hardware queue, and kernels
+    #  of one queue never overlap — profiles/r05q_comm_stream_hw_queue_probe.log)
+    WGRAD_STREAM = torch.cuda.Stream(priority=int(os.environ.get("TN_WGRAD_STREAM_PRIORITY", "-1"))) if on else None
 
 
 def wgrad_streams():

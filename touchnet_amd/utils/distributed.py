@@ -35,6 +35,8 @@ def init_distributed(device_type: str = None, timeout_s: int = 300) -> tuple[int
         os.environ.setdefault("MASTER_PORT", "29512")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC only on this host driver
         os.environ.setdefault("TORCH_NCCL_AVOID_RECORD_STREAMS", "1")  # distributed.py:391
+        # RCCL's own streams on high-priority hardware queues: beside — not behind — the compute queue (utils/zero_dp.py)
+        os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
         backend = backend_env or ("nccl" if device_type == "cuda" else "gloo")
         kw = {}
         if device_type == "cuda" and backend == "nccl":

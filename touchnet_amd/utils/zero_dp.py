@@ -177,7 +177,12 @@ class FlatShardedDataParallel:
                 if self.rep_group is not None:           # (replica 0's shard-rank-0 numbers reach everybody)
                     dist.broadcast(b.flat_p, src=dist.get_global_rank(self.rep_group, 0), group=self.rep_group)
                 dist.broadcast(b.flat_p, src=dist.get_global_rank(self.group, 0), group=self.group)
-        self.comm = torch.cuda.Stream(device=self.device) if self.cuda else None
+        # HIGH priority: ROCm multiplexes HIP streams onto a few hardware queues, and two streams of one priority may share
+        # a queue — their kernels then run strictly one after the other (measured, round 5: every reduce-scatter of a step
+        # on the queue of the backward's GEMMs, 0 % of the RCCL kernels' time beside compute).  Streams of another priority
+        # get a queue of their own (profiles/r05o_*).  TN_COMM_STREAM_PRIORITY=0 restores the default stream.
+        prio = int(os.environ.get("TN_COMM_STREAM_PRIORITY", "-1"))
+        self.comm = torch.cuda.Stream(device=self.device, priority=prio) if self.cuda else None
         self._pool, self._pool_free_at = [], []          # staging buffers + the event after which each is reusable
         self._pool_numel = max(b.total for b in self.buckets if b not in self.rest) if len(self.rest) < len(self.buckets) else 0
         for blk, b in self._hooked_modules:
