@@ -310,6 +310,13 @@ int tn_gemm_bf16_swiglu_fwd(const void* x, const void* wg, const void* wu, void*
  *      tn_swiglu_bwd on the bf16-rounded d(act) (bit-identical).  -22 unless H % 64 == 0, I % 8 == 0, pitches % 8 == 0. */
 int tn_gemm_bf16_swiglu_bwd(const void* dy, const void* wd, const void* gate, const void* up, void* dgate, void* dup,
                             int M, int I, int H, long long lddy, long long ldw, long long ld, void* stream);
+/*      A q / k projection with the rotary embedding in the epilogue (transformers' LlamaAttention.forward: q_proj /
+ *      k_proj followed by apply_rotary_pos_emb, modeling_llama.py:113-160): out[M, N] = rope(x W^T + bias), N = heads x
+ *      head_dim (64 or 128), cos / sin [M, head_dim / 2] bf16 = one table row per output row (tn_rope_table).  Bit-identical
+ *      to tn_gemm_bf16 followed by tn_rope_apply.  -22 unless K % 64 == 0, pitches % 8 == 0, N % 256 == 0 (head_dim 128) /
+ *      N % 64 == 0 (head_dim 64). */
+int tn_gemm_bf16_rope(const void* x, const void* w, const void* bias, const void* cos_t, const void* sin_t, void* out, int M,
+                      int N, int K, long long ldx, long long ldw, long long ldc, int head_dim, void* stream);
 /*      Single segment, both operands contraction-contiguous (the round-2 entry point): */
 int tn_gemm_bf16_tn(const void* A, const void* B, void* C, void* Ct, const void* bias, int M, int N, int K,
                     long long lda, long long ldb, long long ldc, long long ldct, int accumulate, void* stream);

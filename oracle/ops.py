@@ -46,9 +46,17 @@ def pcm16_to_float(pcm):
     return pcm.to(torch.float32) / 32768.0
 
 
-def linear_group(x, layers, wgrad="tn", dgrad_tn=True, norm_src=None):
-    """mirror of touchnet_amd.functional.linear_group: plain nn.Linear math per layer"""
-    return [torch.nn.functional.linear(x, w, b) for w, b in layers]
+def linear_group(x, layers, wgrad="tn", dgrad_tn=True, norm_src=None, rope=None):
+    """mirror of touchnet_amd.functional.linear_group: plain nn.Linear math per layer; `rope = (cos, sin, head_dim, which)`:
+    the outputs `which` come back rotated (apply_rope below on [.., heads, head_dim])"""
+    outs = [torch.nn.functional.linear(x, w, b) for w, b in layers]
+    if rope is not None:
+        cos, sin, D, which = rope
+        for i in which:
+            y = outs[i]
+            y4 = y.reshape(y.shape[0], y.shape[1], -1, D) if y.dim() == 3 else y.reshape(1, y.shape[0], -1, D)
+            outs[i] = apply_rope(y4, y4[:, :, :0], cos, sin)[0].reshape(y.shape)
+    return outs
 
 
 gelu = torch.nn.functional.gelu

@@ -297,3 +297,70 @@ def test_bitwise_repeatability_of_the_cross_entropy_kernels():
     for _ in range(200):
         for a, b in zip(once(), first):
             assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("M,heads,D,K,bias", [
+    (256, 2, 128, 64, True),          # one tile = two heads
+    (520, 6, 128, 192, True),         # ragged rows, three column tiles
+    (4360, 8, 128, 128, False),       # 18 x 4 tiles, no bias
+    (8200, 8, 128, 128, True),        # 264 tiles: persistent workgroups
+    (4360, 32, 128, 4096, True),      # the 7B q / k projection (272 tiles: the unfused reference is not split-K)
+    (1000, 12, 64, 256, True),        # head_dim 64 (Llama-3.2-1B, config B): 4 heads per tile, natural pair layout
+    (300, 5, 64, 128, False),         # N = 320: a ragged last column tile of whole heads
+])
+def test_rope_epilogue_is_bit_identical_to_projection_plus_rope_kernel(M, heads, D, K, bias):
+    """tn_gemm_bf16_rope: rope(x W^T + b) from one launch == tn_gemm_bf16 followed by tn_rope_apply, bit for bit (the
+    product is rounded to bf16 where the separate projection rounds it, the rotation is the row kernel's `rope_rotate`)."""
+    F = _f()
+    g = torch.Generator().manual_seed(M + heads + D + K)
+    x, w = _r(g, M, K), _r(g, heads * D, K, scale=K ** -0.5 * 2)
+    b = _r(g, heads * D) if bias else None
+    pos = torch.randint(0, 4000, (1, M), generator=g).to(DEV)
+    cos, sin = F.rope_tables(pos, F.rope_inv_freq(D, 1e6, device=DEV), torch.bfloat16)
+    got = F.gemm_rope(x, w, b, cos, sin, D)
+    y = F.gemm([(x, w)], bias=b).view(1, M, heads, D)
+    ref = F.apply_rope(y, y.new_empty(1, M, 0, D), cos, sin)[0].view(M, heads * D)
+    assert torch.equal(got, ref)
+    # against fp64 as well: a wrong pair / column permutation cannot hide behind the self-comparison
+    yd = (x.double() @ w.double().t() + (b.double() if bias else 0)).view(M, heads, D)
+    c = torch.cat([cos, cos], -1).double()[:, None, :]
+    sgn = torch.cat([-yd[..., D // 2:], yd[..., :D // 2]], -1)
+    rd = (yd * c + sgn * torch.cat([sin, sin], -1).double()[:, None, :]).view(M, heads * D)
+    assert float((got.double() - rd).abs().max()) <= float(rd.abs().max()) * 2 ** -6
+
+
+def test_linear_group_with_rope_outputs_trains_like_projection_then_rope(monkeypatch):
+    """autograd: q, k rotated in the projections' epilogues (v plain), gradients rotated back in front of the products —
+    outputs and every gradient bit-identical to linear_group followed by apply_rope"""
+    F = _f()
+    g = torch.Generator().manual_seed(11)
+    M, H, D = 8192, 1024, 128
+    x = _r(g, 1, M, H, scale=0.5)
+    layers = [(_r(g, n, H, scale=H ** -0.5), _r(g, n, scale=0.1)) for n in (2048, 1280, 512)]    # 256 / 160 / 64 tiles
+    dys = [_r(g, 1, M, n) for n in (2048, 1280, 512)]
+    pos = torch.arange(M)[None].to(DEV)
+    cos, sin = F.rope_tables(pos, F.rope_inv_freq(D, 1e6, device=DEV), torch.bfloat16)
+
+    def run(fused):
+        monkeypatch.setattr(F, "ROPE_EPILOGUE", fused)
+        xx = x.clone().requires_grad_()
+        lw = [(w.clone().requires_grad_(), b.clone().requires_grad_()) for w, b in layers]
+        if fused is None:                                         # the round-4 composition
+            q, k, v = F.linear_group(xx, lw)
+            q, k = F.apply_rope(q.view(1, M, -1, D), k.view(1, M, -1, D), cos, sin)
+            outs = [q.reshape(1, M, -1), k.reshape(1, M, -1), v]
+        else:
+            outs = F.linear_group(xx, lw, rope=(cos, sin, D, (0, 1)))
+        torch.autograd.backward(outs, dys)
+        return [o.detach() for o in outs] + [xx.grad] + [w.grad for w, _ in lw] + [b.grad for _, b in lw]
+
+    calls = []
+    orig = F.gemm_rope
+    monkeypatch.setattr(F, "gemm_rope", lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
+    want = run(None)
+    got = run(True)
+    assert len(calls) == 2
+    behind = run(False)                                           # epilogue switched off: rotated behind the product
+    assert len(calls) == 2
+    for i, (a, b, c) in enumerate(zip(got, want, behind)):
+        assert torch.equal(a, b) and torch.equal(c, b), i

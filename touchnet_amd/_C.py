@@ -79,6 +79,7 @@ PROTOTYPES = {
     "tn_gemm_bf16_grouped": [C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_ll), C.POINTER(_ll), C.POINTER(_i), C.POINTER(_vp),
                              C.POINTER(_ll), C.POINTER(_i), C.POINTER(_i), _i, _i, _i, _i, _i, _vp, _ll, _vp],
     "tn_gemm_bf16_wgrad_bias": [_vp, _vp, _ll, _ll, _i, _vp, _vp, _i, _i, _ll, _i, _i, _i, _vp, _ll, _vp],
+    "tn_gemm_bf16_rope": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _ll, _ll, _ll, _i, _vp],
     "tn_gemm_bf16_swiglu_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _ll, _ll, _ll, _vp],
     "tn_gemm_bf16_swiglu_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _ll, _ll, _ll, _vp],
     "tn_gemm_set_persistent": [_i],

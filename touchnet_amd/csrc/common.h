@@ -36,6 +36,13 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 // kernels (norm_act.hip) and the fused SwiGLU epilogues of the GEMM (gemm.hip), which must agree bit for bit
 __device__ __forceinline__ float sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 
+// RoPE rotation of one (x[i], x[i + D/2]) pair by (cos, sin) — ONE definition (explicit fma order) for the row kernel
+// (norm_act.hip rope_apply_kernel) and the GEMM's RoPE epilogue (gemm.hip EPI_ROPE), which must agree bit for bit
+__device__ __forceinline__ void rope_rotate(float a, float b, float c, float s, float& ya, float& yb) {
+  ya = __builtin_fmaf(-b, s, a * c);
+  yb = __builtin_fmaf(a, s, b * c);
+}
+
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
   bf16x2_t v = {(__bf16)lo, (__bf16)hi};
   return __builtin_bit_cast(uint32_t, v);

@@ -87,7 +87,14 @@ struct Grp {
 //                   (wr, wc) of the tiles in output column 0 sums its A block wc over the whole contraction (16 VALU
 //                   adds per 8 MFMAs) — so the separate column-sum pass over dY (one more trip of dY through HBM per
 //                   biased layer: 258 launches per Qwen2-Audio step) is gone
-constexpr int EPI_PLAIN = 0, EPI_GROUPED = 1, EPI_SWIGLU_FWD = 2, EPI_SWIGLU_BWD = 3, EPI_BIASG = 4;
+//   EPI_ROPE        a q / k projection whose epilogue applies the rotary embedding (transformers' apply_rotary_pos_emb,
+//                   modeling_llama.py:113-160 behind LlamaAttention.forward): the rotation pairs column c with c + D/2 of a
+//                   head; for D = 128 the B stage image is arranged per DMA wave so that a wave's two 32-column blocks
+//                   are (c .. c + 31) and (c + 64 .. c + 95) of one head — both members of every pair in ONE lane (D = 64:
+//                   the natural layout already has that).  (acc + bias) is rounded to bf16 first, as the separate
+//                   projection leaves it, then rotated with the row kernel's arithmetic: bit-identical, one pass over
+//                   q and k through HBM less per layer
+constexpr int EPI_PLAIN = 0, EPI_GROUPED = 1, EPI_SWIGLU_FWD = 2, EPI_SWIGLU_BWD = 3, EPI_BIASG = 4, EPI_ROPE = 5;
 
 struct Params {
   Seg seg[MAXSEG];
@@ -127,6 +134,10 @@ struct Params {
   // bias_ws[split][nbm * 256] and the reduce kernel adds them up
   bf16_t* bias_out;
   float* bias_ws;
+  // EPI_ROPE: cos / sin tables [M, rope_d / 2] (bf16, one row per output row), head dimension 64 or 128
+  const bf16_t* rope_cos;
+  const bf16_t* rope_sin;
+  int rope_d;
 };
 
 // XCD-aware, bijective workgroup -> tile map
@@ -259,6 +270,7 @@ template <bool AK, bool BK, int PLACE, int ASYM, int ILV, bool HAS_CT, bool SPLI
 struct Kernel {
   static_assert(EPI == EPI_PLAIN || EPI == EPI_BIASG || (!HAS_CT && !SPLITK), "fused epilogues: whole tiles, no transposed copy");
   static_assert(EPI != EPI_BIASG || (AK && BK && !HAS_CT), "bias gradient: weight-gradient mode");
+  static_assert(EPI != EPI_ROPE || (!AK && !BK && !OUT_F32), "RoPE epilogue: x W^T layout");
   static_assert(EPI != EPI_SWIGLU_FWD || (!AK && !BK && !OUT_F32), "SwiGLU forward: x W^T layout");
   static_assert(EPI != EPI_SWIGLU_BWD || (!AK && BK && !OUT_F32), "SwiGLU backward: dY W layout");
   static constexpr int BN_EFF = EPI == EPI_SWIGLU_FWD ? 128 : BN;   // output columns per tile (per matrix)
@@ -405,6 +417,14 @@ struct Kernel {
       } else if constexpr (EPI == EPI_SWIGLU_FWD) {
         // LDS rows [32 w, 32 w + 32) of the B image = rows n0 + 32 (w >> 1) .. of gate_proj (w even) / up_proj (w odd)
         sB.open((wave & 1) ? p.seg[1].B : p.seg[0].B, p.seg[0].ldb, p.seg[0].K, p.N, n0 + (wave >> 1) * 32, 0, lane);
+      } else if constexpr (EPI == EPI_ROPE) {
+        // D = 128: LDS rows [32 w, 32 w + 32) = W rows of head n0 / 128 + (w >> 2), columns 64 (w & 1) + 32 ((w >> 1) & 1) ..:
+        // reader wave wc = w >> 1 then holds (c, c + 64) pairs in its blocks j = 0 / 1.  D = 64: the plain order.
+        if (p.rope_d == 128)
+          sB.open(p.seg[0].B, p.seg[0].ldb, p.seg[0].K, p.N, n0 + (wave >> 2) * 128 + (wave & 1) * 64 + ((wave >> 1) & 1) * 32,
+                  0, lane);
+        else
+          sB.open(p.seg[0].B, p.seg[0].ldb, p.seg[0].K, p.N, n0, wave, lane);
       } else {
         sB.open(p.seg[s].B, p.seg[s].ldb, p.seg[s].K, p.N, n0, wave, lane);
       }
@@ -685,6 +705,11 @@ struct Kernel {
       } else if constexpr (EPI == EPI_SWIGLU_BWD) {
         epilogue_swiglu_bwd(p, acc, smem + (wave < 4 ? pb : pa) * SLOT + (wave & 3) * 8192, m0 + wr * 128, n0 + wc * 64,
                             lane);
+      } else if constexpr (EPI == EPI_ROPE) {
+        const bool d128 = p.rope_d == 128;
+        const int col_a = d128 ? n0 + (wc >> 1) * 128 + (wc & 1) * 32 : n0 + wc * 64;     // block j = 0; j = 1: + D / 2
+        epilogue_rope(p, acc, smem + (wave < 4 ? pb : pa) * SLOT + (wave & 3) * 8192, m0 + wr * 128, col_a,
+                      d128 ? (wc & 1) * 32 : 0, lane);
       } else if constexpr (EPI == EPI_GROUPED) {
         const Out o = {p.grp[grp].C, p.grp[grp].ldc, p.grp[grp].M, p.grp[grp].N};
         epilogue(p, o, acc, smem + (wave < 4 ? pb : pa) * SLOT + (wave & 3) * 8192, m0 + wr * 128, n0 + wc * 64, lane);
@@ -701,7 +726,7 @@ struct Kernel {
       ra = Reader<AK, 4>(lane, wr * 128);
       rb = Reader<BK, 2>(lane, wc * 64);
       sA.set_voff(wave, lane);
-      sB.set_voff(EPI == EPI_SWIGLU_FWD ? 0 : wave, lane);
+      sB.set_voff((EPI == EPI_SWIGLU_FWD || (EPI == EPI_ROPE && p.rope_d == 128)) ? 0 : wave, lane);
       early_pieces(pb, pa);
     }
   }
@@ -828,6 +853,70 @@ struct Kernel {
       const int m = wm0 + (c >> 2) * 64 + row, n = wn0 + (c & 3) * 8;
       if (m < p.M && n < p.N)
         *reinterpret_cast<uint4*>(p.C3 + (long long)m * p.ldc + n) = make_uint4(pv.x, pv.y, pv.z, pv.w);
+    }
+  }
+
+  // RoPE.  The wave holds columns col_a .. + 31 (acc[i][0]) and col_a + D/2 .. + 31 (acc[i][1]) of rows wm0 .. + 127: both
+  // members of every rotary pair in one lane; c0 = the first pair's index inside the head (table column).
+  static __device__ __forceinline__ void epilogue_rope(const Params& p, Acc& acc, char* park, int wm0, int col_a, int c0,
+                                                       int lane) {
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int half = p.rope_d >> 1;
+    const int col_b = col_a + half;
+    // every table / bias element of the tile is requested up front (32 + 8 loads in flight per lane, ONE wait per 64-row
+    // half) — issued one (row block, column quad) at a time the epilogue paid a memory round trip per quad
+    uint2 bwa[4], bwb[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int q = 8 * g + 4 * hi;
+      bwa[g] = bwb[g] = make_uint2(0, 0);
+      if (p.bias != nullptr) {
+        bwa[g] = *reinterpret_cast<const uint2*>(p.bias + min(col_a + q, p.N - 4));
+        bwb[g] = *reinterpret_cast<const uint2*>(p.bias + min(col_b + q, p.N - 4));
+      }
+    }
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      uint2 cw[2][4], sw[2][4];
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii) {
+        const int m = min(wm0 + (hf * 2 + ii) * 32 + l31, p.M - 1);         // (rows >= M are never stored)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const long long o = (long long)m * half + c0 + 8 * g + 4 * hi;
+          cw[ii][g] = *reinterpret_cast<const uint2*>(p.rope_cos + o);
+          sw[ii][g] = *reinterpret_cast<const uint2*>(p.rope_sin + o);
+        }
+      }
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii) {
+        const int i = hf * 2 + ii;
+        const int row = ii * 32 + l31;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float ba[4] = {lo16(bwa[g].x), hi16(bwa[g].x), lo16(bwa[g].y), hi16(bwa[g].y)};
+          const float bb[4] = {lo16(bwb[g].x), hi16(bwb[g].x), lo16(bwb[g].y), hi16(bwb[g].y)};
+          const float cf[4] = {lo16(cw[ii][g].x), hi16(cw[ii][g].x), lo16(cw[ii][g].y), hi16(cw[ii][g].y)};
+          const float sf[4] = {lo16(sw[ii][g].x), hi16(sw[ii][g].x), lo16(sw[ii][g].y), hi16(sw[ii][g].y)};
+          float ya[4], yb[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            rope_rotate(rbf(acc[i][0][4 * g + e] + ba[e]), rbf(acc[i][1][4 * g + e] + bb[e]), cf[e], sf[e], ya[e], yb[e]);
+          const u32x2_t pa_ = {pack2bf(ya[0], ya[1]), pack2bf(ya[2], ya[3])};
+          const u32x2_t pb_ = {pack2bf(yb[0], yb[1]), pack2bf(yb[2], yb[3])};
+          *reinterpret_cast<u32x2_t*>(park + row * 128 + ((g ^ (row & 7)) << 4) + hi * 8) = pa_;
+          *reinterpret_cast<u32x2_t*>(park + row * 128 + (((4 + g) ^ (row & 7)) << 4) + hi * 8) = pb_;
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll 4
+      for (int it = 0; it < 8; ++it) {
+        const int row = it * 8 + (lane >> 3), c = lane & 7;
+        const u32x4_t pv = *reinterpret_cast<const u32x4_t*>(park + row * 128 + ((c ^ (row & 7)) << 4));
+        const int m = wm0 + hf * 64 + row, n = (c < 4 ? col_a : col_b) + (c & 3) * 8;
+        if (m < p.M && n < p.N)
+          *reinterpret_cast<uint4*>(p.C + (long long)m * p.ldc + n) = make_uint4(pv.x, pv.y, pv.z, pv.w);
+      }
     }
   }
 
@@ -1590,6 +1679,47 @@ int tn_gemm_bf16_wgrad_bias(const void* A, const void* B, long long lda, long lo
   if (bias_grad == nullptr) return TN_EINVAL;
   return gemm_launch(&A, &B, &lda, &ldb, &K, 1, 1, 1, C, nullptr, nullptr, M, N, ldc, 0, accumulate,
                      splitk > 1 ? splitk : 1, 0, workspace, workspace_bytes, stream, c_f32, bias_grad);
+}
+
+// A q / k projection with the rotary embedding in the epilogue: out[M, N] = rope(x W^T + bias), N = heads x head_dim
+// (head_dim 64 or 128; N % 256 == 0 for 128, N % 64 == 0 for 64), cos / sin [M, head_dim / 2] bf16 = one table row per
+// output row (tn_rope_table).  -22 unless K % 64 == 0 and the pitches are multiples of 8.
+int tn_gemm_bf16_rope(const void* x, const void* w, const void* bias, const void* cos_t, const void* sin_t, void* out, int M,
+                      int N, int K, long long ldx, long long ldw, long long ldc, int head_dim, void* stream) {
+  using namespace tn::gemm;
+  if (M <= 0 || N <= 0 || K <= 0 || (K % 64) || (ldx % 8) || (ldw % 8) || (ldc % 8) || ldc < N) return TN_EINVAL;
+  if (!((head_dim == 128 && N % 256 == 0) || (head_dim == 64 && N % 64 == 0))) return TN_EINVAL;
+  if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)out) & 15) return TN_EINVAL;
+  if (((uintptr_t)cos_t | (uintptr_t)sin_t | (uintptr_t)bias) & 7) return TN_EINVAL;
+  if (cos_t == nullptr || sin_t == nullptr) return TN_EINVAL;
+  if ((long long)288 * ldx * 2 >= 0x7fffffffLL || (long long)288 * ldw * 2 >= 0x7fffffffLL) return TN_EINVAL;
+  if (TN_GEMM_DEFAULT_VARIANT >= 1000 || getenv("TN_GEMM_VARIANT") != nullptr) return TN_EINVAL;
+  Params p;
+  clear_params(p);
+  p.seg[0].A = (const tn::bf16_t*)x;
+  p.seg[0].B = (const tn::bf16_t*)w;
+  p.seg[0].lda = ldx;
+  p.seg[0].ldb = ldw;
+  p.seg[0].K = K;
+  p.seg[1] = p.seg[2] = p.seg[0];
+  p.stages = K / 64;
+  p.M = M;
+  p.N = N;
+  p.C = (tn::bf16_t*)out;
+  p.bias = (const tn::bf16_t*)bias;
+  p.ldc = ldc;
+  p.rope_cos = (const tn::bf16_t*)cos_t;
+  p.rope_sin = (const tn::bf16_t*)sin_t;
+  p.rope_d = head_dim;
+  p.nbm = (M + BM - 1) / BM;
+  p.nbn = (N + BN - 1) / BN;
+  p.ntiles = p.nbm * p.nbn;
+  const int ncu = num_cus();
+  const dim3 grid(persistent_now() && p.ntiles > ncu ? ncu : p.ntiles);
+  hipLaunchKernelGGL((gemm_kernel<false, false, kDPL, kDAS, kDIL, false, false, false, EPI_ROPE>), grid, dim3(NT), 0,
+                     (hipStream_t)stream, p);
+  TN_LAUNCH_CHECK();
+  return TN_OK;
 }
 
 // C[M,N] = A[M,K] · B[N,K]^T (+ bias) (+ C if accumulate); optional transposed copy Ct[N,M]: the round-2 entry point,

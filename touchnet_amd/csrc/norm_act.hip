@@ -644,9 +644,7 @@ __global__ __launch_bounds__(256) void rope_apply_kernel(const T* xq, const T* x
     sv.unpack(s);
 #pragma unroll
     for (int j = 0; j < N; ++j) {
-      const float sj = sign * s[j];
-      ya[j] = a[j] * c[j] - b[j] * sj;
-      yb[j] = b[j] * c[j] + a[j] * sj;
+      rope_rotate(a[j], b[j], c[j], sign * s[j], ya[j], yb[j]);
     }
     lo.pack(ya);
     hi.pack(yb);
@@ -671,8 +669,10 @@ __global__ void rope_apply_scalar_kernel(const T* xq, const T* xk, T* yq, T* yk,
     T* o = ((hd < hq) ? yq : yk) + off;
     const float a = Elem<T>::ld(p + i), b = Elem<T>::ld(p + half + i);
     const float c = Elem<T>::ld(cos_t + tok * half + i), s = sign * Elem<T>::ld(sin_t + tok * half + i);
-    Elem<T>::st(o + i, a * c - b * s);
-    Elem<T>::st(o + half + i, b * c + a * s);
+    float ya, yb;
+    rope_rotate(a, b, c, s, ya, yb);
+    Elem<T>::st(o + i, ya);
+    Elem<T>::st(o + half + i, yb);
   }
 }
 

@@ -611,6 +611,35 @@ def gemm_swiglu_bwd(dy2: torch.Tensor, w_down: torch.Tensor, gate: torch.Tensor,
     return dgate, dup
 
 
+def gemm_rope(x2: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], cos: torch.Tensor, sin: torch.Tensor,
+              head_dim: int) -> torch.Tensor:
+    """``rope(x2 @ weight^T + bias)`` [M, heads * head_dim] from ONE launch (tn_gemm_bf16_rope): the rotary embedding of a
+    q / k projection in the GEMM's epilogue, bit-identical to the projection followed by `apply_rope`.  cos / sin: the
+    bf16 [M, head_dim / 2] tables of `rope_tables`."""
+    M, K = x2.shape
+    N = weight.shape[0]
+    if (not _bf16_rows(x2, weight) or weight.shape[1] != K or cos.dtype != torch.bfloat16 or sin.dtype != torch.bfloat16
+            or tuple(cos.shape) != (M, head_dim // 2) or tuple(sin.shape) != (M, head_dim // 2)
+            or not cos.is_contiguous() or not sin.is_contiguous()):
+        raise _C.KernelError("gemm_rope: bf16 x [M, K], weight [N, K], cos / sin [M, head_dim / 2]")
+    if bias is not None:
+        bias = _c(bias).to(torch.bfloat16)
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=x2.device)
+    _C.check(_C.lib().tn_gemm_bf16_rope(_p(x2), _p(weight), _p(bias), _p(cos), _p(sin), _p(out), M, N, K, x2.stride(0),
+                                        weight.stride(0), N, int(head_dim), _cur()), "tn_gemm_bf16_rope")
+    return out
+
+
+def rope_epilogue_ok(M: int, N: int, K: int, head_dim: int) -> bool:
+    """shapes tn_gemm_bf16_rope takes (and the hand-written kernel is the configured GEMM for)"""
+    return (ROPE_EPILOGUE and _own(M, N, (K,)) and K % 64 == 0
+            and (not SPLIT_K or split_k(M, N, K, False, False) == 1)     # (a split-K product sums in another order)
+            and ((head_dim == 128 and N % 256 == 0) or (head_dim == 64 and N % 64 == 0))
+            and not os.environ.get("TN_GEMM_VARIANT"))
+
+
+ROPE_EPILOGUE = os.environ.get("TN_ROPE_EPILOGUE", "1") != "0"          # (A/B switch)
+
 # A/B switches of the round-5 fusions (measurements; both default on): SwiGLU inside the gate/up and down-dgrad epilogues,
 # the MLP's three weight gradients as one grouped launch
 MLP_EPILOGUE = os.environ.get("TN_MLP_EPILOGUE", "1") != "0"
@@ -887,9 +916,10 @@ class _LinearGroup(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, n, wgrad, dgrad_tn, *wb):
         ws, bs = wb[:n], wb[n:]
-        src = None
-        if isinstance(wgrad, tuple):                       # (wgrad, norm_src): op-level selective recomputation, see
-            wgrad, src = wgrad                             # `norm_source` below
+        src = rope = None
+        if isinstance(wgrad, tuple):                       # (wgrad, norm_src, rope): op-level selective recomputation
+            wgrad, src, rope = wgrad                       # (`norm_source`) / rotary embedding of outputs (`linear_group`)
+        ctx.rope = rope
         if src is not None:
             # x = RMSNorm(h) * w_norm is a ROW kernel's output: keep its input (which the norm's own backward saves
             # anyway) and recompute x in the backward — bit-identical, the kernel norms the stored h
@@ -902,7 +932,26 @@ class _LinearGroup(torch.autograd.Function):
         ctx.wgrad, ctx.dgrad_tn = wgrad, dgrad_tn
         if LINEAR_GEMM == "own" and x.is_cuda:
             x2 = _c(x.reshape(-1, x.shape[-1]))
-            return tuple(_mm_tn(x2, _c(w), b).view(*x.shape[:-1], w.shape[0]) for w, b in zip(ws, bs))
+            outs = []
+            for i, (w, b) in enumerate(zip(ws, bs)):
+                if rope is not None and i in rope[3]:
+                    # the rotary embedding of this projection in the GEMM's epilogue (or, for shapes the epilogue does not
+                    # take, behind it: same bits)
+                    cos, sin, D = rope[0], rope[1], rope[2]
+                    M_ = x2.shape[0]
+                    if (rope_epilogue_ok(M_, w.shape[0], x2.shape[1], D) and _bf16_rows(x2, w)
+                            and cos.dtype == torch.bfloat16 and tuple(cos.shape) == (M_, D // 2)):
+                        y = gemm_rope(x2, _c(w), b, cos, sin, D)
+                    else:
+                        y = _mm_tn(x2, _c(w), b)
+                        y4 = y.view(1, M_, -1, D)
+                        y = L.rope_apply(y4, y4.new_empty(1, M_, 0, D), cos, sin, False)[0].view(M_, -1)
+                    outs.append(y.view(*x.shape[:-1], w.shape[0]))
+                else:
+                    outs.append(_mm_tn(x2, _c(w), b).view(*x.shape[:-1], w.shape[0]))
+            return tuple(outs)
+        if rope is not None:
+            raise _C.KernelError("linear_group: `rope` needs the hand-written GEMM path (device tensors)")
         return tuple(torch.nn.functional.linear(x, w, b) for w, b in zip(ws, bs))
 
     @staticmethod
@@ -917,6 +966,18 @@ class _LinearGroup(torch.autograd.Function):
         M = x2.shape[0]
         dys = [torch.zeros(M, w.shape[0], dtype=x.dtype, device=x.device) if d is None else _c(d).reshape(M, -1)
                for d, w in zip(dys, ws)]
+        if ctx.rope is not None:
+            # the outputs were rotated: their gradients are rotated back (the transposed rotation) before the products
+            cos, sin, D, which = ctx.rope
+            which = sorted(which)
+            for a in range(0, len(which), 2):
+                i, j = which[a], which[a + 1] if a + 1 < len(which) else None
+                gi = dys[i].view(1, M, -1, D)
+                gj = dys[j].view(1, M, -1, D) if j is not None else gi.new_empty(1, M, 0, D)
+                ri, rj = L.rope_apply(gi, gj, cos, sin, True)
+                dys[i] = ri.view(M, -1)
+                if j is not None:
+                    dys[j] = rj.view(M, -1)
         need_x, need_w = ctx.needs_input_grad[0], [ctx.needs_input_grad[4 + i] for i in range(n)]
         Ns = [w.shape[0] for w in ws]
         hip_ok = x.dtype == torch.bfloat16 and (x.is_cuda or x.is_meta) and _tn_ok(M, K, Ns)
@@ -994,9 +1055,11 @@ def norm_source(h, norm_weight, eps):
     return (h.detach(), norm_weight.detach(), float(eps))
 
 
-def linear_group(x, layers, wgrad: str = "tn", dgrad_tn: bool = True, norm_src=None):
+def linear_group(x, layers, wgrad: str = "tn", dgrad_tn: bool = True, norm_src=None, rope=None):
     """``layers``: list of (weight [N_i, K], bias [N_i] | None) sharing the input ``x`` -> list of outputs.
-    ``norm_src``: see `norm_source`."""
+    ``norm_src``: see `norm_source`.  ``rope = (cos, sin, head_dim, (i, j, ..))``: outputs i, j, .. ([.., heads * head_dim])
+    are returned ROTATED — the rotary embedding `apply_rope` would apply to them, computed in the projection's epilogue
+    (`gemm_rope`); cos / sin as from `rope_tables`, one row per row of x."""
     if wgrad not in ("tn", "nt", "nt_fused"):
         raise ValueError(f"linear_group: wgrad={wgrad!r}")
     if not (x.is_cuda or x.is_meta):
@@ -1005,7 +1068,10 @@ def linear_group(x, layers, wgrad: str = "tn", dgrad_tn: bool = True, norm_src=N
     bs = [b for _, b in layers]
     if norm_src is not None and (tuple(norm_src[0].shape) != tuple(x.shape) or norm_src[0].dtype != x.dtype):
         raise _C.KernelError("linear_group: norm_src does not describe x")
-    return list(_LinearGroup.apply(x, len(ws), (wgrad, norm_src) if norm_src is not None else wgrad, dgrad_tn, *ws, *bs))
+    if rope is not None:
+        rope = (rope[0].detach(), rope[1].detach(), int(rope[2]), tuple(int(i) for i in rope[3]))
+    packed = (wgrad, norm_src, rope) if (norm_src is not None or rope is not None) else wgrad
+    return list(_LinearGroup.apply(x, len(ws), packed, dgrad_tn, *ws, *bs))
 
 
 class _SwiGLUMLP(torch.autograd.Function):

@@ -72,12 +72,13 @@ class Attention(nn.Module):
         # one autograd node for the three projections of x: their weight gradients run as ONE GEMM in the forward
         # layout (functional._LinearGroup); parameters keep the HF names and shapes
         kw = {"norm_src": norm_src} if norm_src is not None else {}
+        # q and k come back ROTATED: the rotary embedding sits in the epilogue of their projections (functional.gemm_rope;
+        # shapes the epilogue does not take are rotated behind the product — same bits)
         q, k, v = ops().linear_group(x, [(self.q_proj.weight, self.q_proj.bias), (self.k_proj.weight, self.k_proj.bias),
-                                         (self.v_proj.weight, self.v_proj.bias)], **kw)
+                                         (self.v_proj.weight, self.v_proj.bias)], rope=(cos, sin, self.head_dim, (0, 1)), **kw)
         q = q.view(B, T, self.num_heads, self.head_dim)
         k = k.view(B, T, self.num_kv_heads, self.head_dim)
         v = v.view(B, T, self.num_kv_heads, self.head_dim)
-        q, k = ops().apply_rope(q, k, cos, sin)
         if cp is not None:            # context parallel, all-gather rotate method (utils/context_parallel.py)
             a = ops().packed_attention_sharded(q, cp.gather_seq(k), cp.gather_seq(v), mask, cp.seq_shard(),
                                                self.scaling)
