@@ -119,6 +119,14 @@ class Trainer:
             # of the process environment (TN_GEMM_PERSIST in the environment still overrides it).
             from touchnet_amd import _C
             _C.lib().tn_gemm_set_persistent(0)
+        elif self.device.type == "cuda":
+            # (set BOTH ways: the switch is process-wide, and a Trainer without collectives built behind a sharded one —
+            #  tests, A/B benches in one process — must not inherit its per-tile launches)
+            from touchnet_amd import _C
+            _C.lib().tn_gemm_set_persistent(1)
+        if self.device.type == "cuda":
+            import touchnet_amd.functional as _F
+            _F.WGRAD_RETURNS_NEED_SYNC = False      # (the sharding engines built below switch it on for themselves)
         if self.spec.additional_pre_init_fn:
             self.spec.additional_pre_init_fn(job)                      # train.py:121-122
         torch.manual_seed(job.training_seed)

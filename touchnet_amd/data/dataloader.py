@@ -174,6 +174,14 @@ def build_datapipe(cfg, tokenizer, dp_rank: int, dp_world_size: int):
         pipe = stage(functions.filter_samples, cfg)
         return stage(batch_text, cfg, tokenizer)
     augment = any(getattr(cfg, a, False) for a in ("audiofeat_spec_aug", "audiofeat_spec_sub", "audiofeat_spec_trim"))
+    # the device pass (tn_feat_augment) holds at most 16 stripes / substitutions of a kind per utterance; the reference takes
+    # any count (touchnet/data/functions.py:193-255) — say so here, not as a bare -22 from the kernel in the middle of an epoch
+    for flag, keys in (("audiofeat_spec_aug", ("audiofeat_spec_aug_num_t_mask", "audiofeat_spec_aug_num_f_mask")),
+                       ("audiofeat_spec_sub", ("audiofeat_spec_sub_num_t_sub",))):
+        for k in keys:
+            if getattr(cfg, flag, False) and int(getattr(cfg, k, 0)) > 16:
+                raise ValueError(f"{k} = {getattr(cfg, k)}: the MI355X augmentation kernel takes at most 16 per utterance "
+                                 f"(the recipes use 1-3)")
     if kind == "touch_audio":
         labels_from_audio = hasattr(tokenizer, "quantizer") or type(tokenizer).__name__ == "BestRQTokenizer"
         if not labels_from_audio:

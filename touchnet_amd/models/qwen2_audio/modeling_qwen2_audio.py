@@ -270,6 +270,10 @@ class Qwen2AudioPackedForConditionalGeneration(nn.Module):
                 # shape: the number of valid rows is the number of AUDIO positions, known from the tensor's size
                 total = audio_positions.numel()
                 ends = torch.cumsum(audio_output_lengths.to(torch.int64), 0)
+                if os.environ.get("TN_DEBUG_CHECKS") == "1" and int(ends[-1]) > total:
+                    # the reference raises here (`__init__.py:215-219` only pads when features are FEWER); the product
+                    # path cannot afford the host read-back per step, so the check is a debugging switch
+                    raise ValueError(f"audio features ({int(ends[-1])}) outnumber the AUDIO tokens ({total})")
                 idx = torch.arange(total, device=feats.device)
                 clip = torch.searchsorted(ends, idx, right=True).clamp_(max=n - 1)
                 src = clip * Ta + (idx - (ends - audio_output_lengths)[clip])

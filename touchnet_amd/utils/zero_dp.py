@@ -466,5 +466,19 @@ def build_flat_engine_optimizer(model: nn.Module, make_optimizer):
                     a, e = max(lo, o), min(hi, o + p.numel())
                     if src is not None and e > a:
                         m[a - lo:e - lo].copy_(src.reshape(-1)[a - o:e - o])
+        # The bf16 buffers were broadcast from rank 0 by the engine; the masters above come from THIS rank's float32 draw.
+        # They agree only if every rank drew the same values (the Trainer seeds all ranks alike).  A rank whose draw
+        # differs would train a replica that drifts away silently: compare a checksum of the float32 values over the
+        # group (one tiny all-reduce at start-up) and refuse loudly.
+        group = mark["mesh"].get_group()
+        if engine.world > 1 and not engine.emulated:
+            sums = torch.stack([src.double().sum() for src in keep.values()]).sum().reshape(1)
+            hi_, lo_ = sums.clone(), sums.clone()
+            dist.all_reduce(hi_, op=dist.ReduceOp.MAX, group=group)
+            dist.all_reduce(lo_, op=dist.ReduceOp.MIN, group=group)
+            if float(hi_) != float(lo_):
+                raise RuntimeError("flat data-parallel engine: the ranks hold different initial parameter values (checksum "
+                                   f"{float(lo_)} .. {float(hi_)}): seed every rank alike or broadcast the model before "
+                                   "build_optimizers_fn")
     model._tn_flat_engine = engine
     return FlatEngineOptimizer(engine, inner)
