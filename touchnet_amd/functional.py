@@ -950,9 +950,13 @@ class _LinearGroup(torch.autograd.Function):
                 else:
                     outs.append(_mm_tn(x2, _c(w), b).view(*x.shape[:-1], w.shape[0]))
             return tuple(outs)
-        if rope is not None:
-            raise _C.KernelError("linear_group: `rope` needs the hand-written GEMM path (device tensors)")
-        return tuple(torch.nn.functional.linear(x, w, b) for w, b in zip(ws, bs))
+        outs = [torch.nn.functional.linear(x, w, b) for w, b in zip(ws, bs)]
+        if rope is not None:                               # (library GEMM path / meta tensors: rotate behind the product)
+            cos, sin, D = rope[0], rope[1], rope[2]
+            for i in rope[3]:
+                y4 = outs[i].reshape(1, -1, outs[i].shape[-1] // D, D)
+                outs[i] = L.rope_apply(y4, y4.new_empty(1, y4.shape[1], 0, D), cos, sin, False)[0].reshape(outs[i].shape)
+        return tuple(outs)
 
     @staticmethod
     def backward(ctx, *dys):
