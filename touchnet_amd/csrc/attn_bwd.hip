@@ -409,9 +409,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(
 template <int D>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(
     const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
-    const bf16_t* __restrict__ dO, const float* __restrict__ LSE2, const float* __restrict__ Delta,
+    const bf16_t* __restrict__ dO, const float* __restrict__ LSE2, float* __restrict__ Delta,
     bf16_t* __restrict__ dQ, const int* __restrict__ doc, AttnMeta meta, QView qv, int T, int Nh, int Nkv,
-    float scale, float scale_log2) {
+    float scale, float scale_log2, const bf16_t* __restrict__ O) {
+  // O != null: this kernel ALSO forms delta = rowsum(dO o O) of its 128 query rows — it holds the dO rows in registers
+  // anyway — and writes it to `Delta` for the dK / dV pass, which is launched BEHIND it (round 5: the separate
+  // attn_delta_kernel pass, 64 launches and 2.5 ms per Qwen2-Audio step, is gone).  O == null: `Delta` is read.
   constexpr int BM = 128, BN = 64, NST = 2;
   constexpr int KSTEPS = D / 16, DBLK = D / 32;
   using Tile = PTile<BN, D>;
@@ -440,22 +443,46 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(
   const bool qvalid = (32 * wave + l31 < qleft) && (qrow < T);
 
   bf16x8_t qreg[KSTEPS], doreg[KSTEPS];
+  float dsum = 0.f;                         // this lane's share of rowsum(dO o O): slots 8 hi .. 8 hi + 7 of every k-step
   {
     const size_t off = (((size_t)b * qv.rpb + (qvalid ? lrow : 0)) * Nh + h) * D + 8 * hi;
+    uint4 orow[KSTEPS];                     // (all loads of the row are issued before the first use: ONE memory round trip)
 #pragma unroll
     for (int s = 0; s < KSTEPS; ++s) {
       uint4 a = make_uint4(0, 0, 0, 0), c = make_uint4(0, 0, 0, 0);
+      orow[s] = make_uint4(0, 0, 0, 0);
       if (qvalid) {
         a = *reinterpret_cast<const uint4*>(Q + off + 16 * s);
         c = *reinterpret_cast<const uint4*>(dO + off + 16 * s);
+        if (O != nullptr) orow[s] = *reinterpret_cast<const uint4*>(O + off + 16 * s);
       }
       qreg[s] = as_bf16x8(a);
       doreg[s] = as_bf16x8(c);
     }
+    if (O != nullptr) {
+#pragma unroll
+      for (int s = 0; s < KSTEPS; ++s) {
+        Vec16<bf16_t> ov, gv;
+        float of[8], gf[8];
+        ov.raw = orow[s];
+        const u32x4_t g4 = __builtin_bit_cast(u32x4_t, doreg[s]);
+        gv.raw = make_uint4(g4.x, g4.y, g4.z, g4.w);
+        ov.unpack(of);
+        gv.unpack(gf);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dsum += of[e] * gf[e];
+      }
+    }
   }
   const int dq = qvalid ? doc[(size_t)b * T + qrow] : 0;
   const float lse2 = qvalid ? LSE2[((size_t)b * Nh + h) * qv.rpb + lrow] : INFINITY;
-  const float delta = qvalid ? Delta[((size_t)b * Nh + h) * qv.rpb + lrow] : 0.f;
+  float delta;
+  if (O != nullptr) {
+    delta = dsum + __shfl_xor(dsum, 32, 64);            // (both 32-lane halves hold the same rows)
+    if (qvalid && hi == 0) Delta[((size_t)b * Nh + h) * qv.rpb + lrow] = delta;
+  } else {
+    delta = qvalid ? Delta[((size_t)b * Nh + h) * qv.rpb + lrow] : 0.f;
+  }
 
   const int* m_min = meta.tmin + (size_t)b * meta.nt;
   const int* m_max = meta.tmax + (size_t)b * meta.nt;
@@ -672,9 +699,18 @@ static int attn_bwd_launch(const void* q, const void* k, const void* v, const vo
   const size_t rows = (size_t)B * qv.rpb * Nh;
   dim3 gq(Nh, qv.tiles(0, 128) + qv.tiles(1, 128), B), gk(Nkv, (T + 127) / 128, B), block(256);
   const bf16_t *Q = (const bf16_t*)q, *K = (const bf16_t*)k, *V = (const bf16_t*)v, *dO = (const bf16_t*)dout;
+  // TN_ATTN_DELTA_KERNEL=1: the round-4 order (separate delta pass, dK / dV, dQ) for A/B runs; default: dQ first — it forms
+  // delta from the dO / O rows it loads anyway and leaves it for the dK / dV pass behind it
+  static const bool delta_pass = [] { const char* e = getenv("TN_ATTN_DELTA_KERNEL"); return e && e[0] == '1'; }();
+  const bf16_t* O_ = delta_pass ? nullptr : (const bf16_t*)o;
+  (void)rows;
   if (D == 128) {
-    hipLaunchKernelGGL((attn_delta_kernel<128>), dim3((rows * 16 + 255) / 256), block, 0, st, (const bf16_t*)o, dO,
-                       delta, B, qv.rpb, Nh);
+    if (delta_pass)
+      hipLaunchKernelGGL((attn_delta_kernel<128>), dim3((rows * 16 + 255) / 256), block, 0, st, (const bf16_t*)o, dO,
+                         delta, B, qv.rpb, Nh);
+    else
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<128>), gq, block, 0, st, Q, K, V, dO, lse2, delta, (bf16_t*)dq, doc, m,
+                         qv, T, Nh, Nkv, scale, sl2, O_);
     if (bwd_kv_split() || qv.bidir) {          // (the fused pass is causal only)
       hipLaunchKernelGGL((attn_bwd_kv_kernel<128, 0>), gk, block, 0, st, Q, K, V, dO, lse2, delta, (bf16_t*)dk,
                          (bf16_t*)dv, doc, m, qv, T, Nh, Nkv, scale, sl2);
@@ -684,15 +720,21 @@ static int attn_bwd_launch(const void* q, const void* k, const void* v, const vo
       launch_attn_bwd_kv_fused128(Q, K, V, dO, lse2, delta, (bf16_t*)dk, (bf16_t*)dv, doc, m, qv, B, T, Nh, Nkv, scale,
                                   sl2, st);
     }
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<128>), gq, block, 0, st, Q, K, V, dO, lse2, delta, (bf16_t*)dq, doc, m,
-                       qv, T, Nh, Nkv, scale, sl2);
+    if (delta_pass)
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<128>), gq, block, 0, st, Q, K, V, dO, lse2, delta, (bf16_t*)dq, doc, m,
+                         qv, T, Nh, Nkv, scale, sl2, O_);
   } else {
-    hipLaunchKernelGGL((attn_delta_kernel<64>), dim3((rows * 8 + 255) / 256), block, 0, st, (const bf16_t*)o, dO,
-                       delta, B, qv.rpb, Nh);
+    if (delta_pass)
+      hipLaunchKernelGGL((attn_delta_kernel<64>), dim3((rows * 8 + 255) / 256), block, 0, st, (const bf16_t*)o, dO,
+                         delta, B, qv.rpb, Nh);
+    else
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<64>), gq, block, 0, st, Q, K, V, dO, lse2, delta, (bf16_t*)dq, doc, m,
+                         qv, T, Nh, Nkv, scale, sl2, O_);
     hipLaunchKernelGGL((attn_bwd_kv_kernel<64, 2>), gk, block, 0, st, Q, K, V, dO, lse2, delta, (bf16_t*)dk,
                        (bf16_t*)dv, doc, m, qv, T, Nh, Nkv, scale, sl2);
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<64>), gq, block, 0, st, Q, K, V, dO, lse2, delta, (bf16_t*)dq, doc, m,
-                       qv, T, Nh, Nkv, scale, sl2);
+    if (delta_pass)
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<64>), gq, block, 0, st, Q, K, V, dO, lse2, delta, (bf16_t*)dq, doc, m,
+                         qv, T, Nh, Nkv, scale, sl2, O_);
   }
   TN_LAUNCH_CHECK();
   return TN_OK;
