@@ -185,7 +185,9 @@ template <int PLACE, bool IS_A> constexpr int piece_at(int pos) {
 }
 
 // ---- operand stream: which bytes the next operand stage comes from -------------------------------------------------------
-template <bool KMAJ>
+// (M16: the stage image the 16x16x32 kernel reads — contraction-major images swap the two 32-byte halves of every 64-byte
+//  group in the k-rows with bit 3 set, see Kernel16)
+template <bool KMAJ, bool M16 = false>
 struct Stream {
   __amdgpu_buffer_rsrc_t rs;
   int soff;      // byte offset of the next stage inside the descriptor
@@ -212,7 +214,8 @@ struct Stream {
       for (int q = 0; q < 4; ++q) {
         const int k = wave * 8 + q * 2 + (lane >> 5);
         const int u = lane & 31;
-        voff[q] = (TN_GEMM_ABLATE == 6 ? (k & 1) : k) * ld2 + ((((u >> 2) ^ (k & 3)) << 6) | ((u & 3) << 4));
+        const int ch = M16 ? ((u & 3) ^ (((k >> 3) & 1) << 1)) : (u & 3);
+        voff[q] = (TN_GEMM_ABLATE == 6 ? (k & 1) : k) * ld2 + ((((u >> 2) ^ (k & 3)) << 6) | (ch << 4));
       }
     }
   }
@@ -1111,6 +1114,616 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const Params p) {
   Kernel<AK, BK, PLACE, ASYM, ILV, HAS_CT, SPLITK, OUT_F32, EPI>::run(p, smem);
 }
 
+// =====================================================================================================================
+// Kernel16: the same workgroup geometry, stage ring, DMA placement and persistent tile walk as Kernel above, with
+// v_mfma_f32_16x16x32_bf16 instead of v_mfma_f32_32x32x16_bf16.  Why (round 5, profiles/r05p_*): with operands in
+// registers only the 32x32x16 shape SUSTAINS 1.73-1.78 PF on this chip — the 1.67 GHz the GEMM was always measured at —
+// and the 16x16x32 shape 1.98-1.99 PF (half the accumulator register traffic per flop): the "power limit" of the
+// kernel was its instruction shape (hipBLASLt's gfx950 kernels issue 16x16x32).
+//  * wave tile 128 x 64 = 8 x 4 blocks of 16 x 16, accumulators f32x4 [8][4] (the same 128 registers)
+//  * a 64-deep stage = two 32-deep halves; a "quarter" = 16 MFMAs = A blocks 4 part .. 4 part + 3 (part = quarter & 1) of
+//    half quarter >> 1 against the half's four B blocks.  Fragment sets: 4 A fragments per quarter (double buffered),
+//    4 B fragments per half (double buffered); one fragment read behind every second MFMA.
+//  * operand fragment of v_mfma_f32_16x16x32: lane l holds row l & 15, contraction slots 8 (l >> 4) .. + 7:
+//      ROW   one ds_read_b128 at row * 128 + ((4 half + (l >> 4)) ^ ((row >> 1) & 7)) * 16   (same image as Kernel)
+//      KMAJ  two ds_read_b64_tr_b16: the 16 lanes of group g4 = l >> 4 point at k-rows 32 half + 8 g4 + (0..3) [+ 4] x the
+//            32 bytes of a 16-row block.  Lanes 0-15 and 16-31 are served together and would hit the same banks (their
+//            k-rows are 8 apart: same (k & 3) group swizzle), so the IMAGE swaps the two 32-byte halves of every 64-byte
+//            group in k-rows with bit 3 set (Stream<.., M16>): the second group reads the other half.
+//  * result of mfma(b, a): lane holds column m = l & 15 of its 16 x 16 block, registers r = rows n = 4 (l >> 4) + r
+// =====================================================================================================================
+typedef f32x4_t Acc16[8][4];
+#ifndef TN_G16_RSTEP
+#define TN_G16_RSTEP 1
+#endif
+
+template <bool AK, bool BK, int PLACE, int EPI = EPI_PLAIN>
+struct Kernel16 {
+  static_assert(EPI == EPI_PLAIN || EPI == EPI_SWIGLU_FWD || EPI == EPI_SWIGLU_BWD || EPI == EPI_ROPE,
+                "Kernel16: plain / SwiGLU / RoPE epilogues (the weight-gradient modes stay on Kernel)");
+  static_assert(!AK, "Kernel16 is used where it is faster: row-stored A (forward and input-gradient products)");
+  static_assert(EPI != EPI_SWIGLU_FWD || !BK, "SwiGLU forward: x W^T layout");
+  static_assert(EPI != EPI_SWIGLU_BWD || BK, "SwiGLU backward: dY W layout");
+  static_assert(EPI != EPI_ROPE || !BK, "RoPE epilogue: x W^T layout");
+  static constexpr int BN_EFF = EPI == EPI_SWIGLU_FWD ? 128 : BN;
+  static __device__ __forceinline__ float sigm(float x) { return sigmoid_fast(x); }
+  static __device__ __forceinline__ float lo16(uint32_t w) { return __uint_as_float(w << 16); }
+  static __device__ __forceinline__ float hi16(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+  static __device__ __forceinline__ float rbf(float v) { return __uint_as_float(((uint32_t)f2bf(v)) << 16); }
+  template <bool KMAJ>
+  struct F4 {
+    bf16x8_t v[4];
+    u32x2_t h[KMAJ ? 4 : 1][2];
+  };
+  // per-lane LDS offsets.  ROW: x[half]; block b of the wave's rows at + b * 2048.  KMAJ: x[G] for the 64-byte group G of
+  // the wave's 32-row pairs, x ^ 32 for the odd 16-row block of the pair; k-row offsets are compile-time.
+  template <bool KMAJ, int NB /* 16-row blocks: 8 (A) or 4 (B) */>
+  struct Reader {
+    int x[KMAJ ? NB / 2 : 2];
+    __device__ __forceinline__ Reader(int lane, int row0) {
+      const int l15 = lane & 15, g4 = lane >> 4;
+      if constexpr (!KMAJ) {
+        const int f = (l15 >> 1) & 7;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) x[h] = (row0 + l15) * 128 + (((4 * h + g4) ^ f) << 4);
+      } else {
+        const int j = l15 >> 2, w = l15 & 3;
+#pragma unroll
+        for (int g = 0; g < NB / 2; ++g)
+          x[g] = (8 * g4 + j) * 512 + w * 8 + ((((row0 >> 5) + g) ^ j) << 6) + (g4 & 1) * 32;
+      }
+    }
+    // fragment I (0..3) of the set: 16-row block BLK of the wave's rows, half H of the stage
+    template <int H, int BLK, int I>
+    __device__ __forceinline__ void read(const char* smem, int sbase, F4<KMAJ>& f) const {
+      if constexpr (!KMAJ) {
+        f.v[I] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(smem + sbase + x[H] + BLK * 2048));
+      } else {
+        const uint32_t a = (uint32_t)(size_t)(lds_ptr_t)smem + (uint32_t)(sbase + (x[BLK >> 1] ^ ((BLK & 1) * 32)));
+        f.h[I][0] = ds_tr16<(32 * H) * 512>(a);
+        f.h[I][1] = ds_tr16<(32 * H + 4) * 512>(a);
+      }
+    }
+  };
+  template <bool KMAJ>
+  static __device__ __forceinline__ void retire(F4<KMAJ>& f) {
+    if constexpr (KMAJ) {
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(f.h[0][0]), "+v"(f.h[0][1]), "+v"(f.h[1][0]), "+v"(f.h[1][1]), "+v"(f.h[2][0]), "+v"(f.h[2][1]),
+                     "+v"(f.h[3][0]), "+v"(f.h[3][1]));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const u32x4_t t = {f.h[i][0].x, f.h[i][0].y, f.h[i][1].x, f.h[i][1].y};
+        f.v[i] = __builtin_bit_cast(bf16x8_t, t);
+      }
+    }
+  }
+
+  static __device__ __forceinline__ void run(const Params& p, char* smem) {
+    const int tid = threadIdx.x;
+    int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int bid = blockIdx.x, G = gridDim.x;
+    const int tiles = p.ntiles;
+    const int mine = (tiles - bid + G - 1) / G;
+    auto origin = [&](int k, int& m0, int& n0) {
+      int tm, tn;
+      tile_of_block(p.tile0 + bid + k * G, p.nbm, p.nbn, tm, tn);
+      m0 = tm * BM;
+      n0 = tn * BN_EFF;
+    };
+    Stream<AK, true> sA;
+    Stream<BK, true> sB;
+    int ka = 0, kb = 0;
+    auto open_a = [&](int s) {
+      int m0, n0;
+      origin(ka, m0, n0);
+      sA.open(p.seg[s].A, p.seg[s].lda, p.seg[s].K, p.M, m0, wave, lane);
+      sA.seg = s;
+    };
+    // (B stage images of the fused epilogues: the per-DMA-wave row choices of Kernel::open_b — they concern LDS rows, not
+    //  the MFMA shape)
+    const bool b_wave0 = EPI == EPI_SWIGLU_FWD || (EPI == EPI_ROPE && p.rope_d == 128);
+    auto open_b = [&](int s) {
+      int m0, n0;
+      origin(kb, m0, n0);
+      if constexpr (EPI == EPI_SWIGLU_FWD) {
+        sB.open((wave & 1) ? p.seg[1].B : p.seg[0].B, p.seg[0].ldb, p.seg[0].K, p.N, n0 + (wave >> 1) * 32, 0, lane);
+      } else if constexpr (EPI == EPI_ROPE) {
+        if (p.rope_d == 128)
+          sB.open(p.seg[0].B, p.seg[0].ldb, p.seg[0].K, p.N, n0 + (wave >> 2) * 128 + (wave & 1) * 64 + ((wave >> 1) & 1) * 32,
+                  0, lane);
+        else
+          sB.open(p.seg[0].B, p.seg[0].ldb, p.seg[0].K, p.N, n0, wave, lane);
+      } else {
+        sB.open(p.seg[s].B, p.seg[s].ldb, p.seg[s].K, p.N, n0, wave, lane);
+      }
+      sB.seg = s;
+    };
+    auto adv_a = [&]() {
+      sA.soff += sA.step;
+      if (--sA.left == 0) {
+        if (sA.seg + 1 < p.nseg) open_a(sA.seg + 1);
+        else if (++ka < mine) open_a(0);
+        else sA.kill(p.C);
+      }
+    };
+    auto adv_b = [&]() {
+      sB.soff += sB.step;
+      if (--sB.left == 0) {
+        if (sB.seg + 1 < p.nseg) open_b(sB.seg + 1);
+        else if (++kb < mine) open_b(0);
+        else sB.kill(p.C);
+      }
+    };
+    auto piece_a = [&](int slot, int q) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(sA.rs, (lds_ptr_t)(smem + slot * SLOT + wave * 4096 + q * 1024), 16,
+                                               sA.voff[q], sA.soff, 0, 0);
+    };
+    auto piece_b = [&](int slot, int q) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(sB.rs, (lds_ptr_t)(smem + slot * SLOT + wave * 4096 + q * 1024), 16,
+                                               sB.voff[q], sB.soff, 0, 0);
+    };
+    open_a(0);
+    open_b(0);
+
+    Reader<AK, 8> ra(lane, wr * 128);
+    Reader<BK, 4> rb(lane, wc * 64);
+    Acc16 acc;
+    auto zero_acc = [&]() {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    };
+    zero_acc();
+    F4<AK> ae, ao;
+    F4<BK> be, bo;
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+
+    // read fragment R (0..3 = A blocks of quarter Q, 4..7 = the B blocks of half Q >> 1) of the quarter that follows
+    auto read_frag = [&](auto QC, auto RC, int sa, int sb, F4<AK>& a, F4<BK>& b) {
+      constexpr int Q = decltype(QC)::value, R = decltype(RC)::value;
+      if constexpr (R < 4) ra.template read<(Q >> 1), (Q & 1) * 4 + R, R>(smem, sa * SLOT, a);
+      else rb.template read<(Q >> 1), R - 4, R - 4>(smem, sb * SLOT, b);
+    };
+    // One quarter: 16 MFMAs of A part PART (fragments ca) against the half's B fragments cb; fragment r of the NEXT quarter
+    // NQ (4 A fragments, and with RB its half's 4 B fragments) is read behind MFMA 2 r; DMA pieces of positions
+    // P0 .. P0 + 7 go behind MFMAs 0, 2, .. 14 (P0 < 0: none).
+    auto quarter = [&](auto NQC, auto RBC, auto P0C, auto PARTC, const F4<AK>& ca, const F4<BK>& cb, F4<AK>& na,
+                       F4<BK>& nb, int nsa, int nsb, int dst_b, int dst_a) {
+      constexpr int P0 = decltype(P0C)::value, PART = decltype(PARTC)::value;
+      constexpr bool RB = decltype(RBC)::value;
+      auto step = [&](auto MC) {
+        constexpr int m = decltype(MC)::value, i = m >> 2, j = m & 3;
+        acc[PART * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cb.v[j], ca.v[i], acc[PART * 4 + i][j], 0, 0, 0);
+        TN_PIN();
+        // fragment reads behind the FIRST MFMAs of the quarter (TN_G16_RSTEP = MFMAs per read: 1 = reads 0..7 behind
+        // MFMAs 0..7, so the last one is 8+ MFMAs old when the quarter's fragments are retired)
+        if constexpr ((m % TN_G16_RSTEP) == 0 && m / TN_G16_RSTEP < 8) {
+          constexpr int r = m / TN_G16_RSTEP;
+          if constexpr (r < 4 || RB) {
+            read_frag(NQC, std::integral_constant<int, r>{}, nsa, nsb, na, nb);
+            TN_PIN();
+          }
+        }
+        if constexpr ((m & 1) == 0) {
+          constexpr int r = m >> 1;
+          constexpr int pb = P0 < 0 ? -1 : piece_at<PLACE, false>(P0 + r);
+          constexpr int pa = P0 < 0 ? -1 : piece_at<PLACE, true>(P0 + r);
+          if constexpr (pb >= 0) {
+            piece_b(dst_b, pb);
+            if constexpr (pb == 3) adv_b();
+            TN_PIN();
+          }
+          if constexpr (pa >= 0) {
+            piece_a(dst_a, pa);
+            if constexpr (pa == 3) adv_a();
+            TN_PIN();
+          }
+        }
+      };
+      step(std::integral_constant<int, 0>{});
+      step(std::integral_constant<int, 1>{});
+      step(std::integral_constant<int, 2>{});
+      step(std::integral_constant<int, 3>{});
+      step(std::integral_constant<int, 4>{});
+      step(std::integral_constant<int, 5>{});
+      step(std::integral_constant<int, 6>{});
+      step(std::integral_constant<int, 7>{});
+      step(std::integral_constant<int, 8>{});
+      step(std::integral_constant<int, 9>{});
+      step(std::integral_constant<int, 10>{});
+      step(std::integral_constant<int, 11>{});
+      step(std::integral_constant<int, 12>{});
+      step(std::integral_constant<int, 13>{});
+      step(std::integral_constant<int, 14>{});
+      step(std::integral_constant<int, 15>{});
+    };
+    auto early_pieces = [&](int dst_b, int dst_a) {
+      auto one = [&](auto MC) {
+        constexpr int m = decltype(MC)::value;
+        constexpr int pb = piece_at<PLACE, false>(m), pa = piece_at<PLACE, true>(m);
+        if constexpr (pb >= 0) {
+          piece_b(dst_b, pb);
+          if constexpr (pb == 3) adv_b();
+        }
+        if constexpr (pa >= 0) {
+          piece_a(dst_a, pa);
+          if constexpr (pa == 3) adv_a();
+        }
+      };
+      one(std::integral_constant<int, 0>{});
+      one(std::integral_constant<int, 1>{});
+      one(std::integral_constant<int, 2>{});
+      one(std::integral_constant<int, 3>{});
+      one(std::integral_constant<int, 4>{});
+      one(std::integral_constant<int, 5>{});
+      one(std::integral_constant<int, 6>{});
+      one(std::integral_constant<int, 7>{});
+    };
+    auto next = [](int s, int d) { s += d; return s >= 5 ? s - 5 : s; };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+
+#pragma unroll
+    for (int q = 0; q < 4; ++q) piece_a(0, q);
+    adv_a();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) piece_b(1, q);
+    adv_b();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) piece_a(2, q);
+    adv_a();
+    early_pieces(3, 4);
+    constexpr int kEarly = (Place<PLACE>::B[0] < 8) + (Place<PLACE>::B[1] < 8) + (Place<PLACE>::B[2] < 8) +
+                           (Place<PLACE>::B[3] < 8) + (Place<PLACE>::A[0] < 8) + (Place<PLACE>::A[1] < 8) +
+                           (Place<PLACE>::A[2] < 8) + (Place<PLACE>::A[3] < 8);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + kEarly) : "memory");
+    __builtin_amdgcn_s_barrier();
+    int sa = 0, sb = 1;
+    int pa = 4, pb = 3;
+
+    auto trip = [&](auto LASTC) {
+      constexpr bool LAST = decltype(LASTC)::value;
+      const int sa1 = next(sa, 2), sb1 = next(sb, 2);
+      __builtin_amdgcn_s_setprio(1);
+      // quarter 0 (half 0, A part 0): reads A of quarter 1
+      quarter(I1{}, F_{}, std::integral_constant<int, 8>{}, I0{}, ae, be, ao, bo, sa, sb, pb, pa);
+      retire(ao);
+      TN_PIN();
+      // quarter 1 (half 0, part 1): reads A of quarter 2 and B of half 1
+      quarter(I2{}, T_{}, std::integral_constant<int, 16>{}, I1{}, ao, be, ae, bo, sa, sb, pb, pa);
+      retire(ae);
+      retire(bo);
+      TN_PIN();
+      // quarter 2 (half 1, part 0): reads A of quarter 3
+      quarter(I3{}, F_{}, std::integral_constant<int, 24>{}, I0{}, ae, bo, ao, be, sa, sb, pb, pa);
+      __builtin_amdgcn_s_setprio(0);
+      retire(ao);
+      __builtin_amdgcn_s_waitcnt(0xc07f);                 // my reads of stage t are complete
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");    // A(t+1), B(t+1) landed; A(t+2) may still be in flight
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_setprio(1);
+      if constexpr (!LAST) {
+        // quarter 3 (half 1, part 1): the new piece set opens; reads A of quarter 0 and B of half 0 of stage t + 1
+        quarter(I0{}, T_{}, I0{}, I1{}, ao, bo, ae, be, sa1, sb1, sa, sb);
+        __builtin_amdgcn_s_setprio(0);
+        retire(ae);
+        retire(be);
+        TN_PIN();
+      } else {
+#pragma unroll
+        for (int m = 0; m < 16; ++m)
+          acc[4 + (m >> 2)][m & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bo.v[m & 3], ao.v[m >> 2], acc[4 + (m >> 2)][m & 3], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+      }
+      pb = sa;
+      pa = sb;
+      sa = sa1;
+      sb = sb1;
+    };
+
+    const int np = p.stages;
+    for (int kc = 0; kc < mine; ++kc) {
+      // quarter 0's fragments of the tile's first stage
+      read_frag(I0{}, I0{}, sa, sb, ae, be);
+      read_frag(I0{}, I1{}, sa, sb, ae, be);
+      read_frag(I0{}, I2{}, sa, sb, ae, be);
+      read_frag(I0{}, I3{}, sa, sb, ae, be);
+      read_frag(I0{}, std::integral_constant<int, 4>{}, sa, sb, ae, be);
+      read_frag(I0{}, std::integral_constant<int, 5>{}, sa, sb, ae, be);
+      read_frag(I0{}, std::integral_constant<int, 6>{}, sa, sb, ae, be);
+      read_frag(I0{}, std::integral_constant<int, 7>{}, sa, sb, ae, be);
+      retire(ae);
+      retire(be);
+      TN_PIN();
+      for (int t = 1; t < np; ++t) trip(F_{});
+      trip(T_{});
+      int m0, n0;
+      origin(kc, m0, n0);
+      char* park = smem + (wave < 4 ? pb : pa) * SLOT + (wave & 3) * 8192;
+      if constexpr (EPI == EPI_SWIGLU_FWD) {
+        epilogue16_swiglu_fwd(p, acc, park, m0 + wr * 128, n0 + wc * 32, lane);
+      } else if constexpr (EPI == EPI_SWIGLU_BWD) {
+        epilogue16_swiglu_bwd(p, acc, park, m0 + wr * 128, n0 + wc * 64, lane);
+      } else if constexpr (EPI == EPI_ROPE) {
+        const bool d128 = p.rope_d == 128;
+        epilogue16_rope(p, acc, park, m0 + wr * 128, d128 ? n0 + (wc >> 1) * 128 + (wc & 1) * 32 : n0 + wc * 64,
+                        d128 ? (wc & 1) * 32 : 0, lane);
+      } else {
+        epilogue16(p, acc, park, m0 + wr * 128, n0 + wc * 64, lane);
+      }
+      zero_acc();
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" : "+v"(lane));
+      ra = Reader<AK, 8>(lane, wr * 128);
+      rb = Reader<BK, 4>(lane, wc * 64);
+      sA.set_voff(wave, lane);
+      sB.set_voff(b_wave0 ? 0 : wave, lane);
+      early_pieces(pb, pa);
+    }
+  }
+
+  // ---- park helpers: a 64-row half of the wave tile (A blocks 4 half .. 4 half + 3) <-> the [64 rows][64 columns] bf16 park.
+  // Element (row = 16 bi + l15, columns 16 bj + 4 g4 .. + 3) = one 8-byte pack at chunk (2 bj + (g4 >> 1)) ^ (row & 7).
+  static __device__ __forceinline__ char* park_at(char* park, int bi, int bj, int l15, int g4) {
+    const int row = bi * 16 + l15;
+    return park + row * 128 + (((bj * 2 + (g4 >> 1)) ^ (row & 7)) << 4) + (g4 & 1) * 8;
+  }
+
+  // SwiGLU forward (see Kernel::epilogue_swiglu_fwd): blocks bj = 0, 1 of a lane are gate, bj = 2, 3 up of the SAME columns
+  // wn0 + 16 bj + 4 g4 ..; three park trips: gate | up of 64 rows each, then act of all 128 rows.
+  static __device__ __forceinline__ void epilogue16_swiglu_fwd(const Params& p, Acc16& acc, char* park, int wm0, int wn0,
+                                                               int lane) {
+    const int l15 = lane & 15, g4 = lane >> 4;
+    const uintptr_t c_gate = (uintptr_t)p.C, c_up = (uintptr_t)p.C2;
+    bf16_t* const gu_base = reinterpret_cast<bf16_t*>(c_gate + ((lane & 4) ? c_up - c_gate : (uintptr_t)0));
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+      for (int bi = 0; bi < 4; ++bi)
+#pragma unroll
+        for (int bj = 0; bj < 4; ++bj) {
+          const f32x4_t a = acc[half * 4 + bi][bj];
+          *reinterpret_cast<u32x2_t*>(park_at(park, bi, bj, l15, g4)) = u32x2_t{pack2bf(a[0], a[1]), pack2bf(a[2], a[3])};
+        }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll 4
+      for (int it = 0; it < 8; ++it) {
+        const int row = it * 8 + (lane >> 3), c = lane & 7;
+        const u32x4_t pv = *reinterpret_cast<const u32x4_t*>(park + row * 128 + ((c ^ (row & 7)) << 4));
+        const int m = wm0 + half * 64 + row, n = wn0 + (c & 3) * 8;
+        if (m < p.M && n < p.N)
+          *reinterpret_cast<uint4*>(gu_base + (long long)m * p.ldc + n) = make_uint4(pv.x, pv.y, pv.z, pv.w);
+      }
+    }
+#pragma unroll
+    for (int bi = 0; bi < 8; ++bi)
+#pragma unroll
+      for (int bj = 0; bj < 2; ++bj) {
+        float h[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float gf = rbf(acc[bi][bj][e]), uf = rbf(acc[bi][bj + 2][e]);
+          h[e] = rbf(gf * sigm(gf)) * uf;
+        }
+        // columns 0-31 of the park = rows 0-63, columns 32-63 = rows 64-127
+        *reinterpret_cast<u32x2_t*>(park_at(park, bi & 3, (bi >> 2) * 2 + bj, l15, g4)) =
+            u32x2_t{pack2bf(h[0], h[1]), pack2bf(h[2], h[3])};
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll 4
+    for (int it = 0; it < 8; ++it) {
+      const int row = it * 8 + (lane >> 3), c = lane & 7;
+      const u32x4_t pv = *reinterpret_cast<const u32x4_t*>(park + row * 128 + ((c ^ (row & 7)) << 4));
+      const int m = wm0 + (c >> 2) * 64 + row, n = wn0 + (c & 3) * 8;
+      if (m < p.M && n < p.N)
+        *reinterpret_cast<uint4*>(p.C3 + (long long)m * p.ldc + n) = make_uint4(pv.x, pv.y, pv.z, pv.w);
+    }
+  }
+
+  // SwiGLU backward (see Kernel::epilogue_swiglu_bwd): gate / up rows in through the park, d(gate) / d(up) out through it
+  static __device__ __forceinline__ void epilogue16_swiglu_bwd(const Params& p, Acc16& acc, char* park, int wm0, int wn0,
+                                                               int lane) {
+    const int l15 = lane & 15, g4 = lane >> 4;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      uint4 gv[8], uv[8];
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int row = it * 8 + (lane >> 3), c = lane & 7;
+        const int m = wm0 + half * 64 + row, n = wn0 + c * 8;
+        const bool in = m < p.M && n < p.N;
+        const long long off = (long long)m * p.lde + n;
+        gv[it] = in ? *reinterpret_cast<const uint4*>(p.E1 + off) : make_uint4(0, 0, 0, 0);
+        uv[it] = in ? *reinterpret_cast<const uint4*>(p.E2 + off) : make_uint4(0, 0, 0, 0);
+      }
+      u32x2_t gq[4][4], uq[4][4];
+      auto through_park = [&](const uint4 (&src)[8], u32x2_t (&dst)[4][4]) {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          const int row = it * 8 + (lane >> 3), c = lane & 7;
+          const u32x4_t v = {src[it].x, src[it].y, src[it].z, src[it].w};
+          *reinterpret_cast<u32x4_t*>(park + row * 128 + ((c ^ (row & 7)) << 4)) = v;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int bi = 0; bi < 4; ++bi)
+#pragma unroll
+          for (int bj = 0; bj < 4; ++bj) dst[bi][bj] = *reinterpret_cast<const u32x2_t*>(park_at(park, bi, bj, l15, g4));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      };
+      through_park(gv, gq);
+      through_park(uv, uq);
+#pragma unroll
+      for (int bi = 0; bi < 4; ++bi)
+#pragma unroll
+        for (int bj = 0; bj < 4; ++bj) {
+          float dg[4], du[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const uint32_t wg = e < 2 ? gq[bi][bj].x : gq[bi][bj].y, wu = e < 2 ? uq[bi][bj].x : uq[bi][bj].y;
+            const float gf = (e & 1) ? hi16(wg) : lo16(wg), uf = (e & 1) ? hi16(wu) : lo16(wu);
+            const float d = rbf(acc[half * 4 + bi][bj][e]);
+            const float sg = sigm(gf);
+            const float silu = gf * sg;
+            du[e] = d * silu;
+            dg[e] = d * uf * (sg + silu * (1.f - sg));
+          }
+          gq[bi][bj] = u32x2_t{pack2bf(dg[0], dg[1]), pack2bf(dg[2], dg[3])};
+          uq[bi][bj] = u32x2_t{pack2bf(du[0], du[1]), pack2bf(du[2], du[3])};
+        }
+      auto out_park = [&](const u32x2_t (&src)[4][4], bf16_t* C) {
+#pragma unroll
+        for (int bi = 0; bi < 4; ++bi)
+#pragma unroll
+          for (int bj = 0; bj < 4; ++bj) *reinterpret_cast<u32x2_t*>(park_at(park, bi, bj, l15, g4)) = src[bi][bj];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll 4
+        for (int it = 0; it < 8; ++it) {
+          const int row = it * 8 + (lane >> 3), c = lane & 7;
+          const u32x4_t pv = *reinterpret_cast<const u32x4_t*>(park + row * 128 + ((c ^ (row & 7)) << 4));
+          const int m = wm0 + half * 64 + row, n = wn0 + c * 8;
+          if (m < p.M && n < p.N)
+            *reinterpret_cast<uint4*>(C + (long long)m * p.ldc + n) = make_uint4(pv.x, pv.y, pv.z, pv.w);
+        }
+      };
+      out_park(gq, p.C);
+      out_park(uq, p.C2);
+    }
+  }
+
+  // RoPE (see Kernel::epilogue_rope): blocks bj = 0, 1 hold columns col_a + 16 bj + 4 g4 .., blocks bj = 2, 3 the partners
+  // half a head further (col_a + D / 2 + ..); c0 = index of col_a's pair inside the head
+  static __device__ __forceinline__ void epilogue16_rope(const Params& p, Acc16& acc, char* park, int wm0, int col_a, int c0,
+                                                         int lane) {
+    const int l15 = lane & 15, g4 = lane >> 4;
+    const int hd = p.rope_d >> 1;
+    const int col_b = col_a + hd;
+    uint2 bwa[2], bwb[2];
+#pragma unroll
+    for (int bj = 0; bj < 2; ++bj) {
+      const int q = 16 * bj + 4 * g4;
+      bwa[bj] = bwb[bj] = make_uint2(0, 0);
+      if (p.bias != nullptr) {
+        bwa[bj] = *reinterpret_cast<const uint2*>(p.bias + min(col_a + q, p.N - 4));
+        bwb[bj] = *reinterpret_cast<const uint2*>(p.bias + min(col_b + q, p.N - 4));
+      }
+    }
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      uint2 cw[4][2], sw[4][2];
+#pragma unroll
+      for (int bi = 0; bi < 4; ++bi) {
+        const int m = min(wm0 + (half * 4 + bi) * 16 + l15, p.M - 1);
+#pragma unroll
+        for (int bj = 0; bj < 2; ++bj) {
+          const long long o = (long long)m * hd + c0 + 16 * bj + 4 * g4;
+          cw[bi][bj] = *reinterpret_cast<const uint2*>(p.rope_cos + o);
+          sw[bi][bj] = *reinterpret_cast<const uint2*>(p.rope_sin + o);
+        }
+      }
+#pragma unroll
+      for (int bi = 0; bi < 4; ++bi)
+#pragma unroll
+        for (int bj = 0; bj < 2; ++bj) {
+          const float ba[4] = {lo16(bwa[bj].x), hi16(bwa[bj].x), lo16(bwa[bj].y), hi16(bwa[bj].y)};
+          const float bb[4] = {lo16(bwb[bj].x), hi16(bwb[bj].x), lo16(bwb[bj].y), hi16(bwb[bj].y)};
+          const float cf[4] = {lo16(cw[bi][bj].x), hi16(cw[bi][bj].x), lo16(cw[bi][bj].y), hi16(cw[bi][bj].y)};
+          const float sf[4] = {lo16(sw[bi][bj].x), hi16(sw[bi][bj].x), lo16(sw[bi][bj].y), hi16(sw[bi][bj].y)};
+          float ya[4], yb[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            rope_rotate(rbf(acc[half * 4 + bi][bj][e] + ba[e]), rbf(acc[half * 4 + bi][bj + 2][e] + bb[e]), cf[e], sf[e],
+                        ya[e], yb[e]);
+          *reinterpret_cast<u32x2_t*>(park_at(park, bi, bj, l15, g4)) = u32x2_t{pack2bf(ya[0], ya[1]), pack2bf(ya[2], ya[3])};
+          *reinterpret_cast<u32x2_t*>(park_at(park, bi, bj + 2, l15, g4)) = u32x2_t{pack2bf(yb[0], yb[1]), pack2bf(yb[2], yb[3])};
+        }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll 4
+      for (int it = 0; it < 8; ++it) {
+        const int row = it * 8 + (lane >> 3), c = lane & 7;
+        const u32x4_t pv = *reinterpret_cast<const u32x4_t*>(park + row * 128 + ((c ^ (row & 7)) << 4));
+        const int m = wm0 + half * 64 + row, n = (c < 4 ? col_a : col_b) + (c & 3) * 8;
+        if (m < p.M && n < p.N)
+          *reinterpret_cast<uint4*>(p.C + (long long)m * p.ldc + n) = make_uint4(pv.x, pv.y, pv.z, pv.w);
+      }
+    }
+  }
+
+  // Epilogue through LDS, as Kernel::epilogue: the wave parks its 128 x 64 tile 64 rows at a time in its XOR-swizzled 8 KB
+  // ([64 rows m][64 columns n] bf16, 16-byte chunk ^= row & 7) and writes full 128-byte lines.  A lane holds, per 16 x 16
+  // block, column m = l & 15 and the 4 consecutive n = 4 (l >> 4) ..: 8-byte packs.
+  static __device__ __forceinline__ void epilogue16(const Params& p, Acc16& acc, char* park, int wm0, int wn0, int lane) {
+    const int l15 = lane & 15, g4 = lane >> 4;
+    float bias_v[4][4];
+    if (p.bias != nullptr) {
+#pragma unroll
+      for (int bj = 0; bj < 4; ++bj) {
+        const int n = min(wn0 + bj * 16 + 4 * g4, p.N - 4);
+        const uint2 w = *reinterpret_cast<const uint2*>(p.bias + n);
+        bias_v[bj][0] = __uint_as_float(w.x << 16);
+        bias_v[bj][1] = __uint_as_float(w.x & 0xffff0000u);
+        bias_v[bj][2] = __uint_as_float(w.y << 16);
+        bias_v[bj][3] = __uint_as_float(w.y & 0xffff0000u);
+      }
+    }
+    const bool acc_c = p.accumulate != 0;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+      for (int bi = 0; bi < 4; ++bi) {
+        const int row = bi * 16 + l15;
+#pragma unroll
+        for (int bj = 0; bj < 4; ++bj) {
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = acc[half * 4 + bi][bj][e] + (p.bias != nullptr ? bias_v[bj][e] : 0.f);
+          const int chunk = (bj * 2 + (g4 >> 1)) ^ (row & 7);
+          const u32x2_t pk = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+          *reinterpret_cast<u32x2_t*>(park + row * 128 + chunk * 16 + (g4 & 1) * 8) = pk;
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll 4
+      for (int it = 0; it < 8; ++it) {
+        const int row = it * 8 + (lane >> 3), c = lane & 7;
+        const u32x4_t pv = *reinterpret_cast<const u32x4_t*>(park + row * 128 + ((c ^ (row & 7)) << 4));
+        uint4 v = make_uint4(pv.x, pv.y, pv.z, pv.w);
+        const int m = wm0 + half * 64 + row, n = wn0 + c * 8;
+        if (m < p.M && n < p.N) {
+          bf16_t* dst = p.C + (long long)m * p.ldc + n;
+          if (acc_c) {
+            Vec16<bf16_t> o, nw;
+            o.load(dst);
+            nw.raw = v;
+            float fo[8], fn[8];
+            o.unpack(fo);
+            nw.unpack(fn);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) fn[e] += fo[e];
+            nw.pack(fn);
+            v = nw.raw;
+          }
+          *reinterpret_cast<uint4*>(dst) = v;
+        }
+      }
+    }
+  }
+};
+
+template <bool AK, bool BK, int PLACE, int EPI = EPI_PLAIN>
+__global__ __launch_bounds__(NT, 2) void gemm16_kernel(const Params p) {
+  __shared__ __attribute__((aligned(1024))) char smem[LDS_BYTES];
+  Kernel16<AK, BK, PLACE, EPI>::run(p, smem);
+}
+
 // ws[S][ntiles][256 x 256] fp32 partial sums -> C = bf16(sum_s ws[s] (+ bias) (+ C)) on the tiles [tile0, tile0 + ntiles);
 // 32 blocks of 256 threads per tile, one thread per 8 consecutive columns
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int S, int M, int N, int nbm,
@@ -1263,6 +1876,14 @@ static int launch_variant(int variant, dim3 grid, hipStream_t st, Params p) {
         return -1;
       }
     } else {
+      // row-stored A (forward / input-gradient products): the 16x16x32 kernel (TN_GEMM_M16=0: the 32x32x16 one)
+      static const bool m16 = [] { const char* e = getenv("TN_GEMM_M16"); return !(e && e[0] == '0'); }();
+      if constexpr (!HAS_CT && !AK) {
+        if (m16) {
+          hipLaunchKernelGGL((gemm16_kernel<AK, BK, DPL>), grid, dim3(NT), 0, st, p);
+          return 0;
+        }
+      }
       hipLaunchKernelGGL((gemm_kernel<AK, BK, DPL, DAS, DIL, HAS_CT>), grid, dim3(NT), 0, st, p);
     }
   }
@@ -1447,6 +2068,14 @@ int tn_gemm_bf16_wgrad_f32(const void* A, const void* B, long long lda, long lon
 
 namespace {
 
+// 16x16x32 MFMAs (Kernel16) for the products whose A operand is row-stored — forward and input-gradient products — where
+// they are 5-7 % / 2-3 % faster; the weight-gradient mode (both operands through transpose reads) gains nothing and stays on
+// Kernel.  TN_GEMM_M16=0: every product on the 32x32x16 kernel (A/B runs).
+bool use_m16() {
+  static const bool on = [] { const char* e = getenv("TN_GEMM_M16"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
 constexpr int kDPL = (TN_GEMM_DEFAULT_VARIANT % 1000) / 100, kDAS = (TN_GEMM_DEFAULT_VARIANT / 10) % 10,
               kDIL = TN_GEMM_DEFAULT_VARIANT % 10;
 
@@ -1624,8 +2253,11 @@ int tn_gemm_bf16_swiglu_fwd(const void* x, const void* wg, const void* wu, void*
   p.ntiles = p.nbm * p.nbn;
   const int ncu = num_cus();
   const dim3 grid(persistent_now() && p.ntiles > ncu ? ncu : p.ntiles);
-  hipLaunchKernelGGL((gemm_kernel<false, false, kDPL, kDAS, kDIL, false, false, false, EPI_SWIGLU_FWD>), grid, dim3(NT), 0,
-                     (hipStream_t)stream, p);
+  if (use_m16())
+    hipLaunchKernelGGL((gemm16_kernel<false, false, kDPL, EPI_SWIGLU_FWD>), grid, dim3(NT), 0, (hipStream_t)stream, p);
+  else
+    hipLaunchKernelGGL((gemm_kernel<false, false, kDPL, kDAS, kDIL, false, false, false, EPI_SWIGLU_FWD>), grid, dim3(NT), 0,
+                       (hipStream_t)stream, p);
   TN_LAUNCH_CHECK();
   return TN_OK;
 }
@@ -1663,8 +2295,11 @@ int tn_gemm_bf16_swiglu_bwd(const void* dy, const void* wd, const void* gate, co
   p.ntiles = p.nbm * p.nbn;
   const int ncu = num_cus();
   const dim3 grid(persistent_now() && p.ntiles > ncu ? ncu : p.ntiles);
-  hipLaunchKernelGGL((gemm_kernel<false, true, kDPL, kDAS, kDIL, false, false, false, EPI_SWIGLU_BWD>), grid, dim3(NT), 0,
-                     (hipStream_t)stream, p);
+  if (use_m16())
+    hipLaunchKernelGGL((gemm16_kernel<false, true, kDPL, EPI_SWIGLU_BWD>), grid, dim3(NT), 0, (hipStream_t)stream, p);
+  else
+    hipLaunchKernelGGL((gemm_kernel<false, true, kDPL, kDAS, kDIL, false, false, false, EPI_SWIGLU_BWD>), grid, dim3(NT), 0,
+                       (hipStream_t)stream, p);
   TN_LAUNCH_CHECK();
   return TN_OK;
 }
@@ -1716,8 +2351,11 @@ int tn_gemm_bf16_rope(const void* x, const void* w, const void* bias, const void
   p.ntiles = p.nbm * p.nbn;
   const int ncu = num_cus();
   const dim3 grid(persistent_now() && p.ntiles > ncu ? ncu : p.ntiles);
-  hipLaunchKernelGGL((gemm_kernel<false, false, kDPL, kDAS, kDIL, false, false, false, EPI_ROPE>), grid, dim3(NT), 0,
-                     (hipStream_t)stream, p);
+  if (use_m16())
+    hipLaunchKernelGGL((gemm16_kernel<false, false, kDPL, EPI_ROPE>), grid, dim3(NT), 0, (hipStream_t)stream, p);
+  else
+    hipLaunchKernelGGL((gemm_kernel<false, false, kDPL, kDAS, kDIL, false, false, false, EPI_ROPE>), grid, dim3(NT), 0,
+                       (hipStream_t)stream, p);
   TN_LAUNCH_CHECK();
   return TN_OK;
 }
