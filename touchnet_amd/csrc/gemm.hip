@@ -1154,6 +1154,9 @@ struct Kernel16 {
   struct F4 {
     bf16x8_t v[4];
     u32x2_t h[KMAJ ? 4 : 1][2];
+#ifdef TN_G16_ASMROW
+    u32x4_t r[4];
+#endif
   };
   // per-lane LDS offsets.  ROW: x[half]; block b of the wave's rows at + b * 2048.  KMAJ: x[G] for the 64-byte group G of
   // the wave's 32-row pairs, x ^ 32 for the odd 16-row block of the pair; k-row offsets are compile-time.
@@ -1177,7 +1180,12 @@ struct Kernel16 {
     template <int H, int BLK, int I>
     __device__ __forceinline__ void read(const char* smem, int sbase, F4<KMAJ>& f) const {
       if constexpr (!KMAJ) {
+#ifdef TN_G16_ASMROW   // diagnostic: row fragments as asm reads retired by ONE lgkmcnt(0) per set, like the transpose reads
+        const uint32_t a = (uint32_t)(size_t)(lds_ptr_t)smem + (uint32_t)(sbase + x[H]);
+        f.r[I] = ds_b128<BLK * 2048>(a);
+#else
         f.v[I] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(smem + sbase + x[H] + BLK * 2048));
+#endif
       } else {
         const uint32_t a = (uint32_t)(size_t)(lds_ptr_t)smem + (uint32_t)(sbase + (x[BLK >> 1] ^ ((BLK & 1) * 32)));
         f.h[I][0] = ds_tr16<(32 * H) * 512>(a);
@@ -1187,6 +1195,13 @@ struct Kernel16 {
   };
   template <bool KMAJ>
   static __device__ __forceinline__ void retire(F4<KMAJ>& f) {
+#ifdef TN_G16_ASMROW
+    if constexpr (!KMAJ) {
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.r[0]), "+v"(f.r[1]), "+v"(f.r[2]), "+v"(f.r[3]));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) f.v[i] = __builtin_bit_cast(bf16x8_t, f.r[i]);
+    }
+#endif
     if constexpr (KMAJ) {
       asm volatile("s_waitcnt lgkmcnt(0)"
                    : "+v"(f.h[0][0]), "+v"(f.h[0][1]), "+v"(f.h[1][0]), "+v"(f.h[1][1]), "+v"(f.h[2][0]), "+v"(f.h[2][1]),
@@ -1291,6 +1306,8 @@ struct Kernel16 {
       if constexpr (R < 4) ra.template read<(Q >> 1), (Q & 1) * 4 + R, R>(smem, sa * SLOT, a);
       else rb.template read<(Q >> 1), R - 4, R - 4>(smem, sb * SLOT, b);
     };
+    // (Measured and dropped, round 5: B fragments read first and retired by a counted `lgkmcnt(4)` while the four younger A
+    //  reads stay in flight — 0.7 % SLOWER than A first + lgkmcnt(0), profiles/r05s_*.)
     // One quarter: 16 MFMAs of A part PART (fragments ca) against the half's B fragments cb; fragment r of the NEXT quarter
     // NQ (4 A fragments, and with RB its half's 4 B fragments) is read behind MFMA 2 r; DMA pieces of positions
     // P0 .. P0 + 7 go behind MFMAs 0, 2, .. 14 (P0 < 0: none).
