@@ -472,7 +472,7 @@ def build_flat_engine_optimizer(model: nn.Module, make_optimizer):
         # group (one tiny all-reduce at start-up) and refuse loudly.
         group = mark["mesh"].get_group()
         if engine.world > 1 and not engine.emulated:
-            sums = torch.stack([src.double().sum() for src in keep.values()]).sum().reshape(1)
+            sums = torch.stack([src.sum(dtype=torch.float64) for src in keep.values()]).sum().reshape(1)
             hi_, lo_ = sums.clone(), sums.clone()
             dist.all_reduce(hi_, op=dist.ReduceOp.MAX, group=group)
             dist.all_reduce(lo_, op=dist.ReduceOp.MIN, group=group)
