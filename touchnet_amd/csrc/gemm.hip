@@ -176,6 +176,9 @@ template <> struct Place<3> { static constexpr int B[4] = {0, 2, 4, 6}, A[4] = {
 template <> struct Place<4> { static constexpr int B[4] = {0, 2, 4, 6}, A[4] = {8, 10, 12, 14}; };
 template <> struct Place<5> { static constexpr int B[4] = {0, 1, 2, 3}, A[4] = {9, 13, 17, 21}; };
 template <> struct Place<6> { static constexpr int B[4] = {0, 2, 4, 6}, A[4] = {14, 18, 22, 26}; };
+template <> struct Place<7> { static constexpr int B[4] = {0, 2, 4, 6}, A[4] = {18, 22, 26, 30}; };   // (round 5, Kernel16 sweep)
+template <> struct Place<8> { static constexpr int B[4] = {1, 3, 5, 7}, A[4] = {14, 18, 22, 26}; };
+template <> struct Place<9> { static constexpr int B[4] = {0, 2, 4, 6}, A[4] = {16, 20, 24, 28}; };
 
 // piece index issued at position `pos` for the given table, or -1
 template <int PLACE, bool IS_A> constexpr int piece_at(int pos) {
@@ -1897,6 +1900,21 @@ static int launch_variant(int variant, dim3 grid, hipStream_t st, Params p) {
       static const bool m16 = [] { const char* e = getenv("TN_GEMM_M16"); return !(e && e[0] == '0'); }();
       if constexpr (!HAS_CT && !AK) {
         if (m16) {
+#ifdef TN_G16_SWEEP   // kernel development: DMA placement table of Kernel16 from the environment (scripts/r05_g16_sweep.sh)
+          const char* e16 = getenv("TN_G16_PLACE");
+          switch (e16 ? atoi(e16) : DPL) {
+            case 1: hipLaunchKernelGGL((gemm16_kernel<AK, BK, 1>), grid, dim3(NT), 0, st, p); return 0;
+            case 2: hipLaunchKernelGGL((gemm16_kernel<AK, BK, 2>), grid, dim3(NT), 0, st, p); return 0;
+            case 3: hipLaunchKernelGGL((gemm16_kernel<AK, BK, 3>), grid, dim3(NT), 0, st, p); return 0;
+            case 4: hipLaunchKernelGGL((gemm16_kernel<AK, BK, 4>), grid, dim3(NT), 0, st, p); return 0;
+            case 5: hipLaunchKernelGGL((gemm16_kernel<AK, BK, 5>), grid, dim3(NT), 0, st, p); return 0;
+            case 0: hipLaunchKernelGGL((gemm16_kernel<AK, BK, 0>), grid, dim3(NT), 0, st, p); return 0;
+            case 7: hipLaunchKernelGGL((gemm16_kernel<AK, BK, 7>), grid, dim3(NT), 0, st, p); return 0;
+            case 8: hipLaunchKernelGGL((gemm16_kernel<AK, BK, 8>), grid, dim3(NT), 0, st, p); return 0;
+            case 9: hipLaunchKernelGGL((gemm16_kernel<AK, BK, 9>), grid, dim3(NT), 0, st, p); return 0;
+            default: break;
+          }
+#endif
           hipLaunchKernelGGL((gemm16_kernel<AK, BK, DPL>), grid, dim3(NT), 0, st, p);
           return 0;
         }
