@@ -179,6 +179,10 @@ template <> struct Place<6> { static constexpr int B[4] = {0, 2, 4, 6}, A[4] = {
 template <> struct Place<7> { static constexpr int B[4] = {0, 2, 4, 6}, A[4] = {18, 22, 26, 30}; };   // (round 5, Kernel16 sweep)
 template <> struct Place<8> { static constexpr int B[4] = {1, 3, 5, 7}, A[4] = {14, 18, 22, 26}; };
 template <> struct Place<9> { static constexpr int B[4] = {0, 2, 4, 6}, A[4] = {16, 20, 24, 28}; };
+// (Kernel16: a position = two MFMAs; a quarter's fragment reads sit behind its MFMAs 0..7 = its positions 0..3 — tables 10, 11
+//  put every piece into the read-free second half of a quarter)
+template <> struct Place<10> { static constexpr int B[4] = {4, 5, 6, 7}, A[4] = {12, 14, 20, 22}; };
+template <> struct Place<11> { static constexpr int B[4] = {4, 5, 6, 7}, A[4] = {13, 15, 21, 23}; };
 
 // piece index issued at position `pos` for the given table, or -1
 template <int PLACE, bool IS_A> constexpr int piece_at(int pos) {
@@ -1912,6 +1916,8 @@ static int launch_variant(int variant, dim3 grid, hipStream_t st, Params p) {
             case 7: hipLaunchKernelGGL((gemm16_kernel<AK, BK, 7>), grid, dim3(NT), 0, st, p); return 0;
             case 8: hipLaunchKernelGGL((gemm16_kernel<AK, BK, 8>), grid, dim3(NT), 0, st, p); return 0;
             case 9: hipLaunchKernelGGL((gemm16_kernel<AK, BK, 9>), grid, dim3(NT), 0, st, p); return 0;
+            case 10: hipLaunchKernelGGL((gemm16_kernel<AK, BK, 10>), grid, dim3(NT), 0, st, p); return 0;
+            case 11: hipLaunchKernelGGL((gemm16_kernel<AK, BK, 11>), grid, dim3(NT), 0, st, p); return 0;
             default: break;
           }
 #endif
