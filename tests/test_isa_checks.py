@@ -133,3 +133,47 @@ def test_fused_dkdv_accumulators_and_stage_ring(tmp_path):
     assert not any(x.startswith(("v_readlane", "v_writelane")) for x in seg)
     assert sum(x.startswith("v_accvgpr") for x in seg) == 0
     assert sum(x.startswith("v_pk_") for x in seg) == 0, "packed f32 VALU beside the MFMAs (see the kernel's ds_elem)"
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not on PATH")
+def test_product_gemm_kernels_keep_their_stage_loops_clean(tmp_path):
+    """Every instantiation of the product GEMM (csrc/gemm.hip: `gemm_kernel` with its epilogue modes — plain, grouped, SwiGLU
+    forward / backward, bias gradient, RoPE — and `gemm16_kernel`, the 16x16x32 variant) compiled for gfx950: no scratch, no
+    VGPR spill (a fused epilogue must not push the main loop out of the register file); each kernel issues ONE MFMA shape;
+    and its stage loops hold no `s_waitcnt vmcnt` but the hand-counted `vmcnt(4)` of the five-slot LDS-DMA ring (a
+    compiler-inserted one in front of an LDS access would drain the ring every stage)."""
+    import re
+    out = tmp_path / "gemm.s"
+    r = subprocess.run(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-result", "-S", "--cuda-device-only",
+                        os.path.join(ROOT, "touchnet_amd", "csrc", "gemm.hip"), "-o", str(out)],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr
+    text = out.read_text()
+    kernels = re.findall(r"^(_ZN2tn4gemm(?:11gemm_kernel|13gemm16_kernel)\S*):(.*?)s_endpgm", text, re.S | re.M)
+    names = [n for n, _ in kernels]
+    assert sum("gemm16_kernel" in n for n in names) == 5 and sum("11gemm_kernel" in n for n in names) >= 14, names
+    meta = text[text.find("amdhsa.kernels"):]
+    for ent in meta.split("- .agpr_count")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", ent).group(1)
+        if "gemm" not in name or "splitk_reduce" in name:
+            continue
+        assert int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", ent).group(1)) == 0, name
+        assert int(re.search(r"\.vgpr_spill_count:\s+(\d+)", ent).group(1)) == 0, name
+        assert int(re.search(r"\.vgpr_count:\s+(\d+)", ent).group(1)) <= 256, name
+    for name, body in kernels:
+        ins = [l.strip() for l in body.split("\n") if l.strip() and not l.strip().startswith(";")]
+        m16 = "gemm16_kernel" in name
+        shapes = {l.split()[0] for l in ins if l.startswith("v_mfma")}
+        assert shapes == ({"v_mfma_f32_16x16x32_bf16"} if m16 else {"v_mfma_f32_32x32x16_bf16"}), (name, shapes)
+        per_trip = 64 if m16 else 32
+        labels = {m.group(1): i for i, l in enumerate(ins) for m in [re.match(r"(\.LBB\d+_\d+):", l)] if m}
+        found = 0
+        for i, l in enumerate(ins):
+            m = re.match(r"s_c?branch\S*\s+(\.LBB\d+_\d+)", l)
+            if m and labels.get(m.group(1), len(ins)) < i:
+                seg = ins[labels[m.group(1)]:i + 1]
+                if sum(x.startswith("v_mfma") for x in seg) == per_trip:          # the steady-state stage loop
+                    found += 1
+                    vm = [x for x in seg if x.startswith("s_waitcnt") and "vmcnt" in x]
+                    assert vm == ["s_waitcnt vmcnt(4)"], (name, vm)
+        assert found == 1, (name, found)
