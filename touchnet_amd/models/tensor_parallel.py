@@ -299,7 +299,8 @@ def _checkpoint_view(model: nn.Module, tp_mesh) -> None:
     """`state_dict()` hands the tensor-parallel shards out as DTensors on the tp mesh (Shard(1) for the row-parallel
     o_proj / down_proj weights, Shard(0) for everything else that is sharded), sharing storage with the parameters — what
     the reference's DTensor-based plan gives torch.distributed.checkpoint: an unsharded checkpoint loads into the shards,
-    a sharded one reloads anywhere (the reference's tests/touchnet/models/test_llama.py).  Only for a real DeviceMesh and
+    a sharded one reloads anywhere (the reference's tests/touchnet/models/test_llama.py).  `load_state_dict()` accepts the
+    same view back (and full tensors): a pre-hook turns them into the local shards.  Only for a real DeviceMesh and
     plain (not FSDP2-wrapped) parameters: under tp x FSDP2 the dim-0 shards would need a strided 2-D placement."""
     try:
         from torch.distributed.device_mesh import DeviceMesh
@@ -360,6 +361,36 @@ def _checkpoint_view(model: nn.Module, tp_mesh) -> None:
                                                  shape=torch.Size(shape), stride=tuple(stride))
         return state_dict
     model._register_state_dict_hook(hook)
+
+    def load_hook(module, state_dict, prefix, *unused):
+        """The load side of the view (`model.load_state_dict(...)`; DCP loads in place and never gets here): an incoming
+        DTensor — this model's own `state_dict()`, or another layout of the same global tensor — or a plain tensor of the
+        GLOBAL shape becomes the local shard the plain parameter holds; local-shaped plain tensors pass through.  FSDP2-
+        wrapped parameters (DTensors themselves) are left to FSDP2's own loading."""
+        names = module._tn_tp["sharded_names"]
+        rank = module._tn_tp["rank"]
+        plain = lambda n: n.replace("_checkpoint_wrapped_module.", "")
+        params = {plain(n): p for n, p in module.named_parameters(remove_duplicate=False)}
+        shared = {id(params[n]) for n in names if n in params}
+        for key in list(state_dict.keys()):
+            n = plain(key[len(prefix):])
+            p = params.get(n)
+            t = state_dict[key]
+            if p is None or id(p) not in shared or isinstance(p, DTensor) or not isinstance(t, torch.Tensor) or t.is_meta:
+                continue
+            dim = 1 if _row_parallel(n) else 0
+            if isinstance(t, DTensor):
+                same = t.device_mesh.ndim == 1 and t.device_mesh.size() == tp and tuple(t.device_mesh.mesh.flatten().tolist()) \
+                    == tuple(tp_mesh.mesh.flatten().tolist())
+                t = t.redistribute(placements=[Shard(dim)]).to_local() if same else t.full_tensor()
+            if tuple(t.shape) != tuple(p.shape):
+                want = list(p.shape)
+                want[dim] *= tp
+                if list(t.shape) != want:
+                    continue                                  # (not ours to fix: load_state_dict reports the mismatch)
+                t = t.narrow(dim, rank * p.shape[dim], p.shape[dim])
+            state_dict[key] = t
+    model._register_load_state_dict_pre_hook(load_hook, with_module=True)
 
 
 @torch.no_grad()
