@@ -70,3 +70,45 @@ def test_gemm_tuning_replay_env(monkeypatch, tmp_path):
     monkeypatch.setenv("TN_TUNE_DIR", str(tmp_path / "tune"))
     assert gemm_tuning.enable() is True and os.environ["PYTORCH_TUNABLEOP_TUNING"] == "1"
     assert os.environ["PYTORCH_TUNABLEOP_FILENAME"].startswith(str(tmp_path / "tune"))
+
+
+def test_round5_gemm_entry_points_refuse_malformed_arguments_before_any_launch():
+    """The fused-epilogue / grouped GEMM entry points (include/touchnet_amd.h) check shapes, strides and alignment on the host
+    and return TN_EINVAL (-22) without touching the device — so the checks can be exercised on a box with no GPU.  (Valid calls
+    are the `-m gpu` tests' business: tests/test_gemm_fused_gpu.py.)"""
+    import ctypes as C
+    from touchnet_amd import _C
+    lib = _C.lib()
+    EINVAL = -22
+    raw = (C.c_char * 8192)()
+    p = (C.addressof(raw) + 255) // 256 * 256            # a 256-byte-aligned host address: never dereferenced by a refused call
+    odd = p + 2                                          # not 16-byte aligned
+    H, I, M = 4096, 11008, 256
+    # SwiGLU forward: K not a multiple of 64, an output stride shorter than a row, a misaligned operand
+    ok = dict(M=M, I=I, K=H, ldx=H, ldw=H, ldc=I)
+    def swiglu_fwd(x=p, **kw):
+        a = {**ok, **kw}
+        return lib.tn_gemm_bf16_swiglu_fwd(x, p, p, p, p, p, a["M"], a["I"], a["K"], a["ldx"], a["ldw"], a["ldc"], None)
+    assert swiglu_fwd(K=H + 32) == EINVAL
+    assert swiglu_fwd(ldc=I - 8) == EINVAL
+    assert swiglu_fwd(M=0) == EINVAL
+    assert swiglu_fwd(x=odd) == EINVAL
+    # SwiGLU backward
+    assert lib.tn_gemm_bf16_swiglu_bwd(p, p, p, p, p, p, M, I, H + 8, I, I, I, None) == EINVAL
+    assert lib.tn_gemm_bf16_swiglu_bwd(p, p, p, p, p, p, M, I, H, I, I, I - 8, None) == EINVAL
+    assert lib.tn_gemm_bf16_swiglu_bwd(odd, p, p, p, p, p, M, I, H, I, I, I, None) == EINVAL
+    # RoPE epilogue: head_dim other than 64 / 128, N not a whole number of heads, no tables
+    assert lib.tn_gemm_bf16_rope(p, p, None, p, p, p, M, 4096, H, H, H, 4096, 96, None) == EINVAL
+    assert lib.tn_gemm_bf16_rope(p, p, None, p, p, p, M, 4096 + 128, H, H, H, 4096 + 128, 128, None) == EINVAL
+    assert lib.tn_gemm_bf16_rope(p, p, None, None, None, p, M, 4096, H, H, H, 4096, 128, None) == EINVAL
+    # weight gradient + bias gradient without a bias buffer
+    assert lib.tn_gemm_bf16_wgrad_bias(p, p, I, H, M, p, None, I, H, H, 0, 0, 1, None, 0, None) == EINVAL
+    # grouped launch: no group, too many groups, a mode other than the weight-gradient one
+    arr_p, arr_ll, arr_i = (C.c_void_p * 1)(p), (C.c_longlong * 1)(I), (C.c_int * 1)(M)
+    Ns, Ms, ldc = (C.c_int * 1)(H), (C.c_int * 1)(I), (C.c_longlong * 1)(H)
+    def grouped(ngrp=1, a_kmaj=1, b_kmaj=1):
+        return lib.tn_gemm_bf16_grouped(arr_p, arr_p, arr_ll, (C.c_longlong * 1)(H), arr_i, arr_p, ldc, Ms, Ns, ngrp, a_kmaj,
+                                        b_kmaj, 0, 0, None, 0, None)
+    assert grouped(ngrp=0) == EINVAL
+    assert grouped(ngrp=1000) == EINVAL
+    assert grouped(a_kmaj=0) == EINVAL
