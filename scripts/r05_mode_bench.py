@@ -2,7 +2,7 @@
 W read as stored, ds_read_b64_tr_b16) slower than the row mode on a pre-transposed W, and by how much?  (If it were, one
 transposed weight copy per step — 14 GB of traffic — could buy it back.)  Also the weight-gradient mode against row mode
 on pre-transposed operands.
-    python scripts/r05_mode_bench.py"""
+    python scripts/r05_mode_bench.py [rounds [iters]]      (short runs for the PMC passes of scripts/r05_gemm16_pmc.sh)"""
 import os
 import sys
 
@@ -41,12 +41,14 @@ def main():
     dyt, xt = dy.t().contiguous(), x.t().contiguous()
     cases.append(("wgrad MLP  both contraction-major (as stored)", lambda: F.gemm([(dy, x)], True, True), 2.0 * M * I * H))
     cases.append(("wgrad MLP  row mode on pre-transposed dY, x", lambda: F.gemm([(dyt, xt)]), 2.0 * M * I * H))
-    for rd in range(5):
+    rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+    iters = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+    for rd in range(rounds):
         for name, fn, fl in cases:
-            res.setdefault(name, []).append(timeit(fn))
+            res.setdefault(name, []).append(timeit(fn, iters))
     for name, fn, fl in cases:
         ts = sorted(res[name])
-        print(f"{name:52s} median {ts[2]:7.3f} ms  min {ts[0]:7.3f}  {fl / ts[2] / 1e9:7.1f} TFLOP/s")
+        print(f"{name:52s} median {ts[len(ts) // 2]:7.3f} ms  min {ts[0]:7.3f}  {fl / ts[len(ts) // 2] / 1e9:7.1f} TFLOP/s")
 
 
 if __name__ == "__main__":
