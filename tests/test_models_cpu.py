@@ -471,3 +471,38 @@ def test_padding_slots_are_dropped_from_the_decoders_row_work_without_changing_t
     with use_ops(oops):
         model(**kw, valid_rows_max=B * T - 100)
     assert taken == [False]
+
+
+def test_op_level_ac_is_a_noop_under_sequence_parallelism_and_mismatched_norm_sources_fall_back():
+    """selective AC option "op" marks decoder blocks so that their GEMM nodes keep the residual stream
+    instead of the norm output.  Under tensor-parallel sequence parallelism the attention / MLP wrappers gather x to
+    the full sequence BEHIND the norm: the local residual does not describe the GEMM input.  apply_ac must leave such
+    a model unmarked (the reference's TP + "op" configuration is valid: touchnet/models/helper_func.py:39-96), and the
+    two consumers of a norm source drop one that does not describe their input instead of raising."""
+    import types
+    import warnings
+
+    import touchnet_amd.functional as F
+    from touchnet_amd.models.parallelize import apply_ac
+
+    cfg = DecoderConfig.from_dict(dict(model_type="llama", hidden_size=64, intermediate_size=128, num_attention_heads=4,
+                                       num_hidden_layers=2, num_key_value_heads=2, head_dim=16, vocab_size=128))
+    job = types.SimpleNamespace(training_activation_checkpoint_mode="selective",
+                                training_activation_checkpoint_selective_ac_option="op")
+    plain = PackedCausalLM(cfg)
+    apply_ac(plain, job)
+    assert all(getattr(b, "_tn_recompute_rows", False) for b in plain.model.layers)
+    sp = PackedCausalLM(cfg)
+    sp.model._tn_sp = object()                         # what models/tensor_parallel.apply_tp leaves on a decoder stack
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        apply_ac(sp, job)
+    assert not any(getattr(b, "_tn_recompute_rows", False) for b in sp.model.layers)
+    assert any("sequence parallelism" in str(x.message) for x in w)
+    # a norm source over T/tp local rows against the gathered [B, T, H] input: not a description of x
+    h_local, x_full = torch.zeros(1, 8, 64), torch.zeros(1, 16, 64)
+    src = F.norm_source(h_local, torch.ones(64), 1e-6)
+    assert not F._norm_src_describes(src, x_full)
+    assert F._norm_src_describes(F.norm_source(x_full, torch.ones(64), 1e-6), x_full)
+    assert not F._norm_src_describes(None, x_full)
+    assert not F._norm_src_describes(F.norm_source(x_full.double(), torch.ones(64), 1e-6), x_full)

@@ -91,6 +91,9 @@ _RESTYPE = {"tn_gemm_set_persistent": None, "tn_version": C.c_char_p, "tn_sumsq_
 # kernel-development entry points: exported by the library, deliberately NOT part of the C ABI (include/touchnet_amd.h)
 DEV_PROTOTYPES = {
     "tn_attn_fwd_ablate": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp],   # scripts/attn_ablate.py
+    "tn_attn_fwd_stream_trace": [_vp],         # scripts/r06_attn_trace.py
+    "tn_attn_set_fwd_schedule": [_i],
+    "tn_attn_set_bwd_dq": [_i],                # A/B of the dQ kernels inside one process (scripts/r06_attn_bwd_ab.py)      # A/B of the forward schedules inside one process (scripts/r06_attn_ab.py)
 }
 
 _lib = None

@@ -26,7 +26,8 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-re
 # per-file extras.  -fno-honor-nans: lets fmaxf chains over MFMA outputs become v_max3_f32 without a canonicalising
 # v_max per element (the forward softmax's row max); these kernels produce and consume no NaNs (masked scores are
 # -inf, fully masked rows are handled explicitly).
-EXTRA_FLAGS = {"attn_fwd.hip": ["-fno-honor-nans"], "attn_fwd_pp.hip": ["-fno-honor-nans"]}
+EXTRA_FLAGS = {"attn_fwd.hip": ["-fno-honor-nans"], "attn_fwd_pp.hip": ["-fno-honor-nans"],
+               "attn_fwd_stream.hip": ["-fno-honor-nans"]}
 
 
 def _hipcc() -> str:

@@ -667,6 +667,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(
 }  // namespace tn
 
 namespace tn {
+// attn_bwd_dq_stream.hip: the dQ pass on precomputed tile lists, Q / dO by LDS-DMA, batched operand reads, whole-row stores
+void launch_attn_bwd_dq_stream(const bf16_t* Q, const bf16_t* K, const bf16_t* V, const bf16_t* dO, const float* lse2,
+                               float* delta, bf16_t* dQ, const int* doc, AttnMeta m, QView qv, int B, int T, int Nh,
+                               int Nkv, int D, float scale, float sl2, const bf16_t* O, hipStream_t st);
 // attn_bwd_fused.hip: dK and dV in ONE pass (D = 128)
 void launch_attn_bwd_kv_fused128(const bf16_t* Q, const bf16_t* K, const bf16_t* V, const bf16_t* dO,
                                  const float* lse2, const float* delta, bf16_t* dK, bf16_t* dV, const int* doc,
@@ -684,6 +688,17 @@ static bool bwd_kv_split() {
   return e != nullptr && e[0] == 's';
 }
 
+// dQ kernel selection: 1 = attn_bwd_dq_stream.hip (default), 0 = this file's kernel (the reference the stream kernel is
+// compared against).  TN_ATTN_BWD_DQ = 0 / 1 forces one; tn_attn_set_bwd_dq (development entry point) overrides per process.
+static int g_bwd_dq_override = -1;
+static int bwd_dq_mode() {
+  static int mode = [] {
+    const char* e = getenv("TN_ATTN_BWD_DQ");
+    return e ? atoi(e) : 1;
+  }();
+  return g_bwd_dq_override >= 0 ? g_bwd_dq_override : mode;
+}
+
 static int attn_bwd_launch(const void* q, const void* k, const void* v, const void* o, const void* dout,
                            const float* lse2, float* delta, void* dq, void* dk, void* dv, const int* doc,
                            const int* meta, int B, int T, int Nh, int Nkv, int D, float scale, QView qv,
@@ -692,8 +707,7 @@ static int attn_bwd_launch(const void* q, const void* k, const void* v, const vo
   if (D != 64 && D != 128) return TN_EINVAL;
   for (int s = 0; s < qv.nseg; ++s)
     if (qv.off[s] % 128 || qv.row0[s] % 128 || (s + 1 < qv.nseg && qv.rows[s] % 128)) return TN_EINVAL;
-  const int nt = (T + kTile - 1) / kTile, n = B * nt;
-  AttnMeta m = {meta, meta + n, meta + 2 * n, meta + 3 * n, meta + 4 * n, nt};
+  const AttnMeta m = make_attn_meta(meta, B, T);
   hipStream_t st = (hipStream_t)stream;
   const float sl2 = scale * 1.4426950408889634f;
   const size_t rows = (size_t)B * qv.rpb * Nh;
@@ -704,13 +718,23 @@ static int attn_bwd_launch(const void* q, const void* k, const void* v, const vo
   static const bool delta_pass = [] { const char* e = getenv("TN_ATTN_DELTA_KERNEL"); return e && e[0] == '1'; }();
   const bf16_t* O_ = delta_pass ? nullptr : (const bf16_t*)o;
   (void)rows;
+  const bool dq_stream = bwd_dq_mode() == 1;
+  auto launch_dq = [&]() {
+    if (dq_stream)
+      launch_attn_bwd_dq_stream(Q, K, V, dO, lse2, delta, (bf16_t*)dq, doc, m, qv, B, T, Nh, Nkv, D, scale, sl2, O_, st);
+    else if (D == 128)
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<128>), gq, block, 0, st, Q, K, V, dO, lse2, delta, (bf16_t*)dq, doc, m,
+                         qv, T, Nh, Nkv, scale, sl2, O_);
+    else
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<64>), gq, block, 0, st, Q, K, V, dO, lse2, delta, (bf16_t*)dq, doc, m,
+                         qv, T, Nh, Nkv, scale, sl2, O_);
+  };
   if (D == 128) {
     if (delta_pass)
       hipLaunchKernelGGL((attn_delta_kernel<128>), dim3((rows * 16 + 255) / 256), block, 0, st, (const bf16_t*)o, dO,
                          delta, B, qv.rpb, Nh);
     else
-      hipLaunchKernelGGL((attn_bwd_dq_kernel<128>), gq, block, 0, st, Q, K, V, dO, lse2, delta, (bf16_t*)dq, doc, m,
-                         qv, T, Nh, Nkv, scale, sl2, O_);
+      launch_dq();
     if (bwd_kv_split() || qv.bidir) {          // (the fused pass is causal only)
       hipLaunchKernelGGL((attn_bwd_kv_kernel<128, 0>), gk, block, 0, st, Q, K, V, dO, lse2, delta, (bf16_t*)dk,
                          (bf16_t*)dv, doc, m, qv, T, Nh, Nkv, scale, sl2);
@@ -720,23 +744,24 @@ static int attn_bwd_launch(const void* q, const void* k, const void* v, const vo
       launch_attn_bwd_kv_fused128(Q, K, V, dO, lse2, delta, (bf16_t*)dk, (bf16_t*)dv, doc, m, qv, B, T, Nh, Nkv, scale,
                                   sl2, st);
     }
-    if (delta_pass)
-      hipLaunchKernelGGL((attn_bwd_dq_kernel<128>), gq, block, 0, st, Q, K, V, dO, lse2, delta, (bf16_t*)dq, doc, m,
-                         qv, T, Nh, Nkv, scale, sl2, O_);
+    if (delta_pass) launch_dq();
   } else {
     if (delta_pass)
       hipLaunchKernelGGL((attn_delta_kernel<64>), dim3((rows * 8 + 255) / 256), block, 0, st, (const bf16_t*)o, dO,
                          delta, B, qv.rpb, Nh);
     else
-      hipLaunchKernelGGL((attn_bwd_dq_kernel<64>), gq, block, 0, st, Q, K, V, dO, lse2, delta, (bf16_t*)dq, doc, m,
-                         qv, T, Nh, Nkv, scale, sl2, O_);
+      launch_dq();
     hipLaunchKernelGGL((attn_bwd_kv_kernel<64, 2>), gk, block, 0, st, Q, K, V, dO, lse2, delta, (bf16_t*)dk,
                        (bf16_t*)dv, doc, m, qv, T, Nh, Nkv, scale, sl2);
-    if (delta_pass)
-      hipLaunchKernelGGL((attn_bwd_dq_kernel<64>), gq, block, 0, st, Q, K, V, dO, lse2, delta, (bf16_t*)dq, doc, m,
-                         qv, T, Nh, Nkv, scale, sl2, O_);
+    if (delta_pass) launch_dq();
   }
   TN_LAUNCH_CHECK();
+  return TN_OK;
+}
+
+// Development entry point (NOT part of the C ABI): dQ kernel for A/B runs inside one process (-1 = TN_ATTN_BWD_DQ / default).
+int tn_attn_set_bwd_dq(int mode) {
+  g_bwd_dq_override = mode;
   return TN_OK;
 }
 

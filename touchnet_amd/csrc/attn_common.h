@@ -56,6 +56,16 @@ constexpr int kTile = 64;  // granularity of the document-range metadata
 //   tmin    min over all ids (0 if the tile contains pad)
 //   q_lo    first kv tile j <= t that can interact with q tile t        (t + 1 if none)
 //   kv_hi   last  q  tile t >= j that can interact with kv tile j       (j - 1 if none)
+// Behind them (round 6), what a workgroup used to derive itself through dependent memory round trips at its start:
+//   qstat [B, nq32, 4]   {min positive id, max id, 1 if a pad id occurs, 0} of every 32 positions (one wave's query rows)
+//   klist [B, nq128, 4 + 4 * kListPre]   the KV tiles a 128-position CAUSAL query tile meets, all chunks:
+//                        {count, query tile, 0, 0} then min(count, kListPre) entries {tile, min id, max id, min positive
+//                        id}; count > kListPre: the kernel builds its list itself (long documents).
+//                        (Records SORTED by count, heaviest workgroups first, were measured and dropped: the launch
+//                        balances better — a scheduling model says 0.92 -> 0.97 of the CU slots busy — but neighbouring
+//                        query tiles no longer run side by side, their shared K / V tiles fall out of the XCD's L2 and
+//                        the wait for a tile grows by 40 %: 233 -> 242 us, profiles/r06a_*.)
+constexpr int kListPre = 64;
 struct AttnMeta {
   const int* tmin;
   const int* tmax;
@@ -63,7 +73,19 @@ struct AttnMeta {
   const int* q_lo;
   const int* kv_hi;
   int nt;
+  const int* qstat;
+  const int* klist;
+  int nq32, nq128;
 };
+__host__ inline int attn_meta_ints(int B, int T) {
+  const int nt = (T + kTile - 1) / kTile, nq32 = (T + 31) / 32, nq128 = (T + 127) / 128;
+  return 5 * B * nt + 4 * B * nq32 + (4 + 4 * kListPre) * B * nq128;
+}
+__host__ inline AttnMeta make_attn_meta(const int* meta, int B, int T) {
+  const int nt = (T + kTile - 1) / kTile, n = B * nt, nq32 = (T + 31) / 32, nq128 = (T + 127) / 128;
+  return AttnMeta{meta, meta + n, meta + 2 * n, meta + 3 * n, meta + 4 * n, nt,
+                  meta + 5 * n, meta + 5 * n + 4 * B * nq32, nq32, nq128};
+}
 
 // Which rows of the (possibly sequence-sharded) query-side buffers a launch covers.  Q / O / dO / dQ are
 // [B, rpb, Nh, D] and LSE / delta are [B, Nh, rpb]; segment s = local rows [row0, row0 + rows) holding GLOBAL

@@ -70,6 +70,51 @@ __global__ void attn_meta_range_kernel(const int* __restrict__ tmax, const int* 
   kv_hi[idx] = hi;
 }
 
+// Per 32 positions: the id statistics of one wave's query rows (attn_common.h qstat).
+__global__ void attn_meta_qstat_kernel(const int* __restrict__ doc, int* __restrict__ qstat, int B, int T, int nq32) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * nq32) return;
+  const int b = idx / nq32, g = idx % nq32;
+  int mnp = 0x7fffffff, mx = 0, zero = 0;
+  for (int i = 0; i < 32; ++i) {
+    const int p = g * 32 + i;
+    const int d = p < T ? doc[(size_t)b * T + p] : 0;
+    mx = max(mx, d);
+    if (d > 0) mnp = min(mnp, d);
+    zero |= d == 0;
+  }
+  reinterpret_cast<int4*>(qstat)[idx] = make_int4(mnp, mx, zero, 0);
+}
+
+// Per 128-position causal query tile: the KV tiles it meets (attn_common.h klist) — one wave per tile, ballot compaction
+// in tile order, i.e. exactly the list the forward / dQ workgroups build for themselves.
+__global__ void attn_meta_klist_kernel(const int* __restrict__ tmin, const int* __restrict__ tmax,
+                                       const int* __restrict__ tminpos, const int* __restrict__ q_lo,
+                                       int* __restrict__ klist, int B, int nt, int nq128) {
+  const int qt = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+  const int* mn = tmin + (size_t)b * nt;
+  const int* mx = tmax + (size_t)b * nt;
+  const int* mp = tminpos + (size_t)b * nt;
+  const int t0 = 2 * qt, t1 = min(2 * qt + 1, nt - 1);
+  int bminpos = 0x7fffffff, bmax = 0, j_lo = nt;
+  for (int t = t0; t <= t1; ++t) {
+    bminpos = min(bminpos, mp[t]);
+    bmax = max(bmax, mx[t]);
+    j_lo = min(j_lo, q_lo[(size_t)b * nt + t]);
+  }
+  int4* out = reinterpret_cast<int4*>(klist + ((size_t)b * nq128 + qt) * (4 + 4 * kListPre));
+  int count = 0;
+  for (int base = j_lo; base <= t1; base += 64) {
+    const int j = base + lane;
+    const bool ok = j <= t1 && tile_may_interact(bminpos, bmax, mp[j <= t1 ? j : t1], mx[j <= t1 ? j : t1]);
+    const unsigned long long bal = __ballot(ok);
+    const int pos = count + __popcll(bal & ((1ull << lane) - 1ull));
+    if (ok && pos < kListPre) out[1 + pos] = make_int4(j, mn[j], mx[j], mp[j]);
+    count += __popcll(bal);
+  }
+  if (lane == 0) out[0] = make_int4(count, qt, 0, 0);
+}
+
 // ------------------------------------------------------------------------------------------------
 // ABL (ablation, timing experiments only — results are wrong for ABL != 0; reached through tn_attn_fwd_ablate):
 //   1 no in-loop global loads / LDS stores   2 no softmax VALU   3 no P.V MFMAs   4 no QK^T MFMAs   5 no barrier
@@ -351,19 +396,24 @@ using namespace tn;
 
 int tn_attn_fwd_pp_launch(const void* q, const void* k, const void* v, void* o, float* lse2, const int* doc,
                           AttnMeta m, QView qv, int B, int T, int Nh, int Nkv, int D, float sl2, hipStream_t st);
+// attn_fwd_stream.hip: precomputed tile lists, K / V / Q by LDS-DMA, whole-row stores
+int tn_attn_fwd_stream_launch(const void* q, const void* k, const void* v, void* o, float* lse2, const int* doc,
+                              AttnMeta m, QView qv, int B, int T, int Nh, int Nkv, int D, float sl2, hipStream_t st);
 
-// Schedule selection: 0 = 4 waves x 32 rows, independent workgroups (default: fastest on packed batches of short
-// documents, where a workgroup meets only a handful of KV tiles); 1 = ping-pong (attn_fwd_pp.hip: 256-row
-// workgroups, ~15 % faster on long documents / plain causal, slower on short ones).  TN_ATTN_FWD_SCHEDULE = 0 / 1 forces
-// one; unset = by shape: the long-sequence recipes (T >= 32768, D = 128: config D's 20-minute recordings; measured at
-// T = 65536 plain causal 35.1 vs 38.3 ms) take the ping-pong kernel, everything else — the 8192-token packed batches, the
-// audio tower's 1500-frame clips (0.27 vs 0.35 ms) — schedule 0.
+// Schedule selection: 2 = attn_fwd_stream.hip (default: 14-20 % faster than schedule 0 on every shape measured,
+// profiles/r06a_attn_fwd_stream_vs_base_same_box.log); 1 = ping-pong (attn_fwd_pp.hip: 256-row workgroups, the fastest on
+// the long-sequence recipes — T >= 32768, D = 128: config D's 20-minute recordings, 8.81 vs 9.00 ms at T = 32768 plain
+// causal); 0 = this file's kernel (register-staged K / V tiles, everything derived inside the workgroup: kept as the
+// reference the other two are compared against, and for the ablation entry point).  TN_ATTN_FWD_SCHEDULE = 0 / 1 / 2
+// forces one; unset = by shape.
+static int g_fwd_schedule_override = -2;     // tn_attn_set_fwd_schedule (development entry point)
 static int fwd_schedule(int T, int D) {
   static int mode = [] {
     const char* e = getenv("TN_ATTN_FWD_SCHEDULE");
     return e ? atoi(e) : -1;
   }();
-  return mode >= 0 ? mode : (T >= 32768 && D == 128 ? 1 : 0);
+  const int m = g_fwd_schedule_override >= -1 ? g_fwd_schedule_override : mode;
+  return m >= 0 ? m : (T >= 32768 && D == 128 ? 1 : 2);
 }
 
 template <int ABL, int NW = 4>
@@ -378,8 +428,9 @@ static int attn_fwd_launch_abl(const void* q, const void* k, const void* v, void
 
 extern "C" {
 
-// meta buffers: 5 int32 arrays of B*nt each, nt = ceil(T/64):  [tmin | tmax | tminpos | q_lo | kv_hi]
-int tn_attn_meta_ints(int B, int T) { return 5 * B * ((T + kTile - 1) / kTile); }
+// meta buffers: 5 int32 arrays of B*nt each, nt = ceil(T/64):  [tmin | tmax | tminpos | q_lo | kv_hi], then
+// [qstat | klist] (attn_common.h AttnMeta)
+int tn_attn_meta_ints(int B, int T) { return attn_meta_ints(B, T); }
 
 int tn_attn_build_meta(const int* doc, int* meta, int B, int T, void* stream) {
   if (B <= 0 || T <= 0) return TN_EINVAL;
@@ -391,6 +442,13 @@ int tn_attn_build_meta(const int* doc, int* meta, int B, int T, void* stream) {
   hipLaunchKernelGGL(attn_meta_range_kernel, dim3((n + 127) / 128), dim3(128), 0, st, meta + n, meta + 2 * n,
                      meta + 3 * n, meta + 4 * n, B, nt);
   TN_LAUNCH_CHECK();
+  const AttnMeta m = make_attn_meta(meta, B, T);
+  hipLaunchKernelGGL(attn_meta_qstat_kernel, dim3((B * m.nq32 + 127) / 128), dim3(128), 0, st, doc,
+                     const_cast<int*>(m.qstat), B, T, m.nq32);
+  TN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(attn_meta_klist_kernel, dim3(m.nq128, B), dim3(64), 0, st, m.tmin, m.tmax, m.tminpos, m.q_lo,
+                     const_cast<int*>(m.klist), B, nt, m.nq128);
+  TN_LAUNCH_CHECK();
   return TN_OK;
 }
 
@@ -400,12 +458,16 @@ static int attn_fwd_launch(const void* q, const void* k, const void* v, void* o,
   if (B <= 0 || T <= 0 || Nh <= 0 || Nkv <= 0 || Nh % Nkv) return TN_EINVAL;
   for (int s = 0; s < qv.nseg; ++s)
     if (qv.off[s] % 128 || qv.row0[s] % 128 || (s + 1 < qv.nseg && qv.rows[s] % 128)) return TN_EINVAL;
-  const int nt = (T + kTile - 1) / kTile, n = B * nt;
-  AttnMeta m = {meta, meta + n, meta + 2 * n, meta + 3 * n, meta + 4 * n, nt};
+  const int nt = (T + kTile - 1) / kTile;
+  const AttnMeta m = make_attn_meta(meta, B, T);
   const float sl2 = scale * 1.4426950408889634f;
   hipStream_t st = (hipStream_t)stream;
-  if (!qv.bidir && fwd_schedule(T, D) == 1 && (D == 64 || D == 128) && nt <= 1024)   // (the ping-pong kernel's LDS tile list)
+  int sched = fwd_schedule(T, D);
+  if (sched == 1 && (qv.bidir || nt > 1024)) sched = 2;     // (the ping-pong kernel: causal, its LDS tile list)
+  if (sched == 1 && (D == 64 || D == 128))
     return tn_attn_fwd_pp_launch(q, k, v, o, lse2, doc, m, qv, B, T, Nh, Nkv, D, sl2, st);
+  if (sched == 2 && (D == 64 || D == 128))
+    return tn_attn_fwd_stream_launch(q, k, v, o, lse2, doc, m, qv, B, T, Nh, Nkv, D, sl2, st);
   dim3 grid(Nh, qv.tiles(0, 128) + qv.tiles(1, 128), B), block(256);
   if (D == 128)
     hipLaunchKernelGGL((attn_fwd_kernel<128>), grid, block, 0, st, (const bf16_t*)q, (const bf16_t*)k,
@@ -433,12 +495,18 @@ int tn_attn_fwd_bidir(const void* q, const void* k, const void* v, void* o, floa
   return attn_fwd_launch(q, k, v, o, lse2, doc, meta, B, T, Nh, Nkv, D, scale, qv, stream);
 }
 
+// Development entry point (NOT part of the C ABI): force a forward schedule for A/B runs inside one process.
+// mode -2 = back to TN_ATTN_FWD_SCHEDULE / the shape rule, -1 = the shape rule, 0 / 1 / 2 = a schedule.
+int tn_attn_set_fwd_schedule(int mode) {
+  g_fwd_schedule_override = mode;
+  return TN_OK;
+}
+
 // Timing experiments only (D = 128): the forward with one piece removed, see ABL above.  Output is garbage.
 // Development entry point: exported, but NOT declared in include/touchnet_amd.h (not part of the C ABI).
 int tn_attn_fwd_ablate(const void* q, const void* k, const void* v, void* o, float* lse2, const int* doc,
                        const int* meta, int B, int T, int Nh, int Nkv, float scale, int ablation, void* stream) {
-  const int nt = (T + kTile - 1) / kTile, n = B * nt;
-  AttnMeta m = {meta, meta + n, meta + 2 * n, meta + 3 * n, meta + 4 * n, nt};
+  const AttnMeta m = make_attn_meta(meta, B, T);
   const QView qv = {1, {0, 0}, {T, 0}, {0, 0}, T, 0, ~0ull};
   const float sl2 = scale * 1.4426950408889634f;
   hipStream_t st = (hipStream_t)stream;

@@ -1059,6 +1059,14 @@ def norm_source(h, norm_weight, eps):
     return (h.detach(), norm_weight.detach(), float(eps))
 
 
+def _norm_src_describes(norm_src, x) -> bool:
+    """`norm_src` may stand in for x only if its residual stream has x's rows and dtype; anything else (a sequence-parallel
+    wrapper that gathered x to the full sequence behind the norm) silently keeps x itself: a memory optimisation must
+    never change or break a step."""
+    return (norm_src is not None and tuple(norm_src[0].shape) == tuple(x.shape) and norm_src[0].dtype == x.dtype
+            and norm_src[1].shape[-1] == x.shape[-1])
+
+
 def linear_group(x, layers, wgrad: str = "tn", dgrad_tn: bool = True, norm_src=None, rope=None):
     """``layers``: list of (weight [N_i, K], bias [N_i] | None) sharing the input ``x`` -> list of outputs.
     ``norm_src``: see `norm_source`.  ``rope = (cos, sin, head_dim, (i, j, ..))``: outputs i, j, .. ([.., heads * head_dim])
@@ -1070,8 +1078,8 @@ def linear_group(x, layers, wgrad: str = "tn", dgrad_tn: bool = True, norm_src=N
         raise _C.KernelError("linear_group: device tensors only (the product path has no CPU fallback)")
     ws = [w for w, _ in layers]
     bs = [b for _, b in layers]
-    if norm_src is not None and (tuple(norm_src[0].shape) != tuple(x.shape) or norm_src[0].dtype != x.dtype):
-        raise _C.KernelError("linear_group: norm_src does not describe x")
+    if not _norm_src_describes(norm_src, x):
+        norm_src = None           # (e.g. under tensor-parallel sequence parallelism x is the gathered sequence): keep x itself
     if rope is not None:
         rope = (rope[0].detach(), rope[1].detach(), int(rope[2]), tuple(int(i) for i in rope[3]))
     packed = (wgrad, norm_src, rope) if (norm_src is not None or rope is not None) else wgrad
@@ -1238,6 +1246,8 @@ def swiglu_mlp(x, w_gate, w_up, w_down, norm_src=None):
     if not (x.is_cuda or x.is_meta):
         raise _C.KernelError("swiglu_mlp: device tensors only (the product path has no CPU fallback)")
     M = x.numel() // x.shape[-1]
+    if not _norm_src_describes(norm_src, x):
+        norm_src = None
     if (_MLP_FUSED and x.dtype == torch.bfloat16
             and all(w.dtype == torch.bfloat16 for w in (w_gate, w_up, w_down))
             and _tn_ok(M, x.shape[-1], (w_gate.shape[0], w_down.shape[0]))):

@@ -419,7 +419,9 @@ def attn_build_meta(doc: Tensor) -> Tensor:
 @attn_build_meta.register_fake
 def _(doc):
     B, T = doc.shape
-    return doc.new_empty(5 * B * ((T + 63) // 64), dtype=torch.int32)
+    # (tn_attn_meta_ints: tile statistics + per-wave statistics + precomputed KV-tile lists, csrc/attn_common.h)
+    return doc.new_empty(5 * B * ((T + 63) // 64) + 4 * B * ((T + 31) // 32) + 260 * B * ((T + 127) // 128),
+                         dtype=torch.int32)
 
 
 def _segs_array(segs: List[int]):

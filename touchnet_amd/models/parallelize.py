@@ -46,6 +46,12 @@ def apply_ac(model: nn.Module, job_config) -> None:
                          f"layer frequency")
     if mode == "selective" and option == "op":
         marked = 0
+        if any(getattr(m, "_tn_sp", None) is not None for m in model.modules()):
+            # tensor-parallel SEQUENCE parallelism (apply_tp ran first): the attention / MLP wrappers gather x to the full
+            # sequence behind the norm, so the local residual stream does not describe the GEMM input.  The option stays
+            # what it was before round 5 for this layout: valid, and a no-op.
+            warnings.warn("selective AC option 'op' has no effect under tensor-parallel sequence parallelism")
+            return
         for blocks in block_groups(model):
             for blk in blocks:
                 if hasattr(blk, "post_attention_layernorm") and hasattr(blk, "mlp"):       # (the decoder blocks)
