@@ -17,7 +17,8 @@ def test_attention_backward_stage_ring_is_not_serialised_by_alias_waits():
     r = subprocess.run(["bash", os.path.join(ROOT, "scripts", "check_dma_waits.sh")], capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert r.stdout.count("attn_bwd_") >= 5, r.stdout      # two dK/dV (D=128) + one (D=64) + two dQ kernels seen
+    assert r.stdout.count("attn_bwd_") >= 7, r.stdout      # two dK/dV (D=128) + one (D=64) + two dQ + two stream dQ kernels
+    assert r.stdout.count("attn_fwd_stream") >= 2, r.stdout
 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not on PATH")

@@ -109,9 +109,22 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(
   // ONE LDS variable on purpose: with two, hipcc's module-LDS lowering attaches alias scopes to every access and the
   // waitcnt insertion then puts `s_waitcnt vmcnt(0)` in front of the first LDS read that may alias a pending LDS-DMA
   // (= every read of the ring), which serialises the ring (see attn_common.h, i32x4_t).
-  __shared__ __attribute__((aligned(1024))) char smem[NST * STAGEB + (LCAP + NST) * 32 + 16];
-  i32x4_t* slist = reinterpret_cast<i32x4_t*>(smem + NST * STAGEB);     // entry e = {slist[2e], slist[2e + 1]}
-  int* wcount = reinterpret_cast<int*>(smem + NST * STAGEB + (LCAP + NST) * 32);
+  // Round 6 (attn_fwd_stream.hip's treatment), D = 128 only: the stored list of query tiles instead of dependent metadata
+  // loads; before the ring starts its area holds each wave's private K / V images (the 32 rows arrive by LDS-DMA as
+  // 64-byte runs); behind the last stage the dV / dK rows leave through it as whole rows.  Same box, interleaved
+  // (profiles/r06c_*): the D = 128 passes gain 1-8 % (most on short documents), the D = 64 pass LOSES 1-4 % (187 -> 228
+  // registers for the same two waves per SIMD; its row loads and stores are half as many) and keeps the direct form.
+  using KTile = PTile<32, D>;
+  constexpr int KIMGB = KTile::SIZE * 2;
+  constexpr int OSTR = 2 * D + 16;
+  constexpr bool R6 = D == 128;
+  constexpr int RING0 = NST * STAGEB, RING1 = 4 * 2 * 32 * OSTR, RING2 = 4 * 2 * KIMGB;
+  constexpr int RINGX = RING0 > RING1 ? (RING0 > RING2 ? RING0 : RING2) : (RING1 > RING2 ? RING1 : RING2);
+  constexpr int RING = D == 128 ? RINGX : RING0;
+  __shared__ __attribute__((aligned(1024))) char smem[RING + (LCAP + NST) * 32 + 16 + kListPre * 16];
+  i32x4_t* slist = reinterpret_cast<i32x4_t*>(smem + RING);             // entry e = {slist[2e], slist[2e + 1]}
+  int* wcount = reinterpret_cast<int*>(smem + RING + (LCAP + NST) * 32);
+  i32x4_t* qent = reinterpret_cast<i32x4_t*>(smem + RING + (LCAP + NST) * 32 + 16);   // the stored q-tile list
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -123,8 +136,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(
   const int kvrow = wk0 + l31;
   const bool kvalid = kvrow < T;
 
+  const bool bidir = qv.bidir != 0;
+  // ---- round trip A: the stored list of query tiles, the id statistics of this wave's rows, this lane's id, and the
+  // wave's K / V rows — issued together
+  const bool plain = R6 && qv.nseg == 1 && qv.off[0] == 0 && qv.row0[0] == 0 && !bidir;   // (the stored lists are causal)
+  i32x4_t ql_head = {kListPre + 1, 0, 0, 0}, ql_mine = {0, 0, 0, 0};
+  if (plain) {
+    const i32x4_t* ql = reinterpret_cast<const i32x4_t*>(meta.qlist) + ((size_t)b * meta.nq128 + kt) * (1 + kListPre);
+    ql_head = ql[0];
+    if (tid < kListPre) ql_mine = ql[1 + tid];
+  }
+  i32x4_t ws4 = {0x7fffffff, 0, 1, 0};          // {min positive id, max id, pad present, -} of the wave's 32 kv rows
+  if (R6 && wk0 < T) ws4 = reinterpret_cast<const i32x4_t*>(meta.qstat)[(size_t)b * meta.nq32 + wk0 / 32];
+  const int dkdoc = kvalid ? doc[(size_t)b * T + kvrow] : 0;
   bf16x8_t kreg[KSTEPS], vreg[DO_DK ? KSTEPS : 1];
-  {
+  if constexpr (!R6) {
     const size_t off = (((size_t)b * T + (kvalid ? kvrow : 0)) * Nkv + hk) * D + 8 * hi;
 #pragma unroll
     for (int s = 0; s < KSTEPS; ++s) {
@@ -136,25 +162,72 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(
       kreg[s] = as_bf16x8(a);
       if (DO_DK) vreg[s] = as_bf16x8(c);
     }
+  } else {
+    const size_t krow_elems0 = (size_t)Nkv * D;
+    const uint32_t k_bytes0 = (uint32_t)min((size_t)T * krow_elems0 * 2, (size_t)0x7fffffff);
+    const __amdgpu_buffer_rsrc_t rk0 =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(K + (size_t)b * T * krow_elems0), 0, k_bytes0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv0 =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(V + (size_t)b * T * krow_elems0), 0, k_bytes0, 0x00020000);
+    const int rrk = lane >> 2;
+    const uint32_t voffk = (uint32_t)(((size_t)rrk * krow_elems0 + 8 * ((lane & 3) ^ ((rrk >> 2) & 3))) * 2);
+    char* kpriv = smem + wave * (2 * KIMGB);    // {K image | V image} of this wave's 32 rows
+#pragma unroll
+    for (int pc = 0; pc < KTile::NP * 2; ++pc) {
+      const int panel = pc % KTile::NP, rh = pc / KTile::NP;
+      const uint32_t vo = (wk0 + 16 * rh + rrk < T) ? voffk : 0x80000000u;
+      const uint32_t so = (uint32_t)((((size_t)wk0 + 16 * rh) * krow_elems0 + (size_t)hk * D + 32 * panel) * 2);
+      char* dst = kpriv + panel * (KTile::PSTRIDE * 2) + rh * 1024;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rk0, (lds_ptr_t)dst, 16, vo, so, 0, 0);
+      if (DO_DK) __builtin_amdgcn_raw_ptr_buffer_load_lds(rv0, (lds_ptr_t)(dst + KIMGB), 16, vo, so, 0, 0);
+    }
+    wait_vmcnt<0>();
+    asm volatile("" ::"v"(dkdoc));             // (hipcc's own wait for this load must sit HERE, not inside the stage loop)
+    const PRowReader<32, D> krd(l31, hi);
+    const bf16_t* ki = reinterpret_cast<const bf16_t*>(smem + wave * (2 * KIMGB));
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) {
+      kreg[s] = krd.operand(ki, 0, s);
+      if (DO_DK) vreg[s] = krd.operand(ki + KTile::SIZE, 0, s);
+    }
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) {
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kreg[s]));
+      if (DO_DK) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vreg[s]));
+    }
   }
-  const int dkdoc = kvalid ? doc[(size_t)b * T + kvrow] : 0;
+  const int n_pre = __builtin_amdgcn_readfirstlane(ql_head.x);
+  const bool pre = n_pre <= kListPre;          // the stored list is complete: use it
+  if (pre && tid < n_pre) qent[tid] = ql_mine;
+  // everybody has read its private images (the ring area is free) and the list is in LDS
+  __syncthreads();
 
   const int* m_min = meta.tmin + (size_t)b * meta.nt;
   const int* m_max = meta.tmax + (size_t)b * meta.nt;
   const int* m_minpos = meta.tminpos + (size_t)b * meta.nt;
   const int t0 = 2 * kt, t1 = min(2 * kt + 1, meta.nt - 1);
-  const bool bidir = qv.bidir != 0;
-  // first 64-position query tile, global index: q >= kv under the causal mask; bidirectional: the first tile that shares
-  // a document with these kv rows
-  const int qt_lo = bidir ? min(meta.q_lo[(size_t)b * meta.nt + t0], meta.q_lo[(size_t)b * meta.nt + t1]) : k0 / kTile;
   const int kvcap = bidir ? -0x7fffffff : kvrow;            // `kvcap <= q`: the causal term of the predicate
-  const int bminpos = min(m_minpos[t0], m_minpos[t1]);
-  const int bmax = max(m_max[t0], m_max[t1]);
-  const int qhi64 = max(meta.kv_hi[(size_t)b * meta.nt + t0], meta.kv_hi[(size_t)b * meta.nt + t1]);
-  const int qt_end = min(qhi64 + 1, meta.nt);                 // exclusive
+  int bminpos = 0, bmax = 0, qt_lo = k0 / kTile, qt_end = 0;
+  if (!pre) {
+    // first 64-position query tile, global index: q >= kv under the causal mask; bidirectional: the first tile that
+    // shares a document with these kv rows
+    if (bidir) qt_lo = min(meta.q_lo[(size_t)b * meta.nt + t0], meta.q_lo[(size_t)b * meta.nt + t1]);
+    bminpos = min(m_minpos[t0], m_minpos[t1]);
+    bmax = max(m_max[t0], m_max[t1]);
+    const int qhi64 = max(meta.kv_hi[(size_t)b * meta.nt + t0], meta.kv_hi[(size_t)b * meta.nt + t1]);
+    qt_end = min(qhi64 + 1, meta.nt);                       // exclusive
+  }
   int wminpos, wmax;
-  wave_id_range(dkdoc, wminpos, wmax);
-  const bool w_uniform = (wminpos == wmax) && !__any(dkdoc == 0);   // all 32 kv rows in one document
+  bool w_uniform;                                           // all 32 kv rows in one document
+  if constexpr (R6) {
+    const int4 wsc = scalarize(ws4);
+    wminpos = wsc.x;
+    wmax = wsc.y;
+    w_uniform = wminpos == wmax && wsc.z == 0;
+  } else {
+    wave_id_range(dkdoc, wminpos, wmax);
+    w_uniform = (wminpos == wmax) && !__any(dkdoc == 0);
+  }
   // query tiles this launch owns: per segment, the global 64-tile range clipped to [qt_lo, qt_end)
   int seg_lo[2], seg_n[2];
 #pragma unroll
@@ -163,7 +236,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(
     seg_lo[s] = max(qt_lo, first);
     seg_n[s] = max(min(qt_end, first + cnt) - seg_lo[s], 0);
   }
-  const int nqt = seg_n[0] + seg_n[1];
+  const int nqt = pre ? n_pre : seg_n[0] + seg_n[1];
   // ---- the stream of stages: (head in group, BQ-row part of a 64-row q tile), skipping what cannot interact.
   // The per-stage bookkeeping used to be a scalar scan every wave ran between two stages (≈100 SALU instructions per
   // stage and wave: 7 SALU per MFMA in the dV kernel's PMC); now the workgroup compacts LCAP candidate stages at a time
@@ -175,14 +248,23 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(
     if (c < total_c) {
       const int g = c / per_head, r = c - g * per_head;
       const int idx = r / SPT, part = r % SPT;
-      const int sg = idx >= seg_n[0] ? 1 : 0;
-      const int t64 = seg_lo[sg] + idx - (sg ? seg_n[0] : 0);
-      const int lt = t64 - qv.off[sg] / kTile;
-      const int left = min(qv.rows[sg] - lt * kTile, T - t64 * kTile) - BQ * part;
-      d.mp = m_minpos[t64];
-      d.mx = m_max[t64];
-      d.mn = m_min[t64];
-      d.valid = left > 0 && tile_may_interact(d.mp, d.mx, bminpos, bmax);
+      int sg = 0, t64, lt, left;
+      if (pre) {                                  // (plain launch: local row = global position)
+        const i32x4_t qe = qent[idx];
+        t64 = qe.x; d.mn = qe.y; d.mx = qe.z; d.mp = qe.w;
+        lt = t64;
+        left = T - t64 * kTile - BQ * part;
+        d.valid = left > 0;
+      } else {
+        sg = idx >= seg_n[0] ? 1 : 0;
+        t64 = seg_lo[sg] + idx - (sg ? seg_n[0] : 0);
+        lt = t64 - qv.off[sg] / kTile;
+        left = min(qv.rows[sg] - lt * kTile, T - t64 * kTile) - BQ * part;
+        d.mp = m_minpos[t64];
+        d.mx = m_max[t64];
+        d.mn = m_min[t64];
+        d.valid = left > 0 && tile_may_interact(d.mp, d.mx, bminpos, bmax);
+      }
       d.qsb = t64 * kTile + BQ * part;
       d.lrow = qv.row0[sg] + lt * kTile + BQ * part;
       d.left = min(left, BQ);
@@ -355,6 +437,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(
           for (int e = 0; e < 4; ++e) p[4 * r4 + e] *= dpacc[4 * r4 + e] - de[e];
         }
       };
+      // (Round 6 tried the operand reads of a half as inline-asm batches with counted lgkmcnt waits, the form that serves
+      //  attn_fwd_stream.hip: 1.5 % SLOWER here on both D = 64 shapes, same box — profiles/r06c_*; hipcc's own reads stay.)
 #pragma unroll
       for (int qs = 0; qs < BQ / 32; ++qs) {
         const int qsb = cur.qsb + 32 * qs;
@@ -381,23 +465,62 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(
    __syncthreads();
   }
 
-  if (kvalid) {
-    const size_t off = (((size_t)b * T + kvrow) * Nkv + hk) * D;
+  // ---- epilogue: the ring is quiet behind the last chunk's barrier; each wave writes its 32 x D blocks (8-byte runs of
+  // the accumulator layout) into private images and reads them back as whole rows — 16-byte stores, 64 / (D / 8) rows per
+  // instruction, instead of 8 bytes per lane at a row stride (attn_fwd_stream.hip)
+  if constexpr (!R6) {
+    if (kvalid) {
+      const size_t off = (((size_t)b * T + kvrow) * Nkv + hk) * D;
+#pragma unroll
+      for (int db = 0; db < DBLK; ++db) {
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          uint2 o;
+          if (DO_DK) {
+            o.x = pack2bf(dkacc[db][4 * r4 + 0] * scale, dkacc[db][4 * r4 + 1] * scale);
+            o.y = pack2bf(dkacc[db][4 * r4 + 2] * scale, dkacc[db][4 * r4 + 3] * scale);
+            *reinterpret_cast<uint2*>(dK + off + 32 * db + 8 * r4 + 4 * hi) = o;
+          }
+          if (DO_DV) {
+            o.x = pack2bf(dvacc[db][4 * r4 + 0], dvacc[db][4 * r4 + 1]);
+            o.y = pack2bf(dvacc[db][4 * r4 + 2], dvacc[db][4 * r4 + 3]);
+            *reinterpret_cast<uint2*>(dV + off + 32 * db + 8 * r4 + 4 * hi) = o;
+          }
+        }
+      }
+    }
+  } else {
+    typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
+    char* obv = smem + wave * (2 * 32 * OSTR);
+    char* obk = obv + 32 * OSTR;
 #pragma unroll
     for (int db = 0; db < DBLK; ++db) {
 #pragma unroll
       for (int r4 = 0; r4 < 4; ++r4) {
-        uint2 o;
-        if (DO_DK) {
-          o.x = pack2bf(dkacc[db][4 * r4 + 0] * scale, dkacc[db][4 * r4 + 1] * scale);
-          o.y = pack2bf(dkacc[db][4 * r4 + 2] * scale, dkacc[db][4 * r4 + 3] * scale);
-          *reinterpret_cast<uint2*>(dK + off + 32 * db + 8 * r4 + 4 * hi) = o;
-        }
         if (DO_DV) {
-          o.x = pack2bf(dvacc[db][4 * r4 + 0], dvacc[db][4 * r4 + 1]);
-          o.y = pack2bf(dvacc[db][4 * r4 + 2], dvacc[db][4 * r4 + 3]);
-          *reinterpret_cast<uint2*>(dV + off + 32 * db + 8 * r4 + 4 * hi) = o;
+          const u32x2_t o = {pack2bf(dvacc[db][4 * r4 + 0], dvacc[db][4 * r4 + 1]),
+                             pack2bf(dvacc[db][4 * r4 + 2], dvacc[db][4 * r4 + 3])};
+          *reinterpret_cast<u32x2_t*>(obv + l31 * OSTR + (32 * db + 8 * r4 + 4 * hi) * 2) = o;
         }
+        if (DO_DK) {
+          const u32x2_t o = {pack2bf(dkacc[db][4 * r4 + 0] * scale, dkacc[db][4 * r4 + 1] * scale),
+                             pack2bf(dkacc[db][4 * r4 + 2] * scale, dkacc[db][4 * r4 + 3] * scale)};
+          *reinterpret_cast<u32x2_t*>(obk + l31 * OSTR + (32 * db + 8 * r4 + 4 * hi) * 2) = o;
+        }
+      }
+    }
+    constexpr int CPR = D / 8, RPI = 64 / CPR;           // 16-byte chunks per row, rows per store instruction
+    const int cc = lane % CPR, r0 = lane / CPR;
+    const size_t off = (((size_t)b * T + wk0) * Nkv + hk) * D + cc * 8;
+#pragma unroll
+    for (int i = 0; i < 32 / RPI; ++i) {
+      const int row = i * RPI + r0;
+      u32x4_t v4 = {0, 0, 0, 0}, k4 = {0, 0, 0, 0};
+      if (DO_DV) v4 = *reinterpret_cast<const u32x4_t*>(obv + row * OSTR + cc * 16);
+      if (DO_DK) k4 = *reinterpret_cast<const u32x4_t*>(obk + row * OSTR + cc * 16);
+      if (wk0 + row < T) {
+        if (DO_DV) *reinterpret_cast<u32x4_t*>(dV + off + (size_t)row * Nkv * D) = v4;
+        if (DO_DK) *reinterpret_cast<u32x4_t*>(dK + off + (size_t)row * Nkv * D) = k4;
       }
     }
   }

@@ -19,6 +19,12 @@
 // rules and the output contract are those of attn_bwd.hip's dK/dV kernel (same reference semantics:
 // transformers/integrations/flex_attention.py:190-201 via touchnet/models/kimi_audio/modeling_kimi_audio.py:582-585).
 //
+// Round 6 (the treatment of attn_fwd_stream.hip; one workgroup per CU here, so nothing hides a workgroup's start and end):
+// the query tiles a KV tile meets and the id statistics of the four waves' rows come from the mask metadata
+// (attn_common.h qlist / qstat) instead of dependent loads inside the workgroup; each wave fetches ITS 32 K and V rows by
+// LDS-DMA into a private piece of the ring area (64-byte runs instead of 16 bytes per lane at a row stride); dK / dV leave
+// through the ring area as whole rows, 16 bytes per lane.
+//
 // Hazards hipcc does not see (cdna_hip_programming.md 5.7): an asm MFMA's VGPR result is read by compiler VALU code only
 // behind >= 8 further MFMAs or an explicit s_nop pad tied to the result; packed P / dS operands are written >= one gap
 // before the MFMA that reads them and the first MFMA of a group opens with s_nop 1; transpose reads are asm loads
@@ -185,10 +191,14 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kv_fused_kernel(
   constexpr int STAGEB = 2 * IMGB + 4 * 256;    // {Q image | dO image | lse | delta | doc | doc}, 256-byte aux rows
   constexpr int LCAP = 256;                     // stage-list chunk: one candidate stage per thread
   // ONE LDS variable (attn_bwd.hip explains why two would serialise the DMA ring)
-  __shared__ __attribute__((aligned(1024))) char smem[NST * STAGEB + (LCAP + NST + 1) * 16 + 16 + 64];
+  using KTile = PTile<32, D>;                   // a wave's private 32-row image of K / V (prologue)
+  constexpr int KIMGB = KTile::SIZE * 2;
+  constexpr int OSTR = 2 * D + 16;              // row stride (bytes) of the dV / dK staging images (epilogue)
+  static_assert(4 * 2 * KIMGB <= NST * STAGEB && 4 * 2 * 32 * OSTR <= NST * STAGEB, "private images live in the ring area");
+  __shared__ __attribute__((aligned(1024))) char smem[NST * STAGEB + (LCAP + NST + 1) * 16 + 16 + kListPre * 16];
   i32x4_t* slist = reinterpret_cast<i32x4_t*>(smem + NST * STAGEB);     // stage list, one QStage per entry
   int* wcount = reinterpret_cast<int*>(smem + NST * STAGEB + (LCAP + NST + 1) * 16);
-  i32x4_t* wstat = reinterpret_cast<i32x4_t*>(smem + NST * STAGEB + (LCAP + NST + 1) * 16 + 16);   // per wave
+  i32x4_t* qent = reinterpret_cast<i32x4_t*>(smem + NST * STAGEB + (LCAP + NST + 1) * 16 + 16);   // the stored q-tile list
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -200,48 +210,86 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kv_fused_kernel(
   const int kvrow = wk0 + l31;
   const bool kvalid = kvrow < T;
 
-  bf16x8_t kreg[KSTEPS], vreg[KSTEPS];
-  {
-    const size_t off = (((size_t)b * T + (kvalid ? kvrow : 0)) * Nkv + hk) * D + 8 * hi;
+  // ---- round trip A: the stored list of query tiles, the id statistics of the four waves' rows, this lane's id, and the
+  // wave's K / V rows — issued together
+  const bool plain = qv.nseg == 1 && qv.off[0] == 0 && qv.row0[0] == 0;     // (this pass is causal)
+  i32x4_t ql_head = {kListPre + 1, 0, 0, 0}, ql_mine = {0, 0, 0, 0};
+  if (plain) {
+    const i32x4_t* ql = reinterpret_cast<const i32x4_t*>(meta.qlist) + ((size_t)b * meta.nq128 + kt) * (1 + kListPre);
+    ql_head = ql[0];
+    if (tid < kListPre) ql_mine = ql[1 + tid];
+  }
+  i32x4_t ws4[4];                             // {min positive id, max id, pad present, -} of every wave's 32 kv rows
 #pragma unroll
-    for (int s = 0; s < KSTEPS; ++s) {
-      uint4 a = make_uint4(0, 0, 0, 0), c = make_uint4(0, 0, 0, 0);
-      if (kvalid) {
-        a = *reinterpret_cast<const uint4*>(K + off + 16 * s);
-        c = *reinterpret_cast<const uint4*>(V + off + 16 * s);
-      }
-      kreg[s] = as_bf16x8(a);
-      vreg[s] = as_bf16x8(c);
-    }
+  for (int w = 0; w < 4; ++w) {
+    ws4[w] = i32x4_t{0x7fffffff, 0, 1, 0};
+    if (k0 + 32 * w < T) ws4[w] = reinterpret_cast<const i32x4_t*>(meta.qstat)[(size_t)b * meta.nq32 + (k0 + 32 * w) / 32];
   }
   const int dkdoc = kvalid ? doc[(size_t)b * T + kvrow] : 0;
+  {
+    const size_t krow_elems = (size_t)Nkv * D;
+    const uint32_t k_bytes = (uint32_t)min((size_t)T * krow_elems * 2, (size_t)0x7fffffff);
+    const __amdgpu_buffer_rsrc_t rk =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(K + (size_t)b * T * krow_elems), 0, k_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(V + (size_t)b * T * krow_elems), 0, k_bytes, 0x00020000);
+    const int rrk = lane >> 2;
+    const uint32_t voffk = (uint32_t)(((size_t)rrk * krow_elems + 8 * ((lane & 3) ^ ((rrk >> 2) & 3))) * 2);
+    char* kpriv = smem + wave * (2 * KIMGB);    // {K image | V image} of this wave's 32 rows
+#pragma unroll
+    for (int pc = 0; pc < KTile::NP * 2; ++pc) {
+      const int panel = pc % KTile::NP, rh = pc / KTile::NP;
+      const uint32_t vo = (wk0 + 16 * rh + rrk < T) ? voffk : 0x80000000u;
+      const uint32_t so = (uint32_t)((((size_t)wk0 + 16 * rh) * krow_elems + (size_t)hk * D + 32 * panel) * 2);
+      char* dst = kpriv + panel * (KTile::PSTRIDE * 2) + rh * 1024;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (lds_ptr_t)dst, 16, vo, so, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lds_ptr_t)(dst + KIMGB), 16, vo, so, 0, 0);
+    }
+  }
+  wait_vmcnt<0>();
+  asm volatile("" ::"v"(dkdoc));               // (hipcc's own wait for this load must sit HERE, not inside the stage loop)
+  bf16x8_t kreg[KSTEPS], vreg[KSTEPS];
+  {
+    const PRowReader<32, D> krd(l31, hi);
+    const bf16_t* ki = reinterpret_cast<const bf16_t*>(smem + wave * (2 * KIMGB));
+#pragma unroll
+    for (int s2 = 0; s2 < KSTEPS; ++s2) {
+      kreg[s2] = krd.operand(ki, 0, s2);
+      vreg[s2] = krd.operand(ki + KTile::SIZE, 0, s2);
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < KSTEPS; ++s2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kreg[s2]), "+v"(vreg[s2]));
+  }
+  const int n_pre = __builtin_amdgcn_readfirstlane(ql_head.x);
+  const bool pre = n_pre <= kListPre;          // the stored list is complete: use it
+  if (pre && tid < n_pre) qent[tid] = ql_mine;
+  // everybody has read its private images (the ring area is free) and the list is in LDS
+  __syncthreads();
 
   const int* m_min = meta.tmin + (size_t)b * meta.nt;
   const int* m_max = meta.tmax + (size_t)b * meta.nt;
   const int* m_minpos = meta.tminpos + (size_t)b * meta.nt;
   const int qt_lo = k0 / kTile;                               // first 64-position query tile (q >= kv), global index
   const int t0 = 2 * kt, t1 = min(2 * kt + 1, meta.nt - 1);
-  const int bminpos = min(m_minpos[t0], m_minpos[t1]);
-  const int bmax = max(m_max[t0], m_max[t1]);
-  const int qhi64 = max(meta.kv_hi[(size_t)b * meta.nt + t0], meta.kv_hi[(size_t)b * meta.nt + t1]);
-  const int qt_end = min(qhi64 + 1, meta.nt);                 // exclusive
-  int wminpos, wmax;
-  wave_id_range(dkdoc, wminpos, wmax);
-  const bool w_uniform = (wminpos == wmax) && !__any(dkdoc == 0);   // all 32 kv rows in one document
+  int bminpos = 0, bmax = 0, qt_end = 0;
+  if (!pre) {
+    bminpos = min(m_minpos[t0], m_minpos[t1]);
+    bmax = max(m_max[t0], m_max[t1]);
+    const int qhi64 = max(meta.kv_hi[(size_t)b * meta.nt + t0], meta.kv_hi[(size_t)b * meta.nt + t1]);
+    qt_end = min(qhi64 + 1, meta.nt);                         // exclusive
+  }
+  const int4 wsc = scalarize(ws4[0]);
+  const int4 wsc1 = scalarize(ws4[1]), wsc2 = scalarize(ws4[2]), wsc3 = scalarize(ws4[3]);
+  const int4 wsw[4] = {wsc, wsc1, wsc2, wsc3};
   int seg_lo[2], seg_n[2];
 #pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    const int first = qv.off[s] / kTile, cnt = qv.tiles(s, kTile);
-    seg_lo[s] = max(qt_lo, first);
-    seg_n[s] = max(min(qt_end, first + cnt) - seg_lo[s], 0);
+  for (int s2 = 0; s2 < 2; ++s2) {
+    const int first = qv.off[s2] / kTile, cnt = qv.tiles(s2, kTile);
+    seg_lo[s2] = max(qt_lo, first);
+    seg_n[s2] = max(min(qt_end, first + cnt) - seg_lo[s2], 0);
   }
-  const int nqt = seg_n[0] + seg_n[1];
+  const int nqt = pre ? n_pre : seg_n[0] + seg_n[1];
   const int per_head = SPT * nqt, total_c = per_head * G;
-  // what the list builder needs to know about every wave's 32 kv rows
-  if (lane == 0) wstat[wave] = i32x4_t{wminpos, wmax, w_uniform ? 1 : 0, 0};
-  __syncthreads();                      // (the builder reads ALL four waves' entries: without this barrier a wave that runs
-                                        //  ahead read stale LDS and dropped / mis-masked stages of a slower wave — seen as
-                                        //  one irreproducible dK / dV in some hundred launches, scripts/r04_determinism2.py)
   auto build_list = [&](int cb) {       // candidates [cb, cb + LCAP) -> n entries (+ NST + 1 empty ones behind them)
     const int c = cb + tid;
     QStage d = {0, 0, 0, 0};
@@ -249,12 +297,21 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kv_fused_kernel(
     if (c < total_c) {
       const int g = c / per_head, r = c - g * per_head;
       const int idx = r / SPT, part = r % SPT;
-      const int sg = idx >= seg_n[0] ? 1 : 0;
-      const int t64 = seg_lo[sg] + idx - (sg ? seg_n[0] : 0);
-      const int lt = t64 - qv.off[sg] / kTile;
-      const int left = min(min(qv.rows[sg] - lt * kTile, T - t64 * kTile) - BQ * part, BQ);
-      const int mp = m_minpos[t64], mx = m_max[t64], mn = m_min[t64];
-      valid = left > 0 && tile_may_interact(mp, mx, bminpos, bmax);
+      int sg = 0, t64, lt, left, mp, mx, mn;
+      if (pre) {                                  // (plain launch: local row = global position)
+        const i32x4_t qe = qent[idx];
+        t64 = qe.x; mn = qe.y; mx = qe.z; mp = qe.w;
+        lt = t64;
+        left = min(T - t64 * kTile - BQ * part, BQ);
+        valid = left > 0;
+      } else {
+        sg = idx >= seg_n[0] ? 1 : 0;
+        t64 = seg_lo[sg] + idx - (sg ? seg_n[0] : 0);
+        lt = t64 - qv.off[sg] / kTile;
+        left = min(min(qv.rows[sg] - lt * kTile, T - t64 * kTile) - BQ * part, BQ);
+        mp = m_minpos[t64]; mx = m_max[t64]; mn = m_min[t64];
+        valid = left > 0 && tile_may_interact(mp, mx, bminpos, bmax);
+      }
       const int lrow = qv.row0[sg] + lt * kTile + BQ * part, h = hk * G + g;
       d.qsb = t64 * kTile + BQ * part;
       d.base = (int)(((size_t)lrow * Nh + h) * D * 2);
@@ -262,10 +319,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kv_fused_kernel(
       int flags = 0;
 #pragma unroll
       for (int w = 0; w < 4; ++w) {             // (same rules as attn_bwd.hip's per-wave tests, evaluated once per stage)
-        const i32x4_t ws = wstat[w];
+        const int4 ws = wsw[w];
         const int w0 = k0 + 32 * w;
+        const bool w_uni = ws.x == ws.y && ws.z == 0;             // all 32 kv rows of wave w in one document
         const bool act = d.qsb + BQ - 1 >= w0 && tile_may_interact(mp, mx, ws.x, ws.y);
-        const bool q_uniform = ws.z != 0 && mn == mx && mx == ws.y && left == BQ;
+        const bool q_uniform = w_uni && mn == mx && mx == ws.y && left == BQ;
         const bool msk = !(q_uniform && d.qsb >= w0 + 31);
         flags |= (act ? 1 << (8 + w) : 0) | (msk ? 1 << (12 + w) : 0);
       }
@@ -613,21 +671,38 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kv_fused_kernel(
   }
 
   asm volatile("s_nop 15\n\ts_nop 15");     // the last MFMAs have written their accumulators
-  if (kvalid) {
-    const size_t off = (((size_t)b * T + kvrow) * Nkv + hk) * D;
+  // ---- epilogue: the ring is quiet behind the last chunk's barrier; each wave writes its 32 x D blocks of dV and dK
+  // (8-byte runs of the accumulator layout) into private images and reads them back as whole rows — 16-byte stores, four
+  // rows per instruction, instead of 8 bytes per lane at a row stride (attn_fwd_stream.hip)
+  {
+    char* obv = smem + wave * (2 * 32 * OSTR);
+    char* obk = obv + 32 * OSTR;
     static_for<DBLK>([&](auto DB) {
       constexpr int db = decltype(DB)::value;
       static_for<4>([&](auto R4) {
         constexpr int r4 = decltype(R4)::value;
-        uint2 o;
+        u32x2_t o;
         o.x = pack2bf(acc_read<16 * db + 4 * r4 + 0>(), acc_read<16 * db + 4 * r4 + 1>());
         o.y = pack2bf(acc_read<16 * db + 4 * r4 + 2>(), acc_read<16 * db + 4 * r4 + 3>());
-        *reinterpret_cast<uint2*>(dV + off + 32 * db + 8 * r4 + 4 * hi) = o;
+        *reinterpret_cast<u32x2_t*>(obv + l31 * OSTR + (32 * db + 8 * r4 + 4 * hi) * 2) = o;
         o.x = pack2bf(acc_read<64 + 16 * db + 4 * r4 + 0>() * scale, acc_read<64 + 16 * db + 4 * r4 + 1>() * scale);
         o.y = pack2bf(acc_read<64 + 16 * db + 4 * r4 + 2>() * scale, acc_read<64 + 16 * db + 4 * r4 + 3>() * scale);
-        *reinterpret_cast<uint2*>(dK + off + 32 * db + 8 * r4 + 4 * hi) = o;
+        *reinterpret_cast<u32x2_t*>(obk + l31 * OSTR + (32 * db + 8 * r4 + 4 * hi) * 2) = o;
       });
     });
+    constexpr int CPR = D / 8, RPI = 64 / CPR;           // 16-byte chunks per row, rows per store instruction
+    const int cc = lane % CPR, r0 = lane / CPR;
+    const size_t off = (((size_t)b * T + wk0) * Nkv + hk) * D + cc * 8;
+#pragma unroll
+    for (int i = 0; i < 32 / RPI; ++i) {
+      const int row = i * RPI + r0;
+      const u32x4_t v4 = *reinterpret_cast<const u32x4_t*>(obv + row * OSTR + cc * 16);
+      const u32x4_t k4 = *reinterpret_cast<const u32x4_t*>(obk + row * OSTR + cc * 16);
+      if (wk0 + row < T) {
+        *reinterpret_cast<u32x4_t*>(dV + off + (size_t)row * Nkv * D) = v4;
+        *reinterpret_cast<u32x4_t*>(dK + off + (size_t)row * Nkv * D) = k4;
+      }
+    }
   }
 }
 

@@ -65,6 +65,9 @@ constexpr int kTile = 64;  // granularity of the document-range metadata
 //                        balances better — a scheduling model says 0.92 -> 0.97 of the CU slots busy — but neighbouring
 //                        query tiles no longer run side by side, their shared K / V tiles fall out of the XCD's L2 and
 //                        the wait for a tile grows by 40 %: 233 -> 242 us, profiles/r06a_*.)
+//   qlist [B, nq128, 4 + 4 * kListPre]   the mirror image for the dK / dV pass: the 64-position QUERY tiles a 128-position
+//                        KV tile meets under the causal mask, {count, kv tile, 0, 0} + entries {q tile, min id, max id,
+//                        min positive id}
 constexpr int kListPre = 64;
 struct AttnMeta {
   const int* tmin;
@@ -76,15 +79,17 @@ struct AttnMeta {
   const int* qstat;
   const int* klist;
   int nq32, nq128;
+  const int* qlist;
 };
 __host__ inline int attn_meta_ints(int B, int T) {
   const int nt = (T + kTile - 1) / kTile, nq32 = (T + 31) / 32, nq128 = (T + 127) / 128;
-  return 5 * B * nt + 4 * B * nq32 + (4 + 4 * kListPre) * B * nq128;
+  return 5 * B * nt + 4 * B * nq32 + 2 * (4 + 4 * kListPre) * B * nq128;
 }
 __host__ inline AttnMeta make_attn_meta(const int* meta, int B, int T) {
   const int nt = (T + kTile - 1) / kTile, n = B * nt, nq32 = (T + 31) / 32, nq128 = (T + 127) / 128;
   return AttnMeta{meta, meta + n, meta + 2 * n, meta + 3 * n, meta + 4 * n, nt,
-                  meta + 5 * n, meta + 5 * n + 4 * B * nq32, nq32, nq128};
+                  meta + 5 * n, meta + 5 * n + 4 * B * nq32, nq32, nq128,
+                  meta + 5 * n + 4 * B * nq32 + (4 + 4 * kListPre) * B * nq128};
 }
 
 // Which rows of the (possibly sequence-sharded) query-side buffers a launch covers.  Q / O / dO / dQ are

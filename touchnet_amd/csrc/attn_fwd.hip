@@ -115,6 +115,32 @@ __global__ void attn_meta_klist_kernel(const int* __restrict__ tmin, const int* 
   if (lane == 0) out[0] = make_int4(count, qt, 0, 0);
 }
 
+// Per 128-position KV tile: the 64-position query tiles it meets under the causal mask (attn_common.h qlist) — what the
+// dK / dV workgroups derive for themselves in attn_bwd.hip (first tile = the diagonal, last = kv_hi of its two halves).
+__global__ void attn_meta_qlist_kernel(const int* __restrict__ tmin, const int* __restrict__ tmax,
+                                       const int* __restrict__ tminpos, const int* __restrict__ kv_hi,
+                                       int* __restrict__ qlist, int B, int nt, int nq128) {
+  const int kt = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+  const int* mn = tmin + (size_t)b * nt;
+  const int* mx = tmax + (size_t)b * nt;
+  const int* mp = tminpos + (size_t)b * nt;
+  const int t0 = 2 * kt, t1 = min(2 * kt + 1, nt - 1);
+  const int bminpos = min(mp[t0], mp[t1]), bmax = max(mx[t0], mx[t1]);
+  const int qt_end = min(max(kv_hi[(size_t)b * nt + t0], kv_hi[(size_t)b * nt + t1]) + 1, nt);      // exclusive
+  int4* out = reinterpret_cast<int4*>(qlist + ((size_t)b * nq128 + kt) * (4 + 4 * kListPre));
+  int count = 0;
+  for (int base = t0; base < qt_end; base += 64) {
+    const int t = base + lane;
+    const int tc = t < qt_end ? t : t0;
+    const bool ok = t < qt_end && tile_may_interact(mp[tc], mx[tc], bminpos, bmax);
+    const unsigned long long bal = __ballot(ok);
+    const int pos = count + __popcll(bal & ((1ull << lane) - 1ull));
+    if (ok && pos < kListPre) out[1 + pos] = make_int4(t, mn[t], mx[t], mp[t]);
+    count += __popcll(bal);
+  }
+  if (lane == 0) out[0] = make_int4(count, kt, 0, 0);
+}
+
 // ------------------------------------------------------------------------------------------------
 // ABL (ablation, timing experiments only — results are wrong for ABL != 0; reached through tn_attn_fwd_ablate):
 //   1 no in-loop global loads / LDS stores   2 no softmax VALU   3 no P.V MFMAs   4 no QK^T MFMAs   5 no barrier
@@ -448,6 +474,9 @@ int tn_attn_build_meta(const int* doc, int* meta, int B, int T, void* stream) {
   TN_LAUNCH_CHECK();
   hipLaunchKernelGGL(attn_meta_klist_kernel, dim3(m.nq128, B), dim3(64), 0, st, m.tmin, m.tmax, m.tminpos, m.q_lo,
                      const_cast<int*>(m.klist), B, nt, m.nq128);
+  TN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(attn_meta_qlist_kernel, dim3(m.nq128, B), dim3(64), 0, st, m.tmin, m.tmax, m.tminpos, m.kv_hi,
+                     const_cast<int*>(m.qlist), B, nt, m.nq128);
   TN_LAUNCH_CHECK();
   return TN_OK;
 }

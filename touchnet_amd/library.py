@@ -420,7 +420,7 @@ def attn_build_meta(doc: Tensor) -> Tensor:
 def _(doc):
     B, T = doc.shape
     # (tn_attn_meta_ints: tile statistics + per-wave statistics + precomputed KV-tile lists, csrc/attn_common.h)
-    return doc.new_empty(5 * B * ((T + 63) // 64) + 4 * B * ((T + 31) // 32) + 260 * B * ((T + 127) // 128),
+    return doc.new_empty(5 * B * ((T + 63) // 64) + 4 * B * ((T + 31) // 32) + 520 * B * ((T + 127) // 128),
                          dtype=torch.int32)
 
 
