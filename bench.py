@@ -87,6 +87,20 @@ def kimi_audio_7b_config(use_whisper_feature: bool = False):
         "kimia_mimo_transformer_from_layer_index": 21, "kimia_token_offset": 152064})
 
 
+# BASELINE.json configs: C = Qwen2-Audio-7B FSDP2 dp 8; D = long audio, CP 4 x dp 2; E = Kimi-Audio-7B, TP 2 x dp 4
+RECIPES = {"qwen2_audio_7b_long": {"cp": 4}, "kimi_audio_7b": {"tp": 2}, "kimi_audio_7b_speech": {"tp": 2}}
+
+
+def recipe_degrees(workload: str, gpus: int, cp, tp, emulate_rank=None):
+    """`python bench.py --gpus N --workload W` without --cp / --tp runs W's BASELINE recipe: the degree the config names
+    when N is a multiple of it (8 GPUs: long audio = cp 4 x dp 2, Kimi = tp 2 x dp 4, everything else dp 8), 1 otherwise
+    (and always 1 on one GPU).  An explicit flag always wins."""
+    rec = RECIPES.get(workload, {})
+    pick = lambda given, key: given if given is not None else (
+        rec[key] if (key in rec and emulate_rank is None and gpus > 1 and gpus % rec[key] == 0) else 1)
+    return pick(cp, "cp"), pick(tp, "tp")
+
+
 def parallel_layout(world: int, cp: int = 1, tp: int = 1, emulate_rank=None) -> dict:
     """How `--gpus / --cp / --tp / --emulate-rank` split the job: dp x cp x tp real ranks, or ONE process playing rank
     `emulate_rank` of a cp- or tp-way group."""
@@ -534,8 +548,11 @@ def main():
     ap.add_argument("--linear-gemm", choices=("lib", "own"), default=None,
                     help="own (default) = the linear layers' GEMMs on the hand-written MFMA kernel (csrc/gemm.hip) in its "
                          "native operand modes; lib = hipBLASLt on transposed copies (A/B runs; TN_LINEAR_GEMM)")
-    ap.add_argument("--cp", type=int, default=1, help="context-parallel degree (ranks split as dp x cp x tp)")
-    ap.add_argument("--tp", type=int, default=1, help="tensor-parallel degree")
+    ap.add_argument("--cp", type=int, default=None,
+                    help="context-parallel degree (ranks split as dp x cp x tp); default: the workload's BASELINE recipe "
+                         "when --gpus allows it (qwen2_audio_7b_long: cp 4), else 1")
+    ap.add_argument("--tp", type=int, default=None,
+                    help="tensor-parallel degree; default: the workload's BASELINE recipe (kimi_audio_7b*: tp 2), else 1")
     ap.add_argument("--emulate-rank", type=int, default=None,
                     help="with --gpus 1 and --cp N or --tp N: run rank r of the N-way group alone on one GPU")
     ap.add_argument("--ac", choices=("none", "full", "selective", "op"), default="none",
@@ -555,6 +572,7 @@ def main():
                     help="data parallelism for N > 1: flat (default) = utils/zero_dp.py, flat per-block buffers + sharded "
                          "optimizer state; fsdp2 = torch fully_shard as the reference applies it (TN_DP_ENGINE)")
     args = ap.parse_args()
+    args.cp, args.tp = recipe_degrees(args.workload, args.gpus, args.cp, args.tp, args.emulate_rank)
     layout = parallel_layout(args.gpus, args.cp, args.tp, args.emulate_rank)
     self_launch(args.gpus)
     if args.linear_gemm:
@@ -669,6 +687,20 @@ def main():
     nonpad = int((wl.tokens["attention_mask"] > 0).sum()) if hasattr(wl, "tokens") else None
     lrm = None if args.all_rows_lm_head else wl.make_batch().get("labelled_rows_max")     # what the packer told the model
     loss = float(stats["loss_per_sample"])
+    # what the job really ran on: read from the LIVE process group, with a one-element all-reduce over every rank (a
+    # SCALE line can then be checked without trusting the command line: backend nccl == RCCL on ROCm, N ranks answered)
+    dist_info = {"initialized": bool(dist.is_available() and dist.is_initialized())}
+    if dist_info["initialized"]:
+        ones = torch.ones(1, dtype=torch.float32, device=device)
+        dist.all_reduce(ones)
+        dist_info.update(backend=str(dist.get_backend()), world_size=int(dist.get_world_size()),
+                         ranks_answering_all_reduce=int(round(float(ones))),
+                         devices_visible=int(torch.cuda.device_count()))
+    try:
+        v = torch.cuda.nccl.version()
+        dist_info["rccl_version"] = ".".join(str(x) for x in v) if isinstance(v, tuple) else str(v)
+    except Exception:                                # (never lose the headline number to a diagnostics failure)
+        dist_info["rccl_version"] = None
     if rank == 0:
         line = {
             "metric": "audio+text tokens/sec/node (packed seq, full train step) + step MFU",
@@ -715,6 +747,11 @@ def main():
                               "discount, no recompute credit, tokens = all B*T slots incl. pad (the reference's tps counts "
                               "them, train.py:345) — `roofline.frac` counts only the FLOPs that are executed",
             "nonpad_tokens_per_step_rank0": nonpad,
+            # the decoder drops the padding slots (config.decoder_rows); `value` follows the reference's convention and
+            # counts them: the same job in slots that carry a token (rank 0's count x data-parallel ranks), ADVICE r5
+            "nonpad_tokens_per_s": (round(nonpad * layout["dp"] / (share if emu else 1) * args.steps / elapsed, 1)
+                                    if nonpad is not None else None),
+            "dist": dist_info,
             "loss_per_sample_last": round(loss, 5), "hip_event_ms_per_step_rank0": round(ev_ms, 2),
             "peak_mem_GB_rank0": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
             **({"emulated_state_shards": args.emulate_shards} if args.emulate_shards > 1 else {}),

@@ -14,11 +14,14 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _launch(extra, n=2):
+def _launch(extra, n=2, backend="gloo"):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    env = dict(os.environ, TN_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("TN_DIST_BACKEND", None)
+    if backend == "gloo":
+        env["TN_DIST_BACKEND"] = "gloo"
     env.pop("TN_FORCE_FSDP", None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1",
@@ -40,10 +43,51 @@ def test_bench_two_ranks_on_one_gpu(extra, label):
     assert line["value"] > 0 and line["ms_per_step"] > 0 and line["loss_per_sample_last"] == line["loss_per_sample_last"]
     if label is not None:
         assert label in line["config"]["parallelism"], line["config"]["parallelism"]
+    # the line says what it ran on, read from the live process group
+    d = line["dist"]
+    assert d["initialized"] and d["backend"] == "gloo" and d["world_size"] == 2 and d["ranks_answering_all_reduce"] == 2
     # whole-job tokens: dp ranks each bring B x T, cp / tp peers share one batch
     per_rank = 1 * 512
     dp = 2 if not extra else 1
     assert abs(line["value"] * line["ms_per_step"] / 1e3 - per_rank * dp) / (per_rank * dp) < 0.02
+
+
+def _one_gpu_loss():
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "TN_FORCE_FSDP", "TN_DIST_BACKEND"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+           "--workload", "tiny", "--no-cpu-baseline", "--no-kernel-rooflines"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{") and '"metric"' in l][0])
+    return line["loss_per_sample_last"]
+
+
+def _devices():
+    import torch
+    return torch.cuda.device_count()
+
+
+@pytest.mark.skipif(_devices() < 2, reason="needs two MI355X: one RCCL rank per device (the driver's multi-GPU node)")
+def test_bench_two_ranks_over_rccl_on_two_gpus():
+    """The same four layouts over REAL RCCL, one rank per device (collected everywhere, runs where two GPUs are visible — the
+    driver's scaling node): the line must say backend nccl (= RCCL on ROCm), world size 2 and two ranks answering an
+    all-reduce; context- and tensor-parallel ranks work on ONE batch, so their loss is the one-GPU run's (bf16 summation
+    order apart); the two data-parallel engines see the same two batches and must agree with each other.  Reference
+    layouts: touchnet/models/helper_func.py:134-202 (FSDP2), touchnet/utils/distributed.py:292-315 (CP),
+    touchnet/models/llama/parallelize_llama.py:105-196 (TP)."""
+    one = _one_gpu_loss()
+    got = {}
+    for extra in ([], ["--dp-engine", "fsdp2"], ["--cp", "2"], ["--tp", "2"]):
+        line = _launch(extra, backend="nccl")
+        d = line["dist"]
+        assert d["backend"] == "nccl" and d["world_size"] == 2 and d["ranks_answering_all_reduce"] == 2, d
+        assert d["devices_visible"] >= 2 and d["rccl_version"], d
+        got[" ".join(extra) or "flat"] = line["loss_per_sample_last"]
+    for k in ("--cp 2", "--tp 2"):
+        assert abs(got[k] - one) / abs(one) < 2e-2, (k, got, one)
+    assert abs(got["flat"] - got["--dp-engine fsdp2"]) / abs(got["flat"]) < 2e-2, got
 
 
 def test_plain_command_line_launches_its_own_ranks():

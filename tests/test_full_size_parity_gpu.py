@@ -1,0 +1,142 @@
+"""Full-size parity guard: the decoder at the HEADLINE's size — Qwen2-Audio-7B's decoder widths
+(hidden 4096, 32 heads x 128, MLP 11008, q / k / v biases), the bench's own packed batch (B x T = 2 x 8192, ~790-token ASR
+samples from data/synthetic.qwen2_audio_plan, padding slots dropped -> M = 15872 rows, lm_head on the labelled rows) — which no
+other test reaches (the per-kernel tests stop at M = 8200, the 7B-shape cases at M <= 2048).
+
+(i)  two layers, every fusion of the product path on (SwiGLU / RoPE epilogues, grouped MLP weight gradients, bias gradients
+     from the weight-gradient launches, hand-written GEMM, padding slots dropped, last layer on the labelled rows) against
+     the UNFUSED composition of the same step on hipBLASLt (`LINEAR_GEMM = "lib"`, every switch off, all slots computed):
+     loss, gradient norm and sampled weight gradients at bf16 tolerance;
+(ii) one layer's forward against oracle/nn.py in fp32 on the host — the reference's maths
+     (transformers' Qwen2DecoderLayer as restated in oracle/nn.py:107-120; loss: touchnet/loss/cross_entropy.py:12-50 as
+     restated in oracle/loss.py), document by document (the document mask is block diagonal, so a document's rows depend on
+     nothing outside it: the [T, T] score matrix of the whole row would take 17 GB) — with north_star's 1e-3 bound on the
+     loss and a bf16 bound on the hidden states."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+B, T, V = 2, 8192, 8192            # (a small vocabulary: the lm_head / CE kernels have their own full-size tests)
+
+
+def _config(layers):
+    from touchnet_amd.models.llama import DecoderConfig
+    return DecoderConfig.from_dict(dict(
+        model_type="qwen2", hidden_size=4096, intermediate_size=11008, num_attention_heads=32, num_key_value_heads=32,
+        head_dim=128, num_hidden_layers=layers, vocab_size=V, rms_norm_eps=1e-6, rope_theta=1000000.0,
+        tie_word_embeddings=False, initializer_range=0.02, attention_bias=True))
+
+
+def _batch():
+    from touchnet_amd.data.synthetic import qwen2_audio_plan
+    tok, _ = qwen2_audio_plan(V, V - 1, B, T, seed=2025)
+    ids = tok["input_ids"].clone()
+    g = torch.Generator().manual_seed(7)
+    audio = ids == V - 1                                   # (decoder only: the AUDIO slots get ordinary token ids)
+    ids[audio] = torch.randint(3, V - 2000, (int(audio.sum()),), generator=g)
+    return dict(tok, input_ids=ids)
+
+
+def _model(layers, seed=0):
+    from touchnet_amd.models.llama import PackedCausalLM
+    torch.manual_seed(seed)
+    m = PackedCausalLM(_config(layers))
+    m.post_init()
+    g = torch.Generator().manual_seed(seed + 1)
+    for n, p in m.named_parameters():                      # (biases and norm weights away from their trivial init)
+        if n.endswith(".bias"):
+            p.data.normal_(0.0, 0.02, generator=g)
+        elif "norm" in n:
+            p.data.add_(torch.randn(p.shape, generator=g) * 0.05)
+    return m.to(torch.bfloat16)
+
+
+def _step(m, tok, fused):
+    d = {k: (v.to(DEV) if isinstance(v, torch.Tensor) else v) for k, v in tok.items()}
+    kw = dict(input_ids=d["input_ids"], position_ids=d["position_ids"], attention_mask=d["attention_mask"],
+              labels=d["labels"], sentence_lens=d["sentence_lens"], num_sentence=d["num_sentence"])
+    if fused:
+        kw.update(labelled_rows_max=tok["labelled_rows_max"], valid_rows_max=tok["valid_rows_max"])
+    for p in m.parameters():
+        p.grad = None
+    out = m(**kw)
+    out.loss.backward()
+    torch.cuda.synchronize()
+    gn = torch.sqrt(sum((p.grad.float() ** 2).sum() for p in m.parameters() if p.grad is not None))
+    return float(out.loss), float(gn)
+
+
+def test_two_layers_at_headline_size_fused_path_equals_the_unfused_library_path(monkeypatch):
+    import touchnet_amd.functional as F
+    import touchnet_amd.models.llama.modeling_llama as ML
+    tok = _batch()
+    assert tok["valid_rows_max"] > 15000 and (tok["valid_rows_max"] + 255) // 256 * 256 == 15872      # the headline's M
+    m = _model(2).to(DEV)
+    loss_f, gn_f = _step(m, tok, fused=True)
+    names = ["model.layers.0.self_attn.k_proj.weight", "model.layers.1.mlp.down_proj.weight",
+             "model.layers.0.mlp.gate_proj.weight", "model.layers.1.self_attn.q_proj.bias", "model.layers.0.input_layernorm.weight"]
+    params = dict(m.named_parameters())
+    got = {n: params[n].grad.float().clone() for n in names}
+    # the unfused arm: hipBLASLt GEMMs on transposed copies, separate RoPE / SwiGLU / column-sum kernels, one weight gradient
+    # per launch, every padding slot and every position through every layer
+    for name, val in (("LINEAR_GEMM", "lib"), ("ROPE_EPILOGUE", False), ("MLP_EPILOGUE", False), ("GROUPED_WGRAD", False),
+                      ("BIAS_IN_WGRAD", False), ("_MLP_FUSED", False), ("SPLIT_K", False)):
+        monkeypatch.setattr(F, name, val)
+    monkeypatch.setattr(ML, "SKIP_PAD_ROWS", False)
+    monkeypatch.setattr(ML, "LAST_LAYER_LABELLED_ROWS", False)
+    loss_u, gn_u = _step(m, tok, fused=False)
+    print(f"FULL-SIZE PARITY fused loss {loss_f:.6f} / unfused {loss_u:.6f}; grad norm {gn_f:.5f} / {gn_u:.5f}")
+    assert abs(loss_f - loss_u) / abs(loss_u) < 1e-3, (loss_f, loss_u)
+    assert abs(gn_f - gn_u) / gn_u < 5e-3, (gn_f, gn_u)
+    for n in names:
+        ref = params[n].grad.float()
+        err = float((got[n] - ref).abs().max()) / max(float(ref.abs().max()), 1e-12)
+        print(f"FULL-SIZE PARITY grad {n}: {err:.2e} of its scale")
+        assert err < 3e-2, (n, err)
+
+
+def test_one_layer_forward_at_headline_size_against_the_oracle_on_the_host():
+    import oracle.loss as oloss
+    import oracle.nn as onn
+    tok = _batch()
+    m = _model(1, seed=3)
+    sd = {k: v.detach().float() for k, v in m.state_dict().items()}
+    cfg = dict(num_attention_heads=32, num_key_value_heads=32, head_dim=128, rms_norm_eps=1e-6, rope_theta=1000000.0,
+               num_hidden_layers=1)
+    m = m.to(DEV)
+    d = {k: (v.to(DEV) if isinstance(v, torch.Tensor) else v) for k, v in tok.items()}
+    with torch.no_grad():
+        hid = m.model(input_ids=d["input_ids"], position_ids=d["position_ids"], attention_mask=d["attention_mask"])
+        out = m(input_ids=d["input_ids"], position_ids=d["position_ids"], attention_mask=d["attention_mask"],
+                labels=d["labels"], sentence_lens=d["sentence_lens"], num_sentence=d["num_sentence"],
+                labelled_rows_max=tok["labelled_rows_max"], valid_rows_max=tok["valid_rows_max"])
+    torch.cuda.synchronize()
+    hid = hid.float().cpu()
+    # ---- the oracle, document by document (fp32, host cores)
+    doc = tok["attention_mask"]
+    emb = torch.nn.functional.embedding(tok["input_ids"], sd["model.embed_tokens.weight"])
+    inv = onn.rope_inv_freq(128, 1000000.0)
+    ref = torch.zeros(B, T, 4096)
+    for b in range(B):
+        ids = doc[b].numpy()
+        for dnum in np.unique(ids[ids > 0]):
+            cols = np.nonzero(ids == dnum)[0]
+            lo, hi = int(cols[0]), int(cols[-1]) + 1
+            assert hi - lo == cols.size                      # (a document's slots are contiguous)
+            cos, sin = onn.rope_cos_sin(tok["position_ids"][b:b + 1, lo:hi], inv, torch.float32)
+            h = onn.decoder_layer(sd, "model.layers.0.", cfg, emb[b:b + 1, lo:hi], cos, sin, None)
+            ref[b, lo:hi] = onn.rms_norm(h, sd["model.norm.weight"], 1e-6)[0]
+    valid = doc > 0
+    err = float((hid - ref)[valid].abs().max()) / float(ref[valid].abs().max())
+    rows = tok["labels"] != -100
+    logits = torch.nn.functional.linear(ref[rows], sd["lm_head.weight"])          # labelled rows only: ~600 x 8192
+    lab = torch.full((1, int(rows.sum())), 0, dtype=torch.int64)
+    lab[0] = tok["labels"][rows]
+    ps, pt = oloss.cross_entropy_loss(logits[None], lab, tok["sentence_lens"][rows][None], int(tok["num_sentence"]))
+    rel = abs(float(out.loss) - float(ps)) / abs(float(ps))
+    print(f"FULL-SIZE PARITY one layer vs oracle: hidden states {err:.2e} of scale, loss {float(out.loss):.6f} vs "
+          f"{float(ps):.6f} (rel {rel:.1e})")
+    assert err < 2e-2, err
+    assert rel < 1e-3, (float(out.loss), float(ps))

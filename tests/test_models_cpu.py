@@ -227,6 +227,17 @@ def test_hf_attention_interface_drives_transformers_llama():
         out, w = hf_attention.packed_attention_forward(None, qh, kh, vh, attention_mask=docs, scaling=0.25)
     assert w is None and out.shape == (2, 48, 4, 16) and out.is_contiguous()
     assert torch.equal(hf_attention.documents_from_positions(pos)[0, :45], docs[0, :45].to(torch.int32))
+    # the tile metadata is built ONCE per forward and shared by the layers, also for TouchNet's int64 document-id mask
+    # (the key is the caller's tensor, not the int32 copy made per call); an in-place edit of the mask is seen
+    docs64 = docs.to(torch.int64).clone()
+    with use_ops(oops):
+        before = hf_attention._cache.get("builds", 0)
+        for _ in range(3):
+            hf_attention.packed_attention_forward(None, qh, kh, vh, attention_mask=docs64, scaling=0.25)
+        assert hf_attention._cache["builds"] == before + 1
+        docs64[0, 0] = 7
+        hf_attention.packed_attention_forward(None, qh, kh, vh, attention_mask=docs64, scaling=0.25)
+        assert hf_attention._cache["builds"] == before + 2
     with pytest.raises(NotImplementedError):
         hf_attention.packed_attention_forward(None, qh, kh, vh, dropout=0.1)
 
@@ -506,3 +517,20 @@ def test_op_level_ac_is_a_noop_under_sequence_parallelism_and_mismatched_norm_so
     assert F._norm_src_describes(F.norm_source(x_full, torch.ones(64), 1e-6), x_full)
     assert not F._norm_src_describes(None, x_full)
     assert not F._norm_src_describes(F.norm_source(x_full.double(), torch.ones(64), 1e-6), x_full)
+
+
+def test_rope_frequencies_stay_float32_when_the_model_is_cast():
+    """`model.to(torch.bfloat16)` — the single-GPU Trainer's mixed-precision cast — must not round inv_freq to 8 bits (the
+    reference keeps it float32: touchnet/models/llama/__init__.py:19-36 re-derives it on the init device in fp32).  Found by
+    tests/test_full_size_parity_gpu.py: at position 700 the fastest pairs were off by radians."""
+    cfg = DecoderConfig.from_dict(dict(model_type="qwen2", hidden_size=64, intermediate_size=128, num_attention_heads=4,
+                                       num_hidden_layers=1, num_key_value_heads=2, head_dim=16, vocab_size=128,
+                                       rope_theta=1000000.0))
+    m = PackedCausalLM(cfg)
+    ref = m.model.rotary_emb.inv_freq.clone()
+    m.to(torch.bfloat16)
+    assert m.lm_head.weight.dtype == torch.bfloat16
+    assert m.model.rotary_emb.inv_freq.dtype == torch.float32 and torch.equal(m.model.rotary_emb.inv_freq, ref)
+    m.to(torch.float64).to(torch.bfloat16)
+    assert torch.equal(m.model.rotary_emb.inv_freq, ref)
+    assert "model.rotary_emb.inv_freq" not in m.state_dict()            # (still a non-persistent buffer)

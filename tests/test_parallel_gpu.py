@@ -600,11 +600,14 @@ def test_flat_engine_weight_gradients_written_by_the_gemm_into_fp32_staging(rccl
         assert abs(a - b) / abs(b) < 3e-3, (got, ref)
 
 
-@pytest.mark.parametrize("engine", ["plain", "flat"])
-def test_weight_gradients_on_a_side_stream_train_identically(rccl_single_rank, engine, monkeypatch):
+@pytest.mark.parametrize("engine,bias", [("plain", False), ("flat", False), ("plain", True), ("flat", True)])
+def test_weight_gradients_on_a_side_stream_train_identically(rccl_single_rank, engine, bias, monkeypatch):
     """functional.enable_wgrad_stream(): the weight-gradient GEMMs (own kernel, 2560-wide layers) run on a second stream
     beside the input-gradient chain, inputs kept alive by record_stream, consumers (optimizer, the flat engine's
-    reduce-scatter) waiting for that stream — the same numbers as the single-stream run, step for step."""
+    reduce-scatter) waiting for that stream — the same numbers as the single-stream run, step for step.  `bias` (Qwen2's
+    q / k / v biases): the bias gradient is allocated on the main stream, FILLED by the weight-gradient launch
+    on the side stream and read by autograd on the main stream — `_beside(written=...)` makes the main stream wait; the
+    grouped MLP launch returns a LIST of gradients, which gets the same treatment as a single tensor."""
     import touchnet_amd.functional as F
     import touchnet_amd.specs  # noqa: F401
     from touchnet_amd.bin.train import TrainConfig, Trainer
@@ -612,7 +615,7 @@ def test_weight_gradients_on_a_side_stream_train_identically(rccl_single_rank, e
     from touchnet_amd.models.llama import DecoderConfig
     from touchnet_amd.utils.distributed import build_dp_mesh
     wide = dict(CFG, model_type="llama", hidden_size=2560, intermediate_size=2560, num_attention_heads=20,
-                num_key_value_heads=20, head_dim=128, num_hidden_layers=2)
+                num_key_value_heads=20, head_dim=128, num_hidden_layers=2, attention_bias=bias)
     cfg = DecoderConfig.from_dict(wide)
     job = dict(training_model_name="llama_mi355", training_enable_fused_ce=True, lr_scheduler_warmup_steps=0,
                lr_scheduler_lr=1e-3)

@@ -69,6 +69,24 @@ def test_rank_without_audio_still_runs_the_tower_on_one_clip_and_keeps_no_row():
     assert clips.tolist() == [0] and lpos.size == 0 and rows.size == 0
 
 
+def test_bench_defaults_to_the_baseline_recipe_of_the_workload():
+    """`python bench.py --gpus 8 --workload W` without --cp / --tp runs the layout BASELINE.json names
+    for W (C: dp 8; D: CP 4 x dp 2; E: TP 2 x dp 4); explicit flags win; one GPU and emulated ranks are never re-shaped."""
+    import bench
+    assert bench.recipe_degrees("qwen2_audio_7b", 8, None, None) == (1, 1)
+    assert bench.recipe_degrees("qwen2_audio_7b_long", 8, None, None) == (4, 1)
+    assert bench.parallel_layout(8, *bench.recipe_degrees("qwen2_audio_7b_long", 8, None, None))["dp"] == 2
+    assert bench.recipe_degrees("kimi_audio_7b", 8, None, None) == (1, 2)
+    assert bench.parallel_layout(8, *bench.recipe_degrees("kimi_audio_7b", 8, None, None))["dp"] == 4
+    assert bench.recipe_degrees("qwen2_audio_7b_long", 2, None, None) == (1, 1)        # 2 is not a multiple of 4
+    assert bench.recipe_degrees("qwen2_audio_7b_long", 4, None, None) == (4, 1)
+    assert bench.recipe_degrees("qwen2_audio_7b_long", 1, None, None) == (1, 1)
+    assert bench.recipe_degrees("qwen2_audio_7b_long", 8, 2, None) == (2, 1)           # explicit flag wins
+    assert bench.recipe_degrees("kimi_audio_7b", 8, None, 1) == (1, 1)
+    assert bench.recipe_degrees("qwen2_audio_7b_long", 1, 4, None, emulate_rank=0) == (4, 1)
+    assert bench.recipe_degrees("kimi_audio_7b", 1, None, 2, emulate_rank=1) == (1, 2)
+
+
 def test_parallel_layout_of_the_bench_flags():
     import bench
     d = bench.parallel_layout(8, cp=4)

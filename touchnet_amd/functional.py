@@ -810,8 +810,14 @@ def sync_wgrad_stream() -> None:
         torch.cuda.current_stream().wait_stream(WGRAD_STREAM)
 
 
-def _beside(inputs, fn):
-    """run `fn` (a weight-gradient product over `inputs`) on the side stream, if there is one"""
+def _beside(inputs, fn, written=()):
+    """run `fn` (a weight-gradient product over `inputs`) on the side stream, if there is one.
+
+    `written`: tensors ALLOCATED ON THE MAIN STREAM that `fn` fills on the side stream and that the caller hands to
+    autograd next (the bias gradient that rides on a weight-gradient launch): the main stream waits for the side stream
+    before it returns, and the allocator is told about the second stream.  A tensor (or list / tuple of tensors) RETURNED
+    by `fn` was allocated on the side stream: it is recorded on the main stream, and — when the consumer reads it on the
+    main stream right away (`WGRAD_RETURNS_NEED_SYNC`: FSDP2 and every engine without gradient sinks) — waited for."""
     side = WGRAD_STREAM
     if side is None:
         return fn()
@@ -823,10 +829,18 @@ def _beside(inputs, fn):
         out = fn()
     for t in inputs:
         t.record_stream(side)
-    if isinstance(out, torch.Tensor):
-        out.record_stream(main)
-        if WGRAD_RETURNS_NEED_SYNC:           # (record_stream only protects the allocator, not the reader)
-            main.wait_stream(side)
+    wait = False
+    for t in written:
+        if t is not None:
+            t.record_stream(side)
+            wait = True                           # (read by autograd / the engine's hook on the main stream)
+    outs = out if isinstance(out, (list, tuple)) else (out,)
+    for t in outs:
+        if isinstance(t, torch.Tensor):
+            t.record_stream(main)
+            wait = wait or WGRAD_RETURNS_NEED_SYNC   # (record_stream only protects the allocator, not the reader)
+    if wait:
+        main.wait_stream(side)
     return out
 
 
@@ -1014,11 +1028,11 @@ class _LinearGroup(torch.autograd.Function):
                     # the bias gradient rides on the weight-gradient launch (column sums of the dY fragments it reads anyway)
                     bg = (torch.empty(Ns[i], dtype=x.dtype, device=x.device)
                           if (nw and need_b[i] and BIAS_IN_WGRAD and not os.environ.get("TN_GEMM_VARIANT")) else None)
-                    if nw and _beside((d, x2c), lambda: _sink_wgrad(ws[i], d, x2c, bg)):
+                    if nw and _beside((d, x2c), lambda: _sink_wgrad(ws[i], d, x2c, bg), written=(bg,)):
                         sunk.add(i)
                         dbs[i] = bg
                     elif nw:
-                        dws[i] = _beside((d, x2c), lambda: _wgrad(d, x2c, bg))
+                        dws[i] = _beside((d, x2c), lambda: _wgrad(d, x2c, bg), written=(bg,))
                         if dws[i] is not None:
                             dbs[i] = bg
             todo = [i for i in range(n) if need_w[i] and dws[i] is None and i not in sunk]

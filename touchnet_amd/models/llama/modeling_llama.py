@@ -46,6 +46,19 @@ class RotaryEmbedding(nn.Module):
     def compute_inv_freq(config, device=None):
         return ops().rope_inv_freq(config.head_dim, config.rope_theta, config.rope_scaling, device=device)
 
+    def _apply(self, fn, recurse=True):
+        """The frequencies stay float32 whatever the module is cast to.  `model.to(torch.bfloat16)` (the single-GPU
+        Trainer's mixed-precision cast, every `.to(bf16)` of a test) used to round them to 8 bits: at position 700 the
+        fastest pairs were then rotated by up to ~2.7 rad more or less than the reference rotates them (which keeps
+        inv_freq fp32: transformers' *RotaryEmbedding.forward, touchnet/models/llama/__init__.py:19-36) — found by
+        tests/test_full_size_parity_gpu.py (hidden states 7 % off the oracle on ~790-token documents; the short
+        fixtures sit at positions where the error is below bf16 rounding)."""
+        super()._apply(fn, recurse)
+        inv = self.inv_freq
+        if inv.dtype != torch.float32 and not inv.is_meta:
+            self.inv_freq = self.compute_inv_freq(self.config, device=inv.device)
+        return self
+
     def forward(self, position_ids, dtype):
         return ops().rope_tables(position_ids, self.inv_freq, dtype, self.attention_scaling)
 
