@@ -93,14 +93,18 @@ def test_round5_gemm_entry_points_refuse_malformed_arguments_before_any_launch()
     assert swiglu_fwd(ldc=I - 8) == EINVAL
     assert swiglu_fwd(M=0) == EINVAL
     assert swiglu_fwd(x=odd) == EINVAL
+    assert swiglu_fwd(ldx=H - 64) == EINVAL and swiglu_fwd(ldw=H - 64) == EINVAL     # a row pitch below the contraction
     # SwiGLU backward
     assert lib.tn_gemm_bf16_swiglu_bwd(p, p, p, p, p, p, M, I, H + 8, I, I, I, None) == EINVAL
     assert lib.tn_gemm_bf16_swiglu_bwd(p, p, p, p, p, p, M, I, H, I, I, I - 8, None) == EINVAL
     assert lib.tn_gemm_bf16_swiglu_bwd(odd, p, p, p, p, p, M, I, H, I, I, I, None) == EINVAL
+    assert lib.tn_gemm_bf16_swiglu_bwd(p, p, p, p, p, p, M, I, H, H - 64, I, I, None) == EINVAL      # dY pitch below H
     # RoPE epilogue: head_dim other than 64 / 128, N not a whole number of heads, no tables
     assert lib.tn_gemm_bf16_rope(p, p, None, p, p, p, M, 4096, H, H, H, 4096, 96, None) == EINVAL
     assert lib.tn_gemm_bf16_rope(p, p, None, p, p, p, M, 4096 + 128, H, H, H, 4096 + 128, 128, None) == EINVAL
     assert lib.tn_gemm_bf16_rope(p, p, None, None, None, p, M, 4096, H, H, H, 4096, 128, None) == EINVAL
+    assert lib.tn_gemm_bf16_rope(p, p, None, p, p, p, M, 4096, H, H - 64, H, 4096, 128, None) == EINVAL
+    assert lib.tn_gemm_bf16_rope(p, p, None, p, p, p, M, 4096, H, H, H - 64, 4096, 128, None) == EINVAL
     # weight gradient + bias gradient without a bias buffer
     assert lib.tn_gemm_bf16_wgrad_bias(p, p, I, H, M, p, None, I, H, H, 0, 0, 1, None, 0, None) == EINVAL
     # grouped launch: no group, too many groups, a mode other than the weight-gradient one

@@ -707,3 +707,46 @@ def test_group_mesh_has_device_mesh_layout():
     for r in range(4):
         assert res[r][0] == "ok", res[r][1]
         assert res[r][1] == float((r // 2) * 4 + 1) and res[r][2] == float(2 * (r % 2) + 2)
+
+
+def _replica_check_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from touchnet_amd.utils.zero_dp import _check_replicas_drew_the_same_values as check
+        g = torch.Generator().manual_seed(0)
+        a, b = torch.randn(64, generator=g), torch.randn(7, 5, generator=g)
+        out = {}
+        check([a, b], dist.group.WORLD)                                   # same draw on both ranks: passes
+        out["same"] = True
+        # rank 1 holds a PERMUTATION of tensor 0 (same sum: the old single-total check let it through)
+        try:
+            check([a.flip(0) if rank == 1 else a, b], dist.group.WORLD)
+            out["perm"] = "passed"
+        except RuntimeError as e:
+            out["perm"] = str(e)
+        # compensating differences across two tensors (grand total unchanged)
+        try:
+            check([a + (1.0 / 64 if rank == 1 else 0.0), b - (1.0 / 35 if rank == 1 else 0.0)], dist.group.WORLD)
+            out["comp"] = "passed"
+        except RuntimeError as e:
+            out["comp"] = str(e)
+        if rank == 0:
+            ret.update(out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_flat_engine_replica_check_sees_permuted_and_compensating_draws():
+    """the start-up check compared ONE float64 grand total over all parameters; a permuted tensor or differences
+    that cancel passed, and a NaN raised the 'ranks differ' message.  Now per-tensor sums and sums of squares."""
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_replica_check_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+        ret = dict(ret)
+    assert ret["same"] is True
+    assert "different initial parameter values" in ret["perm"] and "tensor 0" in ret["perm"]
+    assert "different initial parameter values" in ret["comp"]
+    from touchnet_amd.utils.zero_dp import _check_replicas_drew_the_same_values as check
+    with pytest.raises(RuntimeError, match="non-finite"):
+        check([torch.tensor([1.0, float("nan")])], None)

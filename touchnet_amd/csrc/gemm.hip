@@ -67,7 +67,7 @@ struct Grp {
   bf16_t* C;
   long long ldc;
   int M, N, nbm, nbn;
-  int start;           // index of the product's first tile in the launch's tile list (a multiple of 8: XCD affinity)
+  int start;           // index of the product's first tile in the launch's tile list (the running sum of nbm * nbn)
   int stages;          // ceil(K / 64)
 };
 
@@ -2270,6 +2270,7 @@ int tn_gemm_bf16_swiglu_fwd(const void* x, const void* wg, const void* wu, void*
                             int K, long long ldx, long long ldw, long long ldc, void* stream) {
   using namespace tn::gemm;
   if (M <= 0 || I <= 0 || K <= 0 || (K % 64) || (I % 8) || (ldx % 8) || (ldw % 8) || (ldc % 8) || ldc < I) return TN_EINVAL;
+  if (ldx < K || ldw < K) return TN_EINVAL;        // (row pitches of the row-stored operands: at least the contraction)
   if (((uintptr_t)x | (uintptr_t)wg | (uintptr_t)wu | (uintptr_t)gate | (uintptr_t)up | (uintptr_t)act) & 15) return TN_EINVAL;
   if ((long long)288 * ldx * 2 >= 0x7fffffffLL || (long long)288 * ldw * 2 >= 0x7fffffffLL) return TN_EINVAL;
   if (TN_GEMM_DEFAULT_VARIANT >= 1000 || getenv("TN_GEMM_VARIANT") != nullptr) return TN_EINVAL;
@@ -2310,6 +2311,7 @@ int tn_gemm_bf16_swiglu_bwd(const void* dy, const void* wd, const void* gate, co
                             int M, int I, int H, long long lddy, long long ldw, long long ld, void* stream) {
   using namespace tn::gemm;
   if (M <= 0 || I <= 0 || H <= 0 || (H % 64) || (I % 8) || (lddy % 8) || (ldw % 8) || (ld % 8) || ld < I) return TN_EINVAL;
+  if (lddy < H) return TN_EINVAL;                  // (dY is row-stored: its pitch is at least the contraction)
   if (((uintptr_t)dy | (uintptr_t)wd | (uintptr_t)gate | (uintptr_t)up | (uintptr_t)dgate | (uintptr_t)dup) & 15)
     return TN_EINVAL;
   if ((long long)288 * lddy * 2 >= 0x7fffffffLL || ldw < I || ((long long)(H - 1) * ldw + I) * 2 >= 0x7fffffffLL)
@@ -2364,6 +2366,7 @@ int tn_gemm_bf16_rope(const void* x, const void* w, const void* bias, const void
                       int N, int K, long long ldx, long long ldw, long long ldc, int head_dim, void* stream) {
   using namespace tn::gemm;
   if (M <= 0 || N <= 0 || K <= 0 || (K % 64) || (ldx % 8) || (ldw % 8) || (ldc % 8) || ldc < N) return TN_EINVAL;
+  if (ldx < K || ldw < K) return TN_EINVAL;        // (row pitches of the row-stored operands: at least the contraction)
   if (!((head_dim == 128 && N % 256 == 0) || (head_dim == 64 && N % 64 == 0))) return TN_EINVAL;
   if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)out) & 15) return TN_EINVAL;
   if (((uintptr_t)cos_t | (uintptr_t)sin_t | (uintptr_t)bias) & 7) return TN_EINVAL;

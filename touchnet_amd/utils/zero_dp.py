@@ -436,6 +436,33 @@ class FlatEngineOptimizer:
         self.engine.wait_params()
 
 
+
+def _check_replicas_drew_the_same_values(tensors, group) -> None:
+    """Start-up check of the flat engine: every rank of `group` must hold the SAME float32 initial values (the bf16 buffers
+    are broadcast from rank 0, the optimizer's master copies come from each rank's own draw).  Per tensor three float64
+    statistics are compared — sum, sum of squares and a POSITION-WEIGHTED sum (weights 1 .. 8191 repeating) — with one MIN /
+    MAX all-reduce of the stacked vector: differences that cancel across tensors, inside a tensor, or a permutation of a
+    tensor's elements no longer pass as they did with a single grand total; non-finite values are reported as
+    such instead of as a rank mismatch."""
+    if not tensors:
+        return
+    def three(t):
+        d = t.reshape(-1).double()
+        w = (torch.arange(d.numel(), device=d.device) % 8191 + 1).double()
+        return torch.stack([d.sum(), (d * d).sum(), (d * w).sum()])
+    stats = torch.stack([three(t) for t in tensors]).reshape(-1)
+    if not bool(torch.isfinite(stats).all()):
+        raise RuntimeError("flat data-parallel engine: non-finite values in the initial parameters of this rank "
+                           "(the replica check cannot compare them): fix the initialisation")
+    hi_, lo_ = stats.clone(), stats.clone()
+    dist.all_reduce(hi_, op=dist.ReduceOp.MAX, group=group)
+    dist.all_reduce(lo_, op=dist.ReduceOp.MIN, group=group)
+    if not torch.equal(hi_, lo_):
+        bad = int((hi_ != lo_).nonzero()[0]) // 3
+        raise RuntimeError("flat data-parallel engine: the ranks hold different initial parameter values (tensor "
+                           f"{bad} of {len(tensors)}: its checksums differ across ranks): seed every rank alike "
+                           "or broadcast the model before build_optimizers_fn")
+
 def build_flat_engine_optimizer(model: nn.Module, make_optimizer):
     """`make_optimizer(named_shards, process_group)` -> the optimizer over the engine's shards.  Returns the
     FlatEngineOptimizer; the engine is also left at `model._tn_flat_engine`."""
@@ -472,13 +499,6 @@ def build_flat_engine_optimizer(model: nn.Module, make_optimizer):
         # group (one tiny all-reduce at start-up) and refuse loudly.
         group = mark["mesh"].get_group()
         if engine.world > 1 and not engine.emulated:
-            sums = torch.stack([src.sum(dtype=torch.float64) for src in keep.values()]).sum().reshape(1)
-            hi_, lo_ = sums.clone(), sums.clone()
-            dist.all_reduce(hi_, op=dist.ReduceOp.MAX, group=group)
-            dist.all_reduce(lo_, op=dist.ReduceOp.MIN, group=group)
-            if float(hi_) != float(lo_):
-                raise RuntimeError("flat data-parallel engine: the ranks hold different initial parameter values (checksum "
-                                   f"{float(lo_)} .. {float(hi_)}): seed every rank alike or broadcast the model before "
-                                   "build_optimizers_fn")
+            _check_replicas_drew_the_same_values(list(keep.values()), group)
     model._tn_flat_engine = engine
     return FlatEngineOptimizer(engine, inner)
