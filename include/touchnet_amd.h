@@ -255,6 +255,13 @@ int tn_pack_fill(const int* row, const int* col, const int* sent, const int* bat
 int tn_gemm_bf16(const void* const* A, const void* const* B, const long long* lda, const long long* ldb, const int* K,
                  int nseg, int a_kmaj, int b_kmaj, void* C, void* Ct, const void* bias, int M, int N, long long ldc,
                  long long ldct, int accumulate, void* stream);
+/*      C = A B^T (+ bias) + addend: the residual stream added in the epilogue of the producing GEMM — `hidden_states =
+ *      residual + hidden_states` behind o_proj / down_proj (transformers' LlamaDecoderLayer / Qwen2DecoderLayer.forward as
+ *      driven by touchnet/models/llama/__init__.py; WhisperEncoderLayer.forward for the audio tower) — so that the norm
+ *      behind it reads one tensor instead of two.  One segment; addend [M, N] bf16 with pitch ldadd (>= N, % 8), 16-byte
+ *      aligned, must not alias C; the product is rounded to bf16 before the addition (the bits of GEMM + residual add). */
+int tn_gemm_bf16_addend(const void* A, const void* B, long long lda, long long ldb, int K, int a_kmaj, int b_kmaj, void* C,
+                        const void* bias, const void* addend, long long ldadd, int M, int N, long long ldc, void* stream);
 /*      The same product (one segment, no transposed copy) with the contraction cut into `splitk` >= 2 parts that run as
  *      independent units.  tail_only = 0: every tile is split — outputs of few 256 x 256 tiles with a deep contraction (the
  *      audio tower's 1280 x 1280 weight gradients contract 30000 frames: 25 tiles for 256 CUs).  tail_only = 1: the whole
@@ -310,6 +317,17 @@ int tn_gemm_bf16_swiglu_fwd(const void* x, const void* wg, const void* wu, void*
  *      tn_swiglu_bwd on the bf16-rounded d(act) (bit-identical).  -22 unless H % 64 == 0, I % 8 == 0, pitches % 8 == 0. */
 int tn_gemm_bf16_swiglu_bwd(const void* dy, const void* wd, const void* gate, const void* up, void* dgate, void* dup,
                             int M, int I, int H, long long lddy, long long ldw, long long ld, void* stream);
+/*      The audio tower's MLP (transformers' WhisperEncoderLayer.forward: fc2(gelu(fc1(x))), exact-erf GELU, as driven by
+ *      touchnet/models/qwen2_audio/__init__.py:18-133): pre[M, N] = x W^T + bias AND act = gelu(pre) from one launch
+ *      (bit-identical to tn_gemm_bf16 followed by tn_gelu_fwd on the rounded pre).  -22 unless K % 64 == 0, N % 8 == 0,
+ *      pitches % 8 == 0 and >= the rows they span, 16-byte aligned bases, pre != act. */
+int tn_gemm_bf16_gelu_fwd(const void* x, const void* w, const void* bias, void* pre, void* act, int M, int N, int K,
+                          long long ldx, long long ldw, long long ldc, void* stream);
+/*      ... and the backward of its second half: d(pre)[M, I] = (dY[M, H] W2[H, I]) o gelu'(pre): d(act) lives in the
+ *      accumulators only (W2 read contraction-major, pitch ldw; pre / d(pre) with pitch ld) = tn_gemm_bf16 (b_kmaj) followed
+ *      by tn_gelu_bwd on the rounded d(act) (bit-identical).  -22 unless H % 64 == 0, I % 8 == 0, pitches % 8 == 0. */
+int tn_gemm_bf16_gelu_bwd(const void* dy, const void* w2, const void* pre, void* dpre, int M, int I, int H, long long lddy,
+                          long long ldw, long long ld, void* stream);
 /*      A q / k projection with the rotary embedding in the epilogue (transformers' LlamaAttention.forward: q_proj /
  *      k_proj followed by apply_rotary_pos_emb, modeling_llama.py:113-160): out[M, N] = rope(x W^T + bias), N = heads x
  *      head_dim (64 or 128), cos / sin [M, head_dim / 2] bf16 = one table row per output row (tn_rope_table).  Bit-identical

@@ -62,6 +62,12 @@ def linear_group(x, layers, wgrad="tn", dgrad_tn=True, norm_src=None, rope=None)
 gelu = torch.nn.functional.gelu
 
 
+def gelu_mlp(x, w1, b1, w2, b2):
+    """mirror of touchnet_amd.functional.gelu_mlp: WhisperEncoderLayer's fc2(gelu(fc1(x))), exact-erf GELU"""
+    lin = torch.nn.functional.linear
+    return lin(gelu(lin(x, w1, b1)), w2, b2)
+
+
 def rope_inv_freq(head_dim, theta, scaling=None, device=None):
     inv = _nn.rope_inv_freq(head_dim, theta, scaling)
     return inv.to(device) if device is not None else inv

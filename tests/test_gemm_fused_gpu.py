@@ -364,3 +364,87 @@ def test_linear_group_with_rope_outputs_trains_like_projection_then_rope(monkeyp
     assert len(calls) == 2
     for i, (a, b, c) in enumerate(zip(got, want, behind)):
         assert torch.equal(a, b) and torch.equal(c, b), i
+
+
+@pytest.mark.parametrize("M,N,K,bias,kmaj", [
+    (256, 256, 64, False, False), (520, 264, 192, True, False), (8200, 1096, 128, False, False),
+    (15872, 4096, 4096, False, False),      # o_proj at the headline's rows
+    (4096, 4096, 11008, False, False),      # down_proj (256 tiles: not a split-K shape, whose fp32 partial sums round differently)
+    (30000, 1280, 5120, True, False),       # the tower's fc2 (bias) at the headline's frames
+    (1000, 776, 1088, False, True),         # contraction-major B (32x32x16 kernel's epilogue... the 16x16 one takes it too)
+])
+def test_residual_addend_epilogue_is_bit_identical_to_the_product_plus_the_norm_kernels_addition(M, N, K, bias, kmaj):
+    """Round 6: `hidden_states = residual + hidden_states` in the epilogue of the producing GEMM (tn_gemm_bf16_addend).  The
+    product is rounded to bf16 and added to the addend in fp32 — exactly what GEMM + the fused norm kernel's residual add
+    did: bits must agree with `rms_norm(delta, residual)`'s second output and with bf16(a + b)."""
+    F = _f()
+    g = torch.Generator().manual_seed(M + 3 * N + 7 * K)
+    a = _r(g, M, K)
+    b = _r(g, K, N, scale=K ** -0.5 * 2) if kmaj else _r(g, N, K, scale=K ** -0.5 * 2)
+    r = _r(g, M, N, scale=2.0)
+    bv = _r(g, N) if bias else None
+    y = F.gemm([(a, b)], b_kmaj=kmaj, bias=bv, addend=r)
+    ref = F.gemm([(a, b)], b_kmaj=kmaj, bias=bv)
+    assert torch.equal(y, (ref.float() + r.float()).to(torch.bfloat16))
+    if N % 8 == 0 and not kmaj:
+        _, h = F.rms_norm(ref, torch.ones(N, dtype=torch.bfloat16, device=DEV), 1e-6, residual=r)
+        assert torch.equal(y, h)
+    # refused: aliasing the output, a second segment, accumulate
+    with pytest.raises(Exception):
+        F.gemm([(a, b)], b_kmaj=kmaj, out=r, addend=r)
+
+
+@pytest.mark.parametrize("M,N,K,bias", [(256, 256, 64, True), (520, 264, 192, False), (8200, 1096, 128, True),
+                                        (30000, 5120, 1280, True)])        # the tower's fc1 at the headline's frames
+def test_gelu_forward_epilogue_is_bit_identical_to_the_product_and_the_gelu_kernel(M, N, K, bias):
+    F = _f()
+    g = torch.Generator().manual_seed(M + 3 * N + 7 * K)
+    x, w = _r(g, M, K), _r(g, N, K, scale=K ** -0.5 * 4)
+    b = _r(g, N) if bias else None
+    pre, act = F.gemm_gelu_fwd(x, w, b)
+    ref = F.gemm([(x, w)], bias=b)
+    assert torch.equal(pre, ref), "pre"
+    assert torch.equal(act, F.gelu(ref)), "act"
+    # the shared GELU itself against torch's exact-erf GELU in fp64 (A&S 7.1.26: <= 1.5e-7 on erf)
+    exact = torch.nn.functional.gelu(ref.double())
+    assert float((act.double() - exact).abs().max()) <= float(exact.abs().max()) * 2 ** -8
+
+
+@pytest.mark.parametrize("M,I,H", [(256, 256, 64), (520, 264, 192), (4360, 4104, 128), (30000, 5120, 1280)])
+def test_gelu_backward_epilogue_is_bit_identical_to_the_product_and_the_gelu_backward_kernel(M, I, H):
+    F = _f()
+    from touchnet_amd import library as L
+    g = torch.Generator().manual_seed(M + 5 * I + 11 * H)
+    dy, w2 = _r(g, M, H), _r(g, H, I, scale=H ** -0.5 * 2)
+    pre = _r(g, M, I, scale=3.0)
+    dpre = F.gemm_gelu_bwd(dy, w2, pre)
+    dact = F.gemm([(dy, w2)], b_kmaj=True)
+    assert torch.equal(dpre, L.gelu_bwd(dact, pre))
+    # gelu' against autograd of torch's exact GELU
+    xg = pre.double().requires_grad_()
+    torch.nn.functional.gelu(xg).backward(dact.double())
+    assert float((dpre.double() - xg.grad).abs().max()) <= float(xg.grad.abs().max()) * 2 ** -7
+
+
+def test_tower_layer_fused_mlp_equals_the_unfused_layer(monkeypatch):
+    """functional._GeluMLP (GELU in fc1's epilogue, its backward in fc2's input-gradient epilogue) against the composition
+    of the individual ops: same outputs, same gradients, bit for bit."""
+    F = _f()
+    g = torch.Generator().manual_seed(5)
+    M, d, ffn = 6000, 1280, 5120
+    x = _r(g, 1, M, d).requires_grad_()
+    w1, b1 = _r(g, ffn, d, scale=0.05).requires_grad_(), _r(g, ffn, scale=0.1).requires_grad_()
+    w2, b2 = _r(g, d, ffn, scale=0.03).requires_grad_(), _r(g, d, scale=0.1).requires_grad_()
+    dy = _r(g, 1, M, d)
+
+    def run():
+        for t in (x, w1, b1, w2, b2):
+            t.grad = None
+        y = F.gelu_mlp(x, w1, b1, w2, b2)
+        y.backward(dy)
+        return [y.detach().clone()] + [t.grad.clone() for t in (x, w1, b1, w2, b2)]
+    a = run()
+    monkeypatch.setattr(F, "GELU_EPILOGUE", False)
+    b = run()
+    for name, u, v in zip(("y", "dx", "dw1", "db1", "dw2", "db2"), a, b):
+        assert torch.equal(u, v), name

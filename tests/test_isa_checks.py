@@ -139,7 +139,8 @@ def test_fused_dkdv_accumulators_and_stage_ring(tmp_path):
 @pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not on PATH")
 def test_product_gemm_kernels_keep_their_stage_loops_clean(tmp_path):
     """Every instantiation of the product GEMM (csrc/gemm.hip: `gemm_kernel` with its epilogue modes — plain, grouped, SwiGLU
-    forward / backward, bias gradient, RoPE — and `gemm16_kernel`, the 16x16x32 variant) compiled for gfx950: no scratch, no
+    forward / backward, bias gradient, RoPE — and `gemm16_kernel`, the 16x16x32 variant, with the GELU epilogues of round 6)
+    compiled for gfx950: no scratch, no
     VGPR spill (a fused epilogue must not push the main loop out of the register file); each kernel issues ONE MFMA shape;
     and its stage loops hold no `s_waitcnt vmcnt` but the hand-counted `vmcnt(4)` of the five-slot LDS-DMA ring (a
     compiler-inserted one in front of an LDS access would drain the ring every stage)."""
@@ -152,7 +153,8 @@ def test_product_gemm_kernels_keep_their_stage_loops_clean(tmp_path):
     text = out.read_text()
     kernels = re.findall(r"^(_ZN2tn4gemm(?:11gemm_kernel|13gemm16_kernel)\S*):(.*?)s_endpgm", text, re.S | re.M)
     names = [n for n, _ in kernels]
-    assert sum("gemm16_kernel" in n for n in names) == 5 and sum("11gemm_kernel" in n for n in names) >= 14, names
+    # (gemm16: plain x 2 operand modes, SwiGLU forward / backward, RoPE, GELU forward / backward)
+    assert sum("gemm16_kernel" in n for n in names) == 7 and sum("11gemm_kernel" in n for n in names) >= 14, names
     meta = text[text.find("amdhsa.kernels"):]
     for ent in meta.split("- .agpr_count")[1:]:
         name = re.search(r"\.name:\s+(\S+)", ent).group(1)

@@ -71,6 +71,7 @@ PROTOTYPES = {
     "tn_pack_fill": [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _ll, _ll, _ll, _vp, _vp, _vp,
                      _vp, _vp, _vp, _vp, _vp],
     "tn_gemm_bf16_tn": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _ll, _ll, _ll, _ll, _i, _vp],
+    "tn_gemm_bf16_addend": [_vp, _vp, _ll, _ll, _i, _i, _i, _vp, _vp, _vp, _ll, _i, _i, _ll, _vp],
     "tn_gemm_bf16_splitk": [_vp, _vp, _ll, _ll, _i, _i, _i, _vp, _vp, _i, _i, _ll, _i, _i, _i, _vp, _ll, _vp],
     "tn_gemm_bf16_wgrad_f32": [_vp, _vp, _ll, _ll, _i, _vp, _i, _i, _ll, _i, _i, _vp, _ll, _vp],
     "tn_gemm_bf16": [C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_ll), C.POINTER(_ll), C.POINTER(_i), _i, _i, _i, _vp, _vp,
@@ -80,6 +81,8 @@ PROTOTYPES = {
                              C.POINTER(_ll), C.POINTER(_i), C.POINTER(_i), _i, _i, _i, _i, _i, _vp, _ll, _vp],
     "tn_gemm_bf16_wgrad_bias": [_vp, _vp, _ll, _ll, _i, _vp, _vp, _i, _i, _ll, _i, _i, _i, _vp, _ll, _vp],
     "tn_gemm_bf16_rope": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _ll, _ll, _ll, _i, _vp],
+    "tn_gemm_bf16_gelu_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _ll, _ll, _ll, _vp],
+    "tn_gemm_bf16_gelu_bwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _ll, _ll, _ll, _vp],
     "tn_gemm_bf16_swiglu_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _ll, _ll, _ll, _vp],
     "tn_gemm_bf16_swiglu_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _ll, _ll, _ll, _vp],
     "tn_gemm_set_persistent": [_i],

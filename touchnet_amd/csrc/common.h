@@ -36,6 +36,35 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 // kernels (norm_act.hip) and the fused SwiGLU epilogues of the GEMM (gemm.hip), which must agree bit for bit
 __device__ __forceinline__ float sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 
+// Exact-erf GELU, 0.5 x (1 + erf(x / sqrt 2)) (transformers' ACT2FN["gelu"] of the Whisper / Qwen2-Audio encoder layers:
+// touchnet/models/qwen2_audio/__init__.py drives WhisperEncoderLayer), and its derivative — ONE definition for the row
+// kernels (norm_act.hip) and the GELU epilogues of the GEMM (gemm.hip EPI_GELU_FWD / _BWD), which must agree bit for bit.
+// erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7: three orders below bf16 resolution): 1 - erf(z) = t (a1 + t (a2 + t
+// (a3 + t (a4 + t a5)))) e^{-z^2}, t = 1 / (1 + p z) — ~15 VALU instructions with two transcendentals instead of libm's
+// erff (~40 with branches: too slow beside MFMAs, profiles/r05*), and e^{-z^2} = e^{-x^2 / 2} is the density's exponential too.
+__device__ __forceinline__ void gelu_parts(float x, float& cdf, float& e) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.f));
+  float poly = __builtin_fmaf(t, 1.061405429f, -1.453152027f);
+  poly = __builtin_fmaf(t, poly, 1.421413741f);
+  poly = __builtin_fmaf(t, poly, -0.284496736f);
+  poly = __builtin_fmaf(t, poly, 0.254829592f);
+  e = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f);          // e^{-x^2 / 2}
+  const float q = 0.5f * (poly * t) * e;                                  // (1 - erf(z)) / 2
+  cdf = x >= 0.f ? 1.f - q : q;
+}
+__device__ __forceinline__ float gelu_f(float x) {
+  float cdf, e;
+  gelu_parts(x, cdf, e);
+  return x * cdf;
+}
+// d gelu(x) / dx * dy = (cdf + x pdf) dy,  pdf = e^{-x^2 / 2} / sqrt(2 pi)
+__device__ __forceinline__ float gelu_grad_f(float x, float dy) {
+  float cdf, e;
+  gelu_parts(x, cdf, e);
+  return dy * __builtin_fmaf(x * 0.39894228040143267794f, e, cdf);
+}
+
 // RoPE rotation of one (x[i], x[i + D/2]) pair by (cos, sin) — ONE definition (explicit fma order) for the row kernel
 // (norm_act.hip rope_apply_kernel) and the GEMM's RoPE epilogue (gemm.hip EPI_ROPE), which must agree bit for bit
 __device__ __forceinline__ void rope_rotate(float a, float b, float c, float s, float& ya, float& yb) {

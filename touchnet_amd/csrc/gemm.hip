@@ -94,7 +94,11 @@ struct Grp {
 //                   the natural layout already has that).  (acc + bias) is rounded to bf16 first, as the separate
 //                   projection leaves it, then rotated with the row kernel's arithmetic: bit-identical, one pass over
 //                   q and k through HBM less per layer
+//   EPI_GELU_FWD    (round 6, the audio tower's fc1) C = x W^T + bias AND C2 = gelu(C): the activation pass read C again
+//   EPI_GELU_BWD    (the tower's fc2 input gradient) the product d(act) = dY W never reaches HBM: C = d(act) o gelu'(E1),
+//                   E1 = the saved fc1 output (pitch lde) — the GELU backward pass read both and wrote C
 constexpr int EPI_PLAIN = 0, EPI_GROUPED = 1, EPI_SWIGLU_FWD = 2, EPI_SWIGLU_BWD = 3, EPI_BIASG = 4, EPI_ROPE = 5;
+constexpr int EPI_GELU_FWD = 6, EPI_GELU_BWD = 7;
 
 struct Params {
   Seg seg[MAXSEG];
@@ -105,6 +109,11 @@ struct Params {
   const bf16_t* bias;  // optional [N]
   long long ldc, ldct;
   int accumulate;      // C += result
+  // C = result + ADDEND (round 6: the residual stream added in the o_proj / down_proj epilogue — `hidden_states = residual
+  // + hidden_states` of the HF decoder layers — so that the norm behind it reads ONE tensor): same arithmetic as
+  // accumulate (the product rounded to bf16, added in fp32, rounded), the other term read from here instead of from C
+  const bf16_t* addend;
+  long long ldadd;
   int nbm, nbn;
   int stages;          // sum over segments of K / 64
   // split-K (outputs of few tiles with a deep contraction: the tower's 1280 x 1280 weight gradients over 30000 frames are
@@ -1037,7 +1046,7 @@ struct Kernel {
           bias_v[j][g][3] = __uint_as_float(w.y & 0xffff0000u);
         }
     }
-    const bool acc_c = p.accumulate != 0;
+    const bool acc_c = p.accumulate != 0 || p.addend != nullptr;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       // result rows (registers) = n, result column (lane) = m: 4 consecutive n per register quad -> 8-byte packs
@@ -1072,7 +1081,7 @@ struct Kernel {
           bf16_t* dst = o.C + (long long)m * o.ldc + n;
           if (acc_c) {
             Vec16<bf16_t> o, nw;
-            o.load(dst);
+            o.load(p.addend != nullptr ? p.addend + (long long)m * p.ldadd + n : dst);
             nw.raw = v;
             float fo[8], fn[8];
             o.unpack(fo);
@@ -1146,8 +1155,11 @@ typedef f32x4_t Acc16[8][4];
 
 template <bool AK, bool BK, int PLACE, int EPI = EPI_PLAIN>
 struct Kernel16 {
-  static_assert(EPI == EPI_PLAIN || EPI == EPI_SWIGLU_FWD || EPI == EPI_SWIGLU_BWD || EPI == EPI_ROPE,
-                "Kernel16: plain / SwiGLU / RoPE epilogues (the weight-gradient modes stay on Kernel)");
+  static_assert(EPI == EPI_PLAIN || EPI == EPI_SWIGLU_FWD || EPI == EPI_SWIGLU_BWD || EPI == EPI_ROPE ||
+                    EPI == EPI_GELU_FWD || EPI == EPI_GELU_BWD,
+                "Kernel16: plain / SwiGLU / RoPE / GELU epilogues (the weight-gradient modes stay on Kernel)");
+  static_assert(EPI != EPI_GELU_FWD || !BK, "GELU forward: x W^T layout");
+  static_assert(EPI != EPI_GELU_BWD || BK, "GELU backward: dY W layout");
   static_assert(!AK, "Kernel16 is used where it is faster: row-stored A (forward and input-gradient products)");
   static_assert(EPI != EPI_SWIGLU_FWD || !BK, "SwiGLU forward: x W^T layout");
   static_assert(EPI != EPI_SWIGLU_BWD || BK, "SwiGLU backward: dY W layout");
@@ -1698,7 +1710,7 @@ struct Kernel16 {
         bias_v[bj][3] = __uint_as_float(w.y & 0xffff0000u);
       }
     }
-    const bool acc_c = p.accumulate != 0;
+    const bool acc_c = p.accumulate != 0 || p.addend != nullptr;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
 #pragma unroll
@@ -1723,9 +1735,36 @@ struct Kernel16 {
         const int m = wm0 + half * 64 + row, n = wn0 + c * 8;
         if (m < p.M && n < p.N) {
           bf16_t* dst = p.C + (long long)m * p.ldc + n;
+          if constexpr (EPI == EPI_GELU_FWD) {
+            // v = the rounded pre-activation: stored, and its GELU beside it (what the activation kernel made of it)
+            *reinterpret_cast<uint4*>(dst) = v;
+            Vec16<bf16_t> x;
+            x.raw = v;
+            float f[8];
+            x.unpack(f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = gelu_f(f[e]);
+            x.pack(f);
+            *reinterpret_cast<uint4*>(p.C2 + (long long)m * p.ldc + n) = x.raw;
+            continue;
+          }
+          if constexpr (EPI == EPI_GELU_BWD) {
+            // v = the rounded d(act): times gelu'(pre), what the GELU backward kernel made of the two
+            Vec16<bf16_t> x, d;
+            x.load(p.E1 + (long long)m * p.lde + n);
+            d.raw = v;
+            float f[8], df[8];
+            x.unpack(f);
+            d.unpack(df);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) df[e] = gelu_grad_f(f[e], df[e]);
+            d.pack(df);
+            *reinterpret_cast<uint4*>(dst) = d.raw;
+            continue;
+          }
           if (acc_c) {
             Vec16<bf16_t> o, nw;
-            o.load(dst);
+            o.load(p.addend != nullptr ? p.addend + (long long)m * p.ldadd + n : dst);
             nw.raw = v;
             float fo[8], fn[8];
             o.unpack(fo);
@@ -1955,8 +1994,13 @@ int tn_gemm_get_persistent(void) { return g_persistent; }
 static int gemm_launch(const void* const* A, const void* const* B, const long long* lda, const long long* ldb,
                        const int* K, int nseg, int a_kmaj, int b_kmaj, void* C, void* Ct, const void* bias, int M, int N,
                        long long ldc, long long ldct, int accumulate, int splitk, int tail_only, void* workspace,
-                       long long workspace_bytes, void* stream, int c_f32 = 0, void* bias_grad = nullptr) {
+                       long long workspace_bytes, void* stream, int c_f32 = 0, void* bias_grad = nullptr,
+                       const void* addend = nullptr, long long ldadd = 0) {
   using namespace tn::gemm;
+  // (the addend rides on the plain epilogue of an unsplit, single-output product)
+  if (addend != nullptr && (accumulate || splitk > 1 || tail_only || Ct != nullptr || c_f32 || bias_grad != nullptr ||
+                            (ldadd % 8) || ldadd < N || ((uintptr_t)addend & 15)))
+    return TN_EINVAL;
   if (bias_grad != nullptr && (!(a_kmaj && b_kmaj) || nseg != 1 || Ct != nullptr || bias != nullptr || tail_only ||
                                ((uintptr_t)bias_grad & 1) || TN_GEMM_DEFAULT_VARIANT >= 1000 ||
                                getenv("TN_GEMM_VARIANT") != nullptr))
@@ -2008,6 +2052,8 @@ static int gemm_launch(const void* const* A, const void* const* B, const long lo
   p.ldc = ldc;
   p.ldct = ldct;
   p.accumulate = accumulate;
+  p.addend = (const tn::bf16_t*)addend;
+  p.ldadd = ldadd;
   p.nbm = (M + BM - 1) / BM;
   p.nbn = (N + BN - 1) / BN;
   p.splitk = 1;
@@ -2082,6 +2128,17 @@ int tn_gemm_bf16(const void* const* A, const void* const* B, const long long* ld
                  long long ldct, int accumulate, void* stream) {
   return gemm_launch(A, B, lda, ldb, K, nseg, a_kmaj, b_kmaj, C, Ct, bias, M, N, ldc, ldct, accumulate, 1, 0, nullptr, 0,
                      stream);
+}
+
+// C = A B^T (+ bias) + addend: the residual stream added in the producing GEMM's epilogue (addend [M, N] bf16, pitch ldadd;
+// it may NOT alias C).  One segment; the product is rounded to bf16 before the addition — the bits of the two-kernel form
+// (GEMM, then the norm kernel's residual add: modeling_llama.py / modeling_qwen2.py `hidden_states = residual +
+// hidden_states`).
+int tn_gemm_bf16_addend(const void* A, const void* B, long long lda, long long ldb, int K, int a_kmaj, int b_kmaj, void* C,
+                        const void* bias, const void* addend, long long ldadd, int M, int N, long long ldc, void* stream) {
+  if (addend == nullptr || addend == C) return TN_EINVAL;
+  return gemm_launch(&A, &B, &lda, &ldb, &K, 1, a_kmaj, b_kmaj, C, nullptr, bias, M, N, ldc, 0, 0, 1, 0, nullptr, 0, stream,
+                     0, nullptr, addend, ldadd);
 }
 
 // The same product with the contraction cut into `splitk` parts that run as independent units; fp32 partial sums go through
@@ -2400,6 +2457,79 @@ int tn_gemm_bf16_rope(const void* x, const void* w, const void* bias, const void
   else
     hipLaunchKernelGGL((gemm_kernel<false, false, kDPL, kDAS, kDIL, false, false, false, EPI_ROPE>), grid, dim3(NT), 0,
                        (hipStream_t)stream, p);
+  TN_LAUNCH_CHECK();
+  return TN_OK;
+}
+
+// The audio tower's MLP, first half: pre[M, N] = x[M, K] W[N, K]^T + bias AND act = gelu(pre) from one launch (exact-erf
+// GELU, common.h gelu_f: the bits of tn_gelu_fwd on the rounded pre).  -22 unless K % 64 == 0, N % 8 == 0, pitches % 8 and
+// >= the rows they span, 16-byte aligned bases.
+int tn_gemm_bf16_gelu_fwd(const void* x, const void* w, const void* bias, void* pre, void* act, int M, int N, int K,
+                          long long ldx, long long ldw, long long ldc, void* stream) {
+  using namespace tn::gemm;
+  if (M <= 0 || N <= 0 || K <= 0 || (K % 64) || (N % 8) || (ldx % 8) || (ldw % 8) || (ldc % 8) || ldc < N) return TN_EINVAL;
+  if (ldx < K || ldw < K) return TN_EINVAL;
+  if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)pre | (uintptr_t)act) & 15) return TN_EINVAL;
+  if (((uintptr_t)bias & 7) || pre == act) return TN_EINVAL;
+  if ((long long)288 * ldx * 2 >= 0x7fffffffLL || (long long)288 * ldw * 2 >= 0x7fffffffLL) return TN_EINVAL;
+  if (TN_GEMM_DEFAULT_VARIANT >= 1000 || getenv("TN_GEMM_VARIANT") != nullptr || !use_m16()) return TN_EINVAL;
+  Params p;
+  clear_params(p);
+  p.seg[0].A = (const tn::bf16_t*)x;
+  p.seg[0].B = (const tn::bf16_t*)w;
+  p.seg[0].lda = ldx;
+  p.seg[0].ldb = ldw;
+  p.seg[0].K = K;
+  p.seg[1] = p.seg[2] = p.seg[0];
+  p.stages = K / 64;
+  p.M = M;
+  p.N = N;
+  p.C = (tn::bf16_t*)pre;
+  p.C2 = (tn::bf16_t*)act;
+  p.bias = (const tn::bf16_t*)bias;
+  p.ldc = ldc;
+  p.nbm = (M + BM - 1) / BM;
+  p.nbn = (N + BN - 1) / BN;
+  p.ntiles = p.nbm * p.nbn;
+  const int ncu = num_cus();
+  const dim3 grid(persistent_now() && p.ntiles > ncu ? ncu : p.ntiles);
+  hipLaunchKernelGGL((gemm16_kernel<false, false, kDPL, EPI_GELU_FWD>), grid, dim3(NT), 0, (hipStream_t)stream, p);
+  TN_LAUNCH_CHECK();
+  return TN_OK;
+}
+
+// ... and the backward of its second half: d(pre)[M, I] = (dY[M, H] W2[H, I]) o gelu'(pre) — the product d(act) is formed in
+// the accumulators only (W2 read contraction-major, pitch ldw; pre and d(pre) with pitch ld).  -22 unless H % 64 == 0,
+// I % 8 == 0, pitches % 8.
+int tn_gemm_bf16_gelu_bwd(const void* dy, const void* w2, const void* pre, void* dpre, int M, int I, int H, long long lddy,
+                          long long ldw, long long ld, void* stream) {
+  using namespace tn::gemm;
+  if (M <= 0 || I <= 0 || H <= 0 || (H % 64) || (I % 8) || (lddy % 8) || (ldw % 8) || (ld % 8) || ld < I) return TN_EINVAL;
+  if (lddy < H) return TN_EINVAL;
+  if (((uintptr_t)dy | (uintptr_t)w2 | (uintptr_t)pre | (uintptr_t)dpre) & 15) return TN_EINVAL;
+  if ((long long)288 * lddy * 2 >= 0x7fffffffLL || ldw < I || ((long long)(H - 1) * ldw + I) * 2 >= 0x7fffffffLL)
+    return TN_EINVAL;
+  if (TN_GEMM_DEFAULT_VARIANT >= 1000 || getenv("TN_GEMM_VARIANT") != nullptr || !use_m16()) return TN_EINVAL;
+  Params p;
+  clear_params(p);
+  p.seg[0].A = (const tn::bf16_t*)dy;
+  p.seg[0].B = (const tn::bf16_t*)w2;
+  p.seg[0].lda = lddy;
+  p.seg[0].ldb = ldw;
+  p.seg[0].K = H;
+  p.seg[1] = p.seg[2] = p.seg[0];
+  p.stages = H / 64;
+  p.M = M;
+  p.N = I;
+  p.C = (tn::bf16_t*)dpre;
+  p.E1 = (const tn::bf16_t*)pre;
+  p.ldc = p.lde = ld;
+  p.nbm = (M + BM - 1) / BM;
+  p.nbn = (I + BN - 1) / BN;
+  p.ntiles = p.nbm * p.nbn;
+  const int ncu = num_cus();
+  const dim3 grid(persistent_now() && p.ntiles > ncu ? ncu : p.ntiles);
+  hipLaunchKernelGGL((gemm16_kernel<false, true, kDPL, EPI_GELU_BWD>), grid, dim3(NT), 0, (hipStream_t)stream, p);
   TN_LAUNCH_CHECK();
   return TN_OK;
 }

@@ -566,7 +566,7 @@ __global__ __launch_bounds__(256) void gelu_fwd_kernel(const T* __restrict__ x, 
     a.load(x + v * N);
     a.unpack(f);
 #pragma unroll
-    for (int j = 0; j < N; ++j) f[j] = 0.5f * f[j] * (1.f + erff(f[j] * 0.70710678118654752440f));
+    for (int j = 0; j < N; ++j) f[j] = gelu_f(f[j]);
     a.pack(f);
     a.store(out + v * N);
   }
@@ -584,11 +584,7 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const T* __restrict__ dou
     a.unpack(f);
     d.unpack(df);
 #pragma unroll
-    for (int j = 0; j < N; ++j) {
-      const float cdf = 0.5f * (1.f + erff(f[j] * 0.70710678118654752440f));
-      const float pdf = 0.39894228040143267794f * __expf(-0.5f * f[j] * f[j]);
-      df[j] *= cdf + f[j] * pdf;
-    }
+    for (int j = 0; j < N; ++j) df[j] = gelu_grad_f(f[j], df[j]);
     d.pack(df);
     d.store(dx + v * N);
   }

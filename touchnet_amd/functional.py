@@ -436,7 +436,8 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = Non
 
 def gemm(segs, a_kmaj: bool = False, b_kmaj: bool = False, bias: Optional[torch.Tensor] = None,
          out: Optional[torch.Tensor] = None, accumulate: bool = False,
-         out_t: Optional[torch.Tensor] = None, bias_grad: Optional[torch.Tensor] = None) -> torch.Tensor:
+         out_t: Optional[torch.Tensor] = None, bias_grad: Optional[torch.Tensor] = None,
+         addend: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``out[M, N] = sum_s opA_s @ opB_s^T (+ bias) (+ out)`` on the hand-written MFMA kernel (csrc/gemm.hip), fp32
     accumulation over all segments, one rounding.  ``segs`` = 1..3 pairs ``(a, b)`` of bf16 device matrices with
     contiguous rows AS STORED: ``a`` is [M, K] (``a_kmaj=False``) or [K, M] (``a_kmaj=True``: the contraction index is the
@@ -446,7 +447,9 @@ def gemm(segs, a_kmaj: bool = False, b_kmaj: bool = False, bias: Optional[torch.
         weight gradient  gemm([(dy, x)], True, True)             dy [M, N]^T · x [M, K]    (contraction over tokens)
     — none of them needs a transposed copy of an operand.
     ``bias_grad`` (weight-gradient mode, one segment): a bf16 [M] vector that receives the column sums of ``a`` — the bias
-    gradient dY.sum(0) — from the same launch (tn_gemm_bf16_wgrad_bias): no separate pass over dY."""
+    gradient dY.sum(0) — from the same launch (tn_gemm_bf16_wgrad_bias): no separate pass over dY.
+    ``addend`` (one segment, bf16 [M, N], contiguous rows): ``out = bf16(product + bias) + addend`` in the epilogue
+    (tn_gemm_bf16_addend: the residual stream added where the projection is produced)."""
     if not 1 <= len(segs) <= 3:
         raise _C.KernelError("gemm: 1..3 segments")
     for a, b in segs:
@@ -497,6 +500,14 @@ def gemm(segs, a_kmaj: bool = False, b_kmaj: bool = False, bias: Optional[torch.
     n = len(segs)
     if not a0.is_cuda:
         raise _C.KernelError("touchnet_amd kernels need device (HIP) tensors; got a CPU tensor")
+    if addend is not None:
+        if (n != 1 or accumulate or out_t is not None or bias_grad is not None or addend.dtype != torch.bfloat16
+                or tuple(addend.shape) != (M, N) or addend.stride(1) != 1 or addend.data_ptr() == out.data_ptr()):
+            raise _C.KernelError("gemm: addend needs one segment, a bf16 [M, N] matrix with contiguous rows that is not `out`")
+        _C.check(_C.lib().tn_gemm_bf16_addend(_p(a0), _p(b0), a0.stride(0), b0.stride(0), Ks[0], int(a_kmaj), int(b_kmaj),
+                                              _p(out), _p(bias), _p(addend), addend.stride(0), M, N, out.stride(0), _cur()),
+                 "tn_gemm_bf16_addend")
+        return out
     split, tail = 1, 0
     if bias_grad is not None:
         if not (a_kmaj and b_kmaj and n == 1 and bias is None and out_t is None):
@@ -592,6 +603,32 @@ def gemm_swiglu_fwd(x2: torch.Tensor, w_gate: torch.Tensor, w_up: torch.Tensor):
     _C.check(_C.lib().tn_gemm_bf16_swiglu_fwd(_p(x2), _p(w_gate), _p(w_up), _p(gate), _p(up), _p(act), M, I, K, x2.stride(0),
                                               w_gate.stride(0), I, _cur()), "tn_gemm_bf16_swiglu_fwd")
     return gate, up, act
+
+
+def gemm_gelu_fwd(x2: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor]):
+    """``(pre, act)`` with pre = x2 @ w^T + bias and act = gelu(pre) (exact erf) from ONE launch (tn_gemm_bf16_gelu_fwd;
+    bit-identical to the product followed by `gelu`)."""
+    M, K = x2.shape
+    N = w.shape[0]
+    if not _bf16_rows(x2, w) or w.shape[1] != K or (bias is not None and (bias.dtype != torch.bfloat16 or bias.numel() != N)):
+        raise _C.KernelError("gemm_gelu_fwd: bf16 device matrices x [M, K], w [N, K], bias [N]")
+    pre, act = (torch.empty(M, N, dtype=torch.bfloat16, device=x2.device) for _ in range(2))
+    _C.check(_C.lib().tn_gemm_bf16_gelu_fwd(_p(x2), _p(w), _p(_c(bias)) if bias is not None else None, _p(pre), _p(act), M, N,
+                                            K, x2.stride(0), w.stride(0), N, _cur()), "tn_gemm_bf16_gelu_fwd")
+    return pre, act
+
+
+def gemm_gelu_bwd(dy2: torch.Tensor, w2: torch.Tensor, pre: torch.Tensor):
+    """``d(pre) = (dy2 @ w2) o gelu'(pre)`` (w2 [H, I] read contraction-major): one launch, d(act) never reaches HBM
+    (tn_gemm_bf16_gelu_bwd; bit-identical to the product followed by `gelu_bwd`)."""
+    M, H = dy2.shape
+    I = w2.shape[1]
+    if not _bf16_rows(dy2, w2, pre) or w2.shape[0] != H or tuple(pre.shape) != (M, I) or pre.stride(0) != I:
+        raise _C.KernelError("gemm_gelu_bwd: bf16 device matrices dy [M, H], w2 [H, I], dense pre [M, I]")
+    dpre = torch.empty(M, I, dtype=torch.bfloat16, device=dy2.device)
+    _C.check(_C.lib().tn_gemm_bf16_gelu_bwd(_p(dy2), _p(w2), _p(pre), _p(dpre), M, I, H, dy2.stride(0), w2.stride(0), I,
+                                            _cur()), "tn_gemm_bf16_gelu_bwd")
+    return dpre
 
 
 def gemm_swiglu_bwd(dy2: torch.Tensor, w_down: torch.Tensor, gate: torch.Tensor, up: torch.Tensor):
@@ -736,10 +773,19 @@ def _bf16_rows(*ts) -> bool:
 
 
 def _mm_tn(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-           accumulate: bool = False) -> torch.Tensor:
-    """``a @ b.T (+ bias)`` (``out += ...`` if accumulate) for contraction-contiguous a [M, K], b [N, K]."""
+           accumulate: bool = False, addend: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``a @ b.T (+ bias)`` (``out += ...`` if accumulate; ``+ addend`` [M, N] if given) for contraction-contiguous
+    a [M, K], b [N, K]."""
     M, K = a.shape
     N = b.shape[0]
+    if addend is not None:
+        # (a product that would be cut along its contraction — few output tiles, the last layer on the labelled rows — keeps
+        #  its split-K form and gets the addition behind it: the epilogue variant is for whole-tile products)
+        if (RESIDUAL_EPILOGUE and _own(M, N, (K,)) and _bf16_rows(a, b, addend) and (bias is None or bias.dtype == torch.bfloat16)
+                and K % 64 == 0 and not os.environ.get("TN_GEMM_VARIANT")
+                and (not SPLIT_K or split_k(M, N, K, False, False) == 1)):
+            return gemm([(a, b)], bias=bias, addend=addend)
+        return _mm_tn(a, b, bias) + addend           # (same bits: the product is rounded before the addition either way)
     if (_own(M, N, (K,)) and _bf16_rows(a, b) and (bias is None or bias.dtype == torch.bfloat16)):
         return gemm([(a, b)], bias=bias, out=out, accumulate=accumulate)
     if accumulate:
@@ -761,6 +807,14 @@ def _dgrad(dys, ws) -> Optional[torch.Tensor]:
         dx = gemm(segs, b_kmaj=True, out=dx, accumulate=dx is not None)
     return dx
 
+
+# `_mm_tn(addend=...)` / `gemm(addend=...)`: C = bf16(A B^T + bias) + addend in the GEMM's epilogue (tn_gemm_bf16_addend).  Built
+# in round 6 to add the residual stream where o_proj / down_proj / out_proj / fc2 produce their output, bit-identical to
+# GEMM + the norm kernel's residual add, and MEASURED A NET LOSS on the headline step (profiles/r06g_*, same box): the norm
+# kernels got 6.3 ms cheaper (one input), the epilogue's read of the residual tile is exposed in a persistent GEMM (+53 us per
+# launch, +6.8 ms), and the residual gradient — which the fused norm backward adds in passing — became a separate addition
+# per block (+6.0 ms).  The models do not use it; the entry point stays in the library, tested.
+RESIDUAL_EPILOGUE = True
 
 # bias gradients dY.sum(0) from the weight-gradient launch itself (EPI_BIASG, csrc/gemm.hip) instead of a column-sum pass
 BIAS_IN_WGRAD = os.environ.get("TN_BIAS_IN_WGRAD", "1") != "0"          # (A/B switch)
@@ -1252,6 +1306,71 @@ def conv1d_k3(x, weight, bias, stride: int = 1, need_dx: bool = True):
 
 
 _MLP_FUSED = os.environ.get("TN_MLP_FUSED", "1") != "0"       # (A/B switch for measurements)
+
+
+GELU_EPILOGUE = os.environ.get("TN_GELU_EPILOGUE", "1") != "0"          # (A/B switch; same bits either way)
+
+
+class _GeluMLP(torch.autograd.Function):
+    """``fc2(gelu(fc1(x)))`` of the Whisper-style encoder layer as ONE autograd node (round 6): GELU in fc1's epilogue (pre
+    and act from one launch), its backward in the epilogue of fc2's input-gradient product (d(act) stays in the
+    accumulators); weight and bias gradients as `_LinearGroup` forms them (bias gradients ride on the weight-gradient
+    launches).  Every launch is bit-identical to the kernels it replaces.  Same box, interleaved: 707.5 -> 705.5 ms per
+    headline step (profiles/r06g_*: the two GELU passes, 9.3 ms, against 4.9 ms of epilogue time inside the GEMMs)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        K, I, H = x.shape[-1], w1.shape[0], w2.shape[0]
+        x2 = _c(x.reshape(-1, K))
+        pre, act = gemm_gelu_fwd(x2, _c(w1), b1)
+        y = _mm_tn(act, _c(w2), b2)
+        ctx.save_for_backward(x2, pre, act, w1, w2)
+        ctx.xshape, ctx.has_b = x.shape, (b1 is not None, b2 is not None)
+        return y.view(*x.shape[:-1], H)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, pre, act, w1, w2 = ctx.saved_tensors
+        M, K = x2.shape
+        I, H = w1.shape[0], w2.shape[0]
+        dy2 = _c(dy).reshape(M, H)
+        nx, n1, nb1, n2, nb2 = ctx.needs_input_grad[:5]
+        dpre = gemm_gelu_bwd(dy2, _c(w2), pre)                                   # (dY W2) o gelu'(pre)   [M, I]
+        dx = gemm([(dpre, _c(w1))], b_kmaj=True).view(ctx.xshape) if nx else None
+
+        def wgrad(w, d, a, want_w, want_b):
+            bg = (torch.empty(d.shape[1], dtype=d.dtype, device=d.device)
+                  if (want_w and want_b and BIAS_IN_WGRAD) else None)
+            dw = None
+            if want_w:
+                if _beside((d, a), lambda: _sink_wgrad(w, d, a, bg), written=(bg,)):
+                    dw = None
+                else:
+                    dw = _beside((d, a), lambda: _wgrad(d, a, bg), written=(bg,))
+                    if dw is None:                                             # (a shape the kernel does not take)
+                        dw, bg = torch.mm(d.t(), a), None
+            db = bg if bg is not None else (column_sum(d) if want_b else None)
+            return dw, db
+        dw2, db2 = wgrad(w2, dy2, act, n2, nb2 and ctx.has_b[1])
+        dw1, db1 = wgrad(w1, dpre, x2, n1, nb1 and ctx.has_b[0])
+        return dx, dw1, db1, dw2, db2
+
+
+def gelu_mlp(x, w1, b1, w2, b2):
+    """The Whisper / Qwen2-Audio encoder layer's MLP ``fc2(gelu(fc1(x)))``: bf16 device tensors of shapes the GELU
+    epilogues take go through the fused node above, anything else composes the individual ops (same bits)."""
+    if not (x.is_cuda or x.is_meta):
+        raise _C.KernelError("gelu_mlp: device tensors only (the product path has no CPU fallback)")
+    M, K = x.numel() // x.shape[-1], x.shape[-1]
+    I, H = w1.shape[0], w2.shape[0]
+    ok = (GELU_EPILOGUE and x.is_cuda and LINEAR_GEMM == "own" and x.dtype == torch.bfloat16 and K % 64 == 0 and I % 64 == 0
+          and _own(M, I, (K,)) and _own(M, H, (I,)) and _own(M, I, (H,), False, True) and _own(M, K, (I,), False, True)
+          and _bf16_rows(w1, w2) and all(b is None or b.dtype == torch.bfloat16 for b in (b1, b2))
+          and not os.environ.get("TN_GEMM_VARIANT") and os.environ.get("TN_GEMM_M16", "1") != "0")
+    if ok:
+        return _GeluMLP.apply(x, w1, b1, w2, b2)
+    h = linear_group(x, [(w1, b1)], wgrad="nt", dgrad_tn=False)[0]
+    return linear_group(gelu(h), [(w2, b2)], wgrad="nt", dgrad_tn=False)[0]
 
 
 def swiglu_mlp(x, w_gate, w_up, w_down, norm_src=None):

@@ -115,8 +115,9 @@ class EncoderLayer(nn.Module):
             x, residual = self.self_attn_layer_norm(delta, residual)
         a = self.self_attn(x, mask)
         x, residual = self.final_layer_norm(a, residual)
-        lin = lambda t, m: ops().linear_group(t, [(m.weight, m.bias)], wgrad="nt", dgrad_tn=False)[0]   # HIP bias grad
-        return lin(ops().gelu(lin(x, self.fc1)), self.fc2), residual
+        # fc2(gelu(fc1(x))) as one autograd node: GELU in fc1's epilogue, its backward in the epilogue of fc2's input-gradient
+        # product (functional._GeluMLP)
+        return ops().gelu_mlp(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias), residual
 
 
 # TN_TOWER_VALID_FRAMES=0 restores the reference's schedule (all 1500 frames of every padded clip through the tower).
