@@ -94,6 +94,15 @@ int tn_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse
 int tn_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse2,
                 float* delta, void* dq, void* dk, void* dv, const int* doc, const int* meta, int B, int T, int Nh,
                 int Nkv, int D, float scale, void* stream);
+/* tn_attn_bwd for q / k that carry the rotary embedding (tn_gemm_bf16_rope's epilogue or tn_rope_apply put it there): dq / dk
+ * are returned as gradients of the UN-rotated projections — tn_attn_bwd followed by tn_rope_apply(dq, dk, backward = 1), bit
+ * for bit, with the transposed rotation done in the backward kernels' epilogues (D = 128) instead of one more pass over
+ * dq / dk.  Replaces the autograd backward of transformers' apply_rotary_pos_emb inside the reference's decoder layers
+ * (modeling_qwen2.py Qwen2Attention.forward as patched by touchnet/models/llama/__init__.py:11-15; flex_attention's
+ * backward at touchnet/models/llama/parallelize_llama.py).  cos_t / sin_t: bf16 [B * T, D / 2] from tn_rope_table. */
+int tn_attn_bwd_rope(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse2,
+                     float* delta, void* dq, void* dk, void* dv, const int* doc, const int* meta, int B, int T, int Nh,
+                     int Nkv, int D, float scale, const void* cos_t, const void* sin_t, void* stream);
 /* The same pair with the mask BIDIRECTIONAL inside a document (allowed = same positive document id; no causal term):
  * transformers' WhisperEncoder layers, which the reference's Kimi-Audio speech encoder runs on every 30 s clip
  * (touchnet/models/kimi_audio/modeling_kimi_audio.py:933-960; one clip = one document).  Same tensors, same metadata. */

@@ -46,9 +46,10 @@ def pcm16_to_float(pcm):
     return pcm.to(torch.float32) / 32768.0
 
 
-def linear_group(x, layers, wgrad="tn", dgrad_tn=True, norm_src=None, rope=None):
+def linear_group(x, layers, wgrad="tn", dgrad_tn=True, norm_src=None, rope=None, rope_grad_in_attention=False):
     """mirror of touchnet_amd.functional.linear_group: plain nn.Linear math per layer; `rope = (cos, sin, head_dim, which)`:
-    the outputs `which` come back rotated (apply_rope below on [.., heads, head_dim])"""
+    the outputs `which` come back rotated (apply_rope below on [.., heads, head_dim]; autograd rotates their gradients
+    back whoever consumes them, so `rope_grad_in_attention` / packed_attention's `rope_grad` change nothing here)"""
     outs = [torch.nn.functional.linear(x, w, b) for w, b in layers]
     if rope is not None:
         cos, sin, D, which = rope
@@ -95,7 +96,7 @@ def causal_mask(B, T, device):
     return build_packed_mask(torch.ones(B, T, dtype=torch.int64, device=device))
 
 
-def packed_attention(q, k, v, mask, scale=None):
+def packed_attention(q, k, v, mask, scale=None, rope_grad=None):
     scale = q.shape[-1] ** -0.5 if scale is None else scale
     return _nn.attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), mask.allow, scale)
 

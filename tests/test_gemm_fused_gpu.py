@@ -366,6 +366,51 @@ def test_linear_group_with_rope_outputs_trains_like_projection_then_rope(monkeyp
         assert torch.equal(a, b) and torch.equal(c, b), i
 
 
+@pytest.mark.parametrize("heads,kv_heads", [(8, 8), (8, 2)])
+def test_attention_block_with_the_rotary_gradient_in_the_attention_backward_trains_bit_identically(heads, kv_heads, monkeypatch):
+    """models/llama Attention (q / k / v projections with the rotary embedding in their epilogues -> packed attention ->
+    o_proj): with functional.ROPE_GRAD_IN_ATTENTION the attention backward returns dq / dk rotated back (tn_attn_bwd_rope) and
+    the projection node skips its pass over them — output and every gradient equal the separate-pass run bit for bit
+    (multi-head: stacked gradient buffer; grouped-query: flat buffer)."""
+    F = _f()
+    from touchnet_amd.models.llama import DecoderConfig
+    from touchnet_amd.models.llama.modeling_llama import Attention
+    cfg = DecoderConfig.from_dict(dict(model_type="qwen2", hidden_size=1024, intermediate_size=2048, num_attention_heads=heads,
+                                       num_key_value_heads=kv_heads, head_dim=128, num_hidden_layers=1, vocab_size=64,
+                                       attention_bias=True))
+    torch.manual_seed(5)
+    att = Attention(cfg).to(DEV).to(torch.bfloat16)
+    g = torch.Generator().manual_seed(3)
+    B, T = 2, 1024
+    x = _r(g, B, T, 1024, scale=0.5)
+    dy = _r(g, B, T, 1024)
+    doc = torch.ones(B, T, dtype=torch.int32)
+    doc[0, 500:] = 2
+    doc[1, 900:] = 0
+    mask = F.build_packed_mask(doc.to(DEV))
+    pos = torch.arange(T)[None].expand(B, T).contiguous().to(DEV)
+    cos, sin = F.rope_tables(pos, F.rope_inv_freq(128, 1e6, device=DEV), torch.bfloat16)
+    calls = []
+    orig = F._AttentionRopeGrad.apply
+    monkeypatch.setattr(F._AttentionRopeGrad, "apply", lambda *a: (calls.append(1), orig(*a))[1])
+
+    def run(on):
+        monkeypatch.setattr(F, "ROPE_GRAD_IN_ATTENTION", on)
+        xx = x.clone().requires_grad_()
+        for p in att.parameters():
+            p.grad = None
+        y = att(xx, cos, sin, mask)
+        y.backward(dy)
+        return [y.detach(), xx.grad] + [p.grad.clone() for p in att.parameters()]
+
+    want = run(False)
+    assert not calls
+    got = run(True)
+    assert len(calls) == 1
+    for i, (a, b) in enumerate(zip(got, want)):
+        assert torch.equal(a, b), (i, float((a.float() - b.float()).abs().max()))
+
+
 @pytest.mark.parametrize("M,N,K,bias,kmaj", [
     (256, 256, 64, False, False), (520, 264, 192, True, False), (8200, 1096, 128, False, False),
     (15872, 4096, 4096, False, False),      # o_proj at the headline's rows

@@ -282,6 +282,32 @@ def test_packed_attention_fwd_bwd(B, T, Nh, Nkv, D, maxdoc, pad):
         assert float(qd.grad.float().cpu()[pad_rows].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("B,T,Nh,Nkv,D,maxdoc,pad", ATT_CASES + [(1, 2048, 4, 4, 128, 800, 60)])
+def test_attention_backward_with_the_rotary_gradient_in_its_epilogues(B, T, Nh, Nkv, D, maxdoc, pad):
+    """tn_attn_bwd_rope (functional.packed_attention(rope_grad=..) -> library.attn_bwd_rope): dq / dk come back as gradients
+    of the UN-rotated projections — the bits of tn_attn_bwd followed by tn_rope_apply(backward) (D = 128: the transposed
+    rotation sits in the dQ and dK / dV kernels' epilogues; D = 64: the row kernel runs behind the launch), dv unchanged.
+    Multi-head and grouped-query geometries (the stacked and the flat result buffer), ragged T, padded tails."""
+    F = _f()
+    import touchnet_amd.library as L
+    doc = _docs(B, T, T + Nh, maxdoc, pad)
+    g = torch.Generator().manual_seed(T + D)
+    q, do = [torch.randn(B, T, Nh, D, generator=g).bfloat16().to(DEV) for _ in range(2)]
+    k, v = [torch.randn(B, T, Nkv, D, generator=g).bfloat16().to(DEV) for _ in range(2)]
+    pos = torch.randint(0, 4000, (B, T), generator=g)
+    cos, sin = F.rope_tables(pos.to(DEV), F.rope_inv_freq(D, 1000000.0, device=DEV), torch.bfloat16)
+    mask = F.build_packed_mask(doc.to(DEV))
+    qa, ka, va = [t.clone().requires_grad_(True) for t in (q, k, v)]
+    F.packed_attention(qa, ka, va, mask).backward(do)
+    rq, rk = L.rope_apply(qa.grad, ka.grad, cos, sin, True)
+    qb, kb, vb = [t.clone().requires_grad_(True) for t in (q, k, v)]
+    F.packed_attention(qb, kb, vb, mask, rope_grad=(cos, sin)).backward(do)
+    torch.cuda.synchronize()
+    assert torch.equal(vb.grad, va.grad)
+    assert torch.equal(qb.grad, rq), float((qb.grad.float() - rq.float()).abs().max())
+    assert torch.equal(kb.grad, rk), float((kb.grad.float() - rk.float()).abs().max())
+
+
 @pytest.mark.parametrize("D", [128, 64])
 def test_packed_attention_backward_is_reproducible_launch_after_launch(D):
     """The same backward 300 times on a batch of short documents (the shape of the 2560-wide trainer test: B = 4 x 512,

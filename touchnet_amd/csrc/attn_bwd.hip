@@ -793,17 +793,21 @@ namespace tn {
 // attn_bwd_dq_stream.hip: the dQ pass on precomputed tile lists, Q / dO by LDS-DMA, batched operand reads, whole-row stores
 void launch_attn_bwd_dq_stream(const bf16_t* Q, const bf16_t* K, const bf16_t* V, const bf16_t* dO, const float* lse2,
                                float* delta, bf16_t* dQ, const int* doc, AttnMeta m, QView qv, int B, int T, int Nh,
-                               int Nkv, int D, float scale, float sl2, const bf16_t* O, hipStream_t st);
+                               int Nkv, int D, float scale, float sl2, const bf16_t* O, const bf16_t* rcos,
+                               const bf16_t* rsin, hipStream_t st);
 // attn_bwd_fused.hip: dK and dV in ONE pass (D = 128)
 void launch_attn_bwd_kv_fused128(const bf16_t* Q, const bf16_t* K, const bf16_t* V, const bf16_t* dO,
                                  const float* lse2, const float* delta, bf16_t* dK, bf16_t* dV, const int* doc,
                                  AttnMeta m, QView qv, int B, int T, int Nh, int Nkv, float scale, float sl2,
-                                 hipStream_t st);
+                                 const bf16_t* rcos, const bf16_t* rsin, hipStream_t st);
 }  // namespace tn
 
 using namespace tn;
 
 extern "C" {
+
+int tn_rope_apply(const void* q, const void* k, void* q_out, void* k_out, const void* cos_t, const void* sin_t, int n,
+                  int hq, int hk, int D, int backward, int dtype, void* stream);      // (norm_act.hip)
 
 // TN_ATTN_BWD_KV=split restores the two-launch dV / dK scheme for D = 128 (kernel-development A/B switch, read per call)
 static bool bwd_kv_split() {
@@ -825,7 +829,7 @@ static int bwd_dq_mode() {
 static int attn_bwd_launch(const void* q, const void* k, const void* v, const void* o, const void* dout,
                            const float* lse2, float* delta, void* dq, void* dk, void* dv, const int* doc,
                            const int* meta, int B, int T, int Nh, int Nkv, int D, float scale, QView qv,
-                           void* stream) {
+                           void* stream, const void* rope_cos = nullptr, const void* rope_sin = nullptr) {
   if (B <= 0 || T <= 0 || Nh <= 0 || Nkv <= 0 || Nh % Nkv) return TN_EINVAL;
   if (D != 64 && D != 128) return TN_EINVAL;
   for (int s = 0; s < qv.nseg; ++s)
@@ -842,9 +846,17 @@ static int attn_bwd_launch(const void* q, const void* k, const void* v, const vo
   const bf16_t* O_ = delta_pass ? nullptr : (const bf16_t*)o;
   (void)rows;
   const bool dq_stream = bwd_dq_mode() == 1;
+  // rope_cos / rope_sin (tn_attn_bwd_rope): dq / dk are wanted as gradients of the UN-rotated q / k.  The default D = 128
+  // kernels rotate back in their epilogues; every other combination runs as it is and the row kernel follows (same bits).
+  const bool rope = rope_cos != nullptr;
+  const bool rope_fused = rope && D == 128 && dq_stream && !delta_pass && !(bwd_kv_split() || qv.bidir) && qv.nseg == 1 &&
+                          qv.rpb == T;
+  const bf16_t* rc = rope_fused ? (const bf16_t*)rope_cos : nullptr;
+  const bf16_t* rs = rope_fused ? (const bf16_t*)rope_sin : nullptr;
   auto launch_dq = [&]() {
     if (dq_stream)
-      launch_attn_bwd_dq_stream(Q, K, V, dO, lse2, delta, (bf16_t*)dq, doc, m, qv, B, T, Nh, Nkv, D, scale, sl2, O_, st);
+      launch_attn_bwd_dq_stream(Q, K, V, dO, lse2, delta, (bf16_t*)dq, doc, m, qv, B, T, Nh, Nkv, D, scale, sl2, O_, rc, rs,
+                                st);
     else if (D == 128)
       hipLaunchKernelGGL((attn_bwd_dq_kernel<128>), gq, block, 0, st, Q, K, V, dO, lse2, delta, (bf16_t*)dq, doc, m,
                          qv, T, Nh, Nkv, scale, sl2, O_);
@@ -865,7 +877,7 @@ static int attn_bwd_launch(const void* q, const void* k, const void* v, const vo
                          (bf16_t*)dv, doc, m, qv, T, Nh, Nkv, scale, sl2);
     } else {
       launch_attn_bwd_kv_fused128(Q, K, V, dO, lse2, delta, (bf16_t*)dk, (bf16_t*)dv, doc, m, qv, B, T, Nh, Nkv, scale,
-                                  sl2, st);
+                                  sl2, rc, rs, st);
     }
     if (delta_pass) launch_dq();
   } else {
@@ -879,6 +891,8 @@ static int attn_bwd_launch(const void* q, const void* k, const void* v, const vo
     if (delta_pass) launch_dq();
   }
   TN_LAUNCH_CHECK();
+  if (rope && !rope_fused)
+    return tn_rope_apply(dq, dk, dq, dk, rope_cos, rope_sin, B * T, Nh, Nkv, D, 1, 1 /* bf16 */, stream);
   return TN_OK;
 }
 
@@ -894,6 +908,20 @@ int tn_attn_bwd(const void* q, const void* k, const void* v, const void* o, cons
                 int Nkv, int D, float scale, void* stream) {
   const QView qv = {1, {0, 0}, {T, 0}, {0, 0}, T, 0, ~0ull};
   return attn_bwd_launch(q, k, v, o, dout, lse2, delta, dq, dk, dv, doc, meta, B, T, Nh, Nkv, D, scale, qv, stream);
+}
+
+// tn_attn_bwd for q / k that carry a rotary embedding (the projection's epilogue, tn_gemm_bf16_rope, or tn_rope_apply put it
+// there): dq / dk come back as the gradients of the UN-rotated projections — what tn_attn_bwd followed by
+// tn_rope_apply(dq, dk, backward = 1) returns, bit for bit, without that pass over dq / dk (the reference: the rotary
+// embedding's backward in transformers' apply_rotary_pos_emb under autograd, touchnet/models/llama/parallelize_llama.py's
+// attention; cos_t / sin_t: the bf16 [B * T, D / 2] tables of tn_rope_table).  D = 128 rotates in the kernels' epilogues.
+int tn_attn_bwd_rope(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse2,
+                     float* delta, void* dq, void* dk, void* dv, const int* doc, const int* meta, int B, int T, int Nh,
+                     int Nkv, int D, float scale, const void* cos_t, const void* sin_t, void* stream) {
+  if (cos_t == nullptr || sin_t == nullptr || (((uintptr_t)cos_t | (uintptr_t)sin_t) & 15)) return TN_EINVAL;
+  const QView qv = {1, {0, 0}, {T, 0}, {0, 0}, T, 0, ~0ull};
+  return attn_bwd_launch(q, k, v, o, dout, lse2, delta, dq, dk, dv, doc, meta, B, T, Nh, Nkv, D, scale, qv, stream, cos_t,
+                         sin_t);
 }
 
 // Bidirectional inside a document, see tn_attn_fwd_bidir.

@@ -22,7 +22,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_stream_kernel(
     const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
     const bf16_t* __restrict__ dO, const float* __restrict__ LSE2, float* __restrict__ Delta,
     bf16_t* __restrict__ dQ, const int* __restrict__ doc, AttnMeta meta, QView qv, int T, int Nh, int Nkv,
-    float scale, float scale_log2, const bf16_t* __restrict__ O) {
+    float scale, float scale_log2, const bf16_t* __restrict__ O, const bf16_t* __restrict__ rcos,
+    const bf16_t* __restrict__ rsin) {
   // O != null: this kernel ALSO forms delta = rowsum(dO o O) of its 128 query rows and writes it to `Delta` for the
   // dK / dV pass, which is launched BEHIND it.  O == null: `Delta` is read.
   using namespace fstream;
@@ -412,6 +413,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_stream_kernel(
 
   // ---- epilogue: the dQ rows leave through the free ring slot as whole rows (attn_fwd_stream.hip)
   {
+    constexpr int CPR = D / 8, RPI = 64 / CPR, NI = 32 / RPI;
+    const int cc = lane % CPR, r0 = lane / CPR;
+    // rcos / rsin (tn_attn_bwd_rope, D = 128): the rows leave as the gradient of the UN-rotated q.  The table entries of
+    // this lane's eight chunks are asked for first, all at once, and arrive while the accumulators are staged (fetched
+    // chunk by chunk inside the store loop they cost the dK / dV kernel 50 us of a 476 us launch, one L2 round trip each)
+    const bool rot = D == 128 && rcos != nullptr;
+    u32x4_t c4[NI] = {}, s4[NI] = {};
+    if (rot) {
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const size_t to = ((size_t)b * T + min(wq0 + i * RPI + r0, T - 1)) * (D / 2) + (cc & (CPR / 2 - 1)) * 8;
+        c4[i] = *reinterpret_cast<const u32x4_t*>(rcos + to);
+        s4[i] = *reinterpret_cast<const u32x4_t*>(rsin + to);
+      }
+    }
     char* ob = smem + cur * STAGEB + wave * (32 * OSTR);
 #pragma unroll
     for (int db = 0; db < DBLK; ++db)
@@ -421,13 +437,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_stream_kernel(
                       pack2bf(dqacc[db][4 * r4 + 2] * scale, dqacc[db][4 * r4 + 3] * scale)};
         *reinterpret_cast<u32x2_t*>(ob + l31 * OSTR + (32 * db + 8 * r4 + 4 * hi) * 2) = o2;
       }
-    constexpr int CPR = D / 8, RPI = 64 / CPR;
-    const int cc = lane % CPR, r0 = lane / CPR;
     bf16_t* op = dQ + (((size_t)b * qv.rpb + lq0 + 32 * wave) * Nh + h) * D + cc * 8;
 #pragma unroll
-    for (int i = 0; i < 32 / RPI; ++i) {
+    for (int i = 0; i < NI; ++i) {
       const int row = i * RPI + r0;
-      const u32x4_t v4 = *reinterpret_cast<const u32x4_t*>(ob + row * OSTR + cc * 16);
+      u32x4_t v4 = *reinterpret_cast<const u32x4_t*>(ob + row * OSTR + cc * 16);
+      if (rot) {
+        // tn_rope_apply(backward)'s arithmetic on the staged bf16 values, the other half of the row from the same image:
+        // the bits the row kernel would produce
+        const u32x4_t p4 = *reinterpret_cast<const u32x4_t*>(ob + row * OSTR + (cc ^ (CPR / 2)) * 16);
+        v4 = rope_grad_chunk(v4, p4, c4[i], s4[i], cc >= CPR / 2);
+      }
       if (32 * wave + row < qleft && wq0 + row < T) *reinterpret_cast<u32x4_t*>(op + (size_t)row * Nh * D) = v4;
     }
   }
@@ -435,14 +455,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_stream_kernel(
 
 void launch_attn_bwd_dq_stream(const bf16_t* Q, const bf16_t* K, const bf16_t* V, const bf16_t* dO, const float* lse2,
                                float* delta, bf16_t* dQ, const int* doc, AttnMeta m, QView qv, int B, int T, int Nh,
-                               int Nkv, int D, float scale, float sl2, const bf16_t* O, hipStream_t st) {
+                               int Nkv, int D, float scale, float sl2, const bf16_t* O, const bf16_t* rcos, const bf16_t* rsin,
+                               hipStream_t st) {
   dim3 gq(Nh, qv.tiles(0, 128) + qv.tiles(1, 128), B), block(256);
   if (D == 128)
     hipLaunchKernelGGL((attn_bwd_dq_stream_kernel<128>), gq, block, 0, st, Q, K, V, dO, lse2, delta, dQ, doc, m, qv, T,
-                       Nh, Nkv, scale, sl2, O);
+                       Nh, Nkv, scale, sl2, O, rcos, rsin);
   else
     hipLaunchKernelGGL((attn_bwd_dq_stream_kernel<64>), gq, block, 0, st, Q, K, V, dO, lse2, delta, dQ, doc, m, qv, T,
-                       Nh, Nkv, scale, sl2, O);
+                       Nh, Nkv, scale, sl2, O, nullptr, nullptr);
 }
 
 }  // namespace tn

@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kv_fused_kernel(
     const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
     const bf16_t* __restrict__ dO, const float* __restrict__ LSE2, const float* __restrict__ Delta,
     bf16_t* __restrict__ dK, bf16_t* __restrict__ dV, const int* __restrict__ doc, AttnMeta meta, QView qv, int T,
-    int Nh, int Nkv, float scale, float scale_log2) {
+    int Nh, int Nkv, float scale, float scale_log2, const bf16_t* __restrict__ rcos, const bf16_t* __restrict__ rsin) {
   using namespace fusedkv;
   static_assert(D == 128, "the fused dK/dV pass is built for head_dim 128");
   constexpr int BNK = 128, BQ = 32, NST = 4, SPT = kTile / BQ;
@@ -675,6 +675,20 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kv_fused_kernel(
   // (8-byte runs of the accumulator layout) into private images and reads them back as whole rows — 16-byte stores, four
   // rows per instruction, instead of 8 bytes per lane at a row stride (attn_fwd_stream.hip)
   {
+    constexpr int CPR = D / 8, RPI = 64 / CPR, NI = 32 / RPI;      // 16-byte chunks per row, rows per store instruction
+    const int cc = lane % CPR, r0 = lane / CPR;
+    // rcos / rsin (tn_attn_bwd_rope): dK leaves as the gradient of the UN-rotated k; table entries asked for up front
+    // (attn_bwd_dq_stream.hip's epilogue)
+    const bool rot = rcos != nullptr;
+    u32x4_t c4[NI] = {}, s4[NI] = {};
+    if (rot) {
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const size_t to = ((size_t)b * T + min(wk0 + i * RPI + r0, T - 1)) * (D / 2) + (cc & (CPR / 2 - 1)) * 8;
+        c4[i] = *reinterpret_cast<const u32x4_t*>(rcos + to);
+        s4[i] = *reinterpret_cast<const u32x4_t*>(rsin + to);
+      }
+    }
     char* obv = smem + wave * (2 * 32 * OSTR);
     char* obk = obv + 32 * OSTR;
     static_for<DBLK>([&](auto DB) {
@@ -690,14 +704,16 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kv_fused_kernel(
         *reinterpret_cast<u32x2_t*>(obk + l31 * OSTR + (32 * db + 8 * r4 + 4 * hi) * 2) = o;
       });
     });
-    constexpr int CPR = D / 8, RPI = 64 / CPR;           // 16-byte chunks per row, rows per store instruction
-    const int cc = lane % CPR, r0 = lane / CPR;
     const size_t off = (((size_t)b * T + wk0) * Nkv + hk) * D + cc * 8;
 #pragma unroll
-    for (int i = 0; i < 32 / RPI; ++i) {
+    for (int i = 0; i < NI; ++i) {
       const int row = i * RPI + r0;
       const u32x4_t v4 = *reinterpret_cast<const u32x4_t*>(obv + row * OSTR + cc * 16);
-      const u32x4_t k4 = *reinterpret_cast<const u32x4_t*>(obk + row * OSTR + cc * 16);
+      u32x4_t k4 = *reinterpret_cast<const u32x4_t*>(obk + row * OSTR + cc * 16);
+      if (rot) {
+        const u32x4_t p4 = *reinterpret_cast<const u32x4_t*>(obk + row * OSTR + (cc ^ (CPR / 2)) * 16);
+        k4 = rope_grad_chunk(k4, p4, c4[i], s4[i], cc >= CPR / 2);
+      }
       if (wk0 + row < T) {
         *reinterpret_cast<u32x4_t*>(dV + off + (size_t)row * Nkv * D) = v4;
         *reinterpret_cast<u32x4_t*>(dK + off + (size_t)row * Nkv * D) = k4;
@@ -710,10 +726,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kv_fused_kernel(
 void launch_attn_bwd_kv_fused128(const bf16_t* Q, const bf16_t* K, const bf16_t* V, const bf16_t* dO,
                                  const float* lse2, const float* delta, bf16_t* dK, bf16_t* dV, const int* doc,
                                  AttnMeta m, QView qv, int B, int T, int Nh, int Nkv, float scale, float sl2,
-                                 hipStream_t st) {
+                                 const bf16_t* rcos, const bf16_t* rsin, hipStream_t st) {
   dim3 gk(Nkv, (T + 127) / 128, B), block(256);
   hipLaunchKernelGGL((attn_bwd_kv_fused_kernel<128>), gk, block, 0, st, Q, K, V, dO, lse2, delta, dK, dV, doc, m, qv,
-                     T, Nh, Nkv, scale, sl2);
+                     T, Nh, Nkv, scale, sl2, rcos, rsin);
 }
 
 }  // namespace tn

@@ -339,4 +339,29 @@ struct PStage {
   }
 };
 
+// The TRANSPOSED rotary rotation — what tn_rope_apply(backward = 1) applies to the gradient of a rotated q / k row — of one
+// 16-byte chunk of a gradient row in a backward kernel's epilogue: `own` = the lane's 8 columns, `other` = the same 8
+// columns of the row's other half, c4 / s4 = the 8 table entries of the row (bf16 [rows, D / 2] tables of tn_rope_table),
+// upper = the lane's columns are >= D / 2.  rope_rotate itself on the bf16-rounded values: the bits the row kernel produces.
+__device__ __forceinline__ u32x4_t rope_grad_chunk(u32x4_t own, u32x4_t other, u32x4_t c4, u32x4_t s4, bool upper) {
+  // rope_rotate(a, b, c, -sin): lower half ya = fma(-b, -sin, a c) = fma(other, sin, own c); upper half yb = fma(a, -sin, b c)
+  // = fma(other, -sin, own c) — sign flips of a factor are exact, so ONE form with the table's sign bits flipped for the upper
+  // lanes gives the row kernel's bits at a third of its instructions (an epilogue's VALU time is exposed: 1-2 waves per SIMD)
+  typedef __attribute__((ext_vector_type(2))) float f32x2;
+  const uint32_t flip = upper ? 0x80008000u : 0u;
+  u32x4_t out;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint32_t sj = s4[j] ^ flip;
+    const f32x2 x = {__uint_as_float(own[j] << 16), __uint_as_float(own[j] & 0xffff0000u)};
+    const f32x2 y = {__uint_as_float(other[j] << 16), __uint_as_float(other[j] & 0xffff0000u)};
+    const f32x2 c = {__uint_as_float(c4[j] << 16), __uint_as_float(c4[j] & 0xffff0000u)};
+    const f32x2 sv = {__uint_as_float(sj << 16), __uint_as_float(sj & 0xffff0000u)};
+    const f32x2 t = x * c;
+    const f32x2 r = __builtin_elementwise_fma(y, sv, t);
+    out[j] = pack2bf(r.x, r.y);
+  }
+  return out;
+}
+
 }  // namespace tn

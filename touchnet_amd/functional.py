@@ -109,12 +109,49 @@ def causal_mask(B: int, T: int, device) -> PackedMask:
     return build_packed_mask(torch.ones(B, T, dtype=torch.int32, device=device))
 
 
-def packed_attention(q, k, v, mask: PackedMask, scale: Optional[float] = None):
-    """softmax(scale * Q K^T + doc-causal mask) V with q [B,T,Nh,D], k/v [B,T,Nkv,D] -> [B,T,Nh,D]."""
+# TN_ROPE_GRAD_IN_ATTENTION=0: the rotary embedding's backward as its own pass over dq / dk again (A/B switch; same bits)
+ROPE_GRAD_IN_ATTENTION = os.environ.get("TN_ROPE_GRAD_IN_ATTENTION", "1") != "0"
+
+
+class _AttentionRopeGrad(torch.autograd.Function):
+    """`packed_attention` of q / k that carry a rotary embedding put there by `linear_group(rope=..)`: the backward hands
+    dq / dk over as gradients of the UN-rotated projections (tn_attn_bwd_rope — the transposed rotation in the attention
+    kernels' epilogues instead of a pass over dq / dk), and the projection node is told not to rotate them back again
+    (`linear_group(.., rope_grad_in_attention=True)`; the pair is set up in one place, models/llama Attention.forward)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, doc, meta, scale, cos, sin):
+        o, lse2 = L.attn_fwd(q, k, v, doc, meta, scale)
+        ctx.save_for_backward(_c(q), _c(k), _c(v), o, lse2, doc, meta, cos, sin)
+        ctx.scale = scale
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, o, lse2, doc, meta, cos, sin = ctx.saved_tensors
+        B, T, Nh, D = q.shape
+        Nkv = k.shape[2]
+        stacked = Nh == Nkv
+        out = L.attn_bwd_rope(q, k, v, o, _c(do), lse2, doc, meta, ctx.scale, cos, sin, stacked)
+        if stacked:                                        # (one buffer, three slices: library.attn_bwd_stacked)
+            dq, dk, dv = out.unbind(0)
+        else:
+            dq, dk, dv = out.split([B * T * Nh * D, B * T * Nkv * D, B * T * Nkv * D])
+            dq, dk, dv = dq.view(B, T, Nh, D), dk.view(B, T, Nkv, D), dv.view(B, T, Nkv, D)
+        return dq, dk, dv, None, None, None, None, None
+
+
+def packed_attention(q, k, v, mask: PackedMask, scale: Optional[float] = None, rope_grad=None):
+    """softmax(scale * Q K^T + doc-causal mask) V with q [B,T,Nh,D], k/v [B,T,Nkv,D] -> [B,T,Nh,D].
+    ``rope_grad = (cos, sin)``: q and k are ROTATED outputs of `linear_group(.., rope=(cos, sin, ..),
+    rope_grad_in_attention=True)`; their gradients leave this node already rotated back (`_AttentionRopeGrad`)."""
     if scale is None:
         scale = q.shape[-1] ** -0.5
     if tuple(q.shape[:2]) != (mask.B, mask.T):
         raise _C.KernelError(f"mask built for {(mask.B, mask.T)}, got q {tuple(q.shape[:2])}")
+    if rope_grad is not None:
+        cos, sin = rope_grad
+        return _AttentionRopeGrad.apply(q, k, v, mask.doc, mask.meta, float(scale), _c(cos.detach()), _c(sin.detach()))
     return L.attn_fwd(q, k, v, mask.doc, mask.meta, float(scale))[0]
 
 
@@ -1038,9 +1075,10 @@ class _LinearGroup(torch.autograd.Function):
         M = x2.shape[0]
         dys = [torch.zeros(M, w.shape[0], dtype=x.dtype, device=x.device) if d is None else _c(d).reshape(M, -1)
                for d, w in zip(dys, ws)]
-        if ctx.rope is not None:
+        if ctx.rope is not None and not ctx.rope[4]:
             # the outputs were rotated: their gradients are rotated back (the transposed rotation) before the products
-            cos, sin, D, which = ctx.rope
+            # (rope[4]: the consumer did that already — `_AttentionRopeGrad`)
+            cos, sin, D, which = ctx.rope[:4]
             which = sorted(which)
             for a in range(0, len(which), 2):
                 i, j = which[a], which[a + 1] if a + 1 < len(which) else None
@@ -1135,11 +1173,13 @@ def _norm_src_describes(norm_src, x) -> bool:
             and norm_src[1].shape[-1] == x.shape[-1])
 
 
-def linear_group(x, layers, wgrad: str = "tn", dgrad_tn: bool = True, norm_src=None, rope=None):
+def linear_group(x, layers, wgrad: str = "tn", dgrad_tn: bool = True, norm_src=None, rope=None,
+                 rope_grad_in_attention: bool = False):
     """``layers``: list of (weight [N_i, K], bias [N_i] | None) sharing the input ``x`` -> list of outputs.
     ``norm_src``: see `norm_source`.  ``rope = (cos, sin, head_dim, (i, j, ..))``: outputs i, j, .. ([.., heads * head_dim])
     are returned ROTATED — the rotary embedding `apply_rope` would apply to them, computed in the projection's epilogue
-    (`gemm_rope`); cos / sin as from `rope_tables`, one row per row of x."""
+    (`gemm_rope`); cos / sin as from `rope_tables`, one row per row of x.  ``rope_grad_in_attention``: the rotated outputs
+    go to `packed_attention(.., rope_grad=(cos, sin))` and nowhere else, which returns their gradients rotated back."""
     if wgrad not in ("tn", "nt", "nt_fused"):
         raise ValueError(f"linear_group: wgrad={wgrad!r}")
     if not (x.is_cuda or x.is_meta):
@@ -1149,7 +1189,8 @@ def linear_group(x, layers, wgrad: str = "tn", dgrad_tn: bool = True, norm_src=N
     if not _norm_src_describes(norm_src, x):
         norm_src = None           # (e.g. under tensor-parallel sequence parallelism x is the gathered sequence): keep x itself
     if rope is not None:
-        rope = (rope[0].detach(), rope[1].detach(), int(rope[2]), tuple(int(i) for i in rope[3]))
+        rope = (rope[0].detach(), rope[1].detach(), int(rope[2]), tuple(int(i) for i in rope[3]),
+                bool(rope_grad_in_attention))
     packed = (wgrad, norm_src, rope) if (norm_src is not None or rope is not None) else wgrad
     return list(_LinearGroup.apply(x, len(ws), packed, dgrad_tn, *ws, *bs))
 

@@ -385,6 +385,37 @@ def _(q, k, v, o, do, lse2, doc, meta, scale):
     return q.new_empty(3, B, T, Nh, D)
 
 
+@custom_op(f"{NS}::attn_bwd_rope", mutates_args=(), device_types="cuda")
+def attn_bwd_rope(q: Tensor, k: Tensor, v: Tensor, o: Tensor, do: Tensor, lse2: Tensor, doc: Tensor, meta: Tensor,
+                  scale: float, cos: Tensor, sin: Tensor, stacked: bool) -> Tensor:
+    """attn_bwd for ROTATED q / k whose gradients are wanted for the un-rotated projections (tn_attn_bwd_rope: the rotary
+    embedding's backward in the attention kernels' epilogues; bit-identical to attn_bwd followed by rope_apply(backward)).
+    One buffer: stacked (Nh == Nkv) [3, B, T, Nh, D] = dq, dk, dv; otherwise flat [B * T * (Nh + 2 Nkv) * D] = dq | dk | dv."""
+    do = _c(do)
+    B, T, Nh, D = q.shape
+    Nkv = k.shape[2]
+    if not (cos.dtype == torch.bfloat16 and sin.dtype == torch.bfloat16 and cos.is_contiguous() and sin.is_contiguous()
+            and cos.numel() == B * T * (D // 2) and sin.numel() == cos.numel()):
+        raise _C.KernelError("attn_bwd_rope: cos / sin are the bf16 [B * T, head_dim / 2] tables of rope_tables")
+    if stacked:
+        out = q.new_empty(3, B, T, Nh, D)
+        dq, dk, dv = out[0], out[1], out[2]
+    else:
+        out = q.new_empty(B * T * (Nh + 2 * Nkv) * D)
+        dq, dk, dv = out.split([B * T * Nh * D, B * T * Nkv * D, B * T * Nkv * D])
+    delta = torch.empty_like(lse2)
+    _C.check(_lib().tn_attn_bwd_rope(_p(q), _p(k), _p(v), _p(o), _p(do), _p(lse2), _p(delta), _p(dq), _p(dk), _p(dv),
+                                     _p(doc), _p(meta), B, T, Nh, Nkv, D, float(scale), _p(cos), _p(sin), _cur()),
+             "tn_attn_bwd_rope")
+    return out
+
+
+@attn_bwd_rope.register_fake
+def _(q, k, v, o, do, lse2, doc, meta, scale, cos, sin, stacked):
+    B, T, Nh, D = q.shape
+    return q.new_empty(3, B, T, Nh, D) if stacked else q.new_empty(B * T * (Nh + 2 * k.shape[2]) * D)
+
+
 def _attn_setup(ctx, inputs, output):
     q, k, v, doc, meta, scale = inputs
     o, lse2 = output

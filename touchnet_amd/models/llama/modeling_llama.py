@@ -87,6 +87,12 @@ class Attention(nn.Module):
         kw = {"norm_src": norm_src} if norm_src is not None else {}
         # q and k come back ROTATED: the rotary embedding sits in the epilogue of their projections (functional.gemm_rope;
         # shapes the epilogue does not take are rotated behind the product — same bits)
+        # ... and their gradients come back from the attention node rotated back (functional._AttentionRopeGrad: the
+        # transposed rotation in the attention backward's epilogues) unless the keys travel between ranks first
+        grad_in_attn = (cp is None and getattr(ops(), "ROPE_GRAD_IN_ATTENTION", False) and x.dtype == torch.bfloat16
+                        and cos.dtype == torch.bfloat16)
+        if grad_in_attn:
+            kw["rope_grad_in_attention"] = True
         q, k, v = ops().linear_group(x, [(self.q_proj.weight, self.q_proj.bias), (self.k_proj.weight, self.k_proj.bias),
                                          (self.v_proj.weight, self.v_proj.bias)], rope=(cos, sin, self.head_dim, (0, 1)), **kw)
         q = q.view(B, T, self.num_heads, self.head_dim)
@@ -96,7 +102,7 @@ class Attention(nn.Module):
             a = ops().packed_attention_sharded(q, cp.gather_seq(k), cp.gather_seq(v), mask, cp.seq_shard(),
                                                self.scaling)
         else:
-            a = ops().packed_attention(q, k, v, mask, self.scaling)
+            a = ops().packed_attention(q, k, v, mask, self.scaling, **({"rope_grad": (cos, sin)} if grad_in_attn else {}))
         a = a.view(B, T, self.num_heads * self.head_dim)
         if keep_rows is not None:
             a = a.reshape(B * T, -1).index_select(0, keep_rows)[None]
