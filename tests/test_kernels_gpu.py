@@ -1170,11 +1170,11 @@ def test_gemm_split_k_matches_fp64_reference(mode, M, N, K, monkeypatch):
     summation order, equal to fp64 rounded once."""
     F = _f()
     parts = F.split_k(M, N, K, mode == "wgrad", mode != "fwd")
-    if parts == 1:                                   # tail split: off by default (measured neutral), exercised here
-        monkeypatch.setattr(F, "TAIL_SPLIT", True)
-        parts = F.tail_split(M, N, K, mode == "wgrad", mode != "fwd")
-        assert ((M + 255) // 256) * ((N + 255) // 256) > 256
-    assert parts > 1
+    tail = parts == 1          # many tiles: only the last partial round is split (tn_gemm_bf16_splitk tail_only = 1, direct call)
+    if tail:
+        tiles = ((M + 255) // 256) * ((N + 255) // 256)
+        assert tiles > 256 and tiles % 256
+        parts = 4 if mode == "wgrad" else 2
     g = torch.Generator().manual_seed(M + 3 * N + 7 * K)
     r = lambda *sh: (torch.rand(*sh, generator=g) * 2 - 1).to(torch.bfloat16)
     if mode == "fwd":
@@ -1187,7 +1187,20 @@ def test_gemm_split_k_matches_fp64_reference(mode, M, N, K, monkeypatch):
         a, b = r(K, M), r(K, N)
         ref, ak, bk = a.double().t() @ b.double(), True, True
     a, b = a.to(DEV), b.to(DEV)
-    got = F.gemm([(a, b)], ak, bk)
+
+    def product(bias=None, out=None, accumulate=False):
+        if not tail:
+            return F.gemm([(a, b)], ak, bk, bias=bias, out=out, accumulate=accumulate)
+        from touchnet_amd import _C
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV) if out is None else out
+        ws = torch.empty(parts * (tiles % 256) * 65536, dtype=torch.float32, device=DEV)
+        ptr = lambda t: None if t is None else t.data_ptr()
+        _C.check(_C.lib().tn_gemm_bf16_splitk(ptr(a), ptr(b), a.stride(0), b.stride(0), K, int(ak), int(bk), ptr(out), ptr(bias),
+                                              M, N, out.stride(0), int(accumulate), parts, 1, ptr(ws), ws.numel() * 4,
+                                              torch.cuda.current_stream().cuda_stream), "tn_gemm_bf16_splitk")
+        return out
+
+    got = product()
     tol = dict(atol=float(ref.abs().max()) * 2 ** -8, rtol=2 ** -7)
     _close(got, ref, **tol, what=f"split-k gemm {mode} {M}x{N}x{K} / {parts}")
     monkeypatch.setattr(F, "SPLIT_K", False)
@@ -1197,9 +1210,9 @@ def test_gemm_split_k_matches_fp64_reference(mode, M, N, K, monkeypatch):
     bias = r(N).to(DEV)
     base = r(M, N).to(DEV)
     out = base.clone()
-    F.gemm([(a, b)], ak, bk, bias=bias, out=out, accumulate=True)
+    product(bias=bias, out=out, accumulate=True)
     _close(out, ref + bias.double().cpu() + base.double().cpu(), **tol, what="split-k bias + accumulate")
-    assert torch.equal(F.gemm([(a, b)], ak, bk), got)                      # deterministic
+    assert torch.equal(product(), got)                      # deterministic
 
 
 @pytest.mark.parametrize("mode,M,N,K", [("fwd", 4360, 4104, 128), ("dgrad", 1000, 776, 1088), ("wgrad", 1280, 1280, 30000),

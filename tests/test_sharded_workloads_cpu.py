@@ -911,12 +911,6 @@ def test_split_k_plan_of_the_hand_written_gemm():
     assert F.split_k(1024, 512, 4096, False, False) == 8             # 8 tiles, 64 stages: min(32, 8) parts, even
     assert F.split_k(1024, 512, 4096 + 64 * 3, False, False) == 1    # 67 stages (prime): no even split
     assert F.split_k(1000, 776, 2048, False, True) == 4
-    # tail split: only the last partial round of tiles, when it saves >= 1.5 % of the product
-    assert F.tail_split(11008, 4096, 16384, True, True) == 4         # 688 tiles = 2 rounds + 176: 0.75 of a round instead of 1
-    assert F.tail_split(16384, 11008, 4096, False, False) == 4       # 2752 = 10 rounds + 192
-    assert F.tail_split(16384, 4096, 4096, False, False) == 0        # 1024 tiles: whole rounds
-    assert F.tail_split(30000, 1280, 1280, False, False) == 2        # tower: 590 = 2 rounds + 78; 20 stages: 10 per part
-    assert F.tail_split(1280, 1280, 30000, True, True) == 0          # (fewer tiles than CUs: split_k's business)
 
 
 @pytest.mark.parametrize("n,T,C,O,stride", [(2, 20, 8, 16, 1), (3, 20, 8, 64, 2), (1, 7, 5, 8, 2)])

@@ -545,7 +545,7 @@ def gemm(segs, a_kmaj: bool = False, b_kmaj: bool = False, bias: Optional[torch.
                                               _p(out), _p(bias), _p(addend), addend.stride(0), M, N, out.stride(0), _cur()),
                  "tn_gemm_bf16_addend")
         return out
-    split, tail = 1, 0
+    split = 1
     if bias_grad is not None:
         if not (a_kmaj and b_kmaj and n == 1 and bias is None and out_t is None):
             raise _C.KernelError("gemm: bias_grad exists for the single-segment weight-gradient mode only")
@@ -561,14 +561,11 @@ def gemm(segs, a_kmaj: bool = False, b_kmaj: bool = False, bias: Optional[torch.
         return out
     if n == 1 and out_t is None and SPLIT_K:
         split = split_k(M, N, Ks[0], a_kmaj, b_kmaj)
-        if split == 1 and TAIL_SPLIT:
-            split = tail_split(M, N, Ks[0], a_kmaj, b_kmaj) or 1
-            tail = 1 if split > 1 else 0
     if split > 1:
         tiles = ((M + 255) // 256) * ((N + 255) // 256)
-        ws = torch.empty(split * (tiles % _NUM_CU if tail else tiles) * 65536, dtype=torch.float32, device=a0.device)
+        ws = torch.empty(split * tiles * 65536, dtype=torch.float32, device=a0.device)
         _C.check(_C.lib().tn_gemm_bf16_splitk(_p(a0), _p(b0), a0.stride(0), b0.stride(0), Ks[0], int(a_kmaj), int(b_kmaj),
-                                              _p(out), _p(bias), M, N, out.stride(0), int(accumulate), split, tail,
+                                              _p(out), _p(bias), M, N, out.stride(0), int(accumulate), split, 0,
                                               _p(ws), ws.numel() * 4, _cur()), "tn_gemm_bf16_splitk")
         return out
     import ctypes as C
@@ -720,11 +717,9 @@ MLP_EPILOGUE = os.environ.get("TN_MLP_EPILOGUE", "1") != "0"
 GROUPED_WGRAD = os.environ.get("TN_GROUPED_WGRAD", "1") != "0"
 
 SPLIT_K = os.environ.get("TN_GEMM_SPLITK", "1") != "0"      # (A/B switch)
-# Tail split (only the last partial round of tiles is split): measured NEUTRAL-TO-NEGATIVE on the step (747.9 / 751.9 ms with,
-# 750.6 / 751.5 without, same box, while whole-product split-K alone gave 755.5 -> 740.8): the fp32 round trip of the split
-# tiles through the workspace (S x r x 256 KB written and read back: 180 MB for an MLP weight gradient) and the second
-# launch cost what the better occupancy of the last round saves.  Off by default; kept (tested) for a fix-up inside the kernel.
-TAIL_SPLIT = os.environ.get("TN_GEMM_TAIL_SPLIT", "0") == "1"
+# (Splitting only the LAST PARTIAL ROUND of a many-tile product — tn_gemm_bf16_splitk's tail_only = 1 — was measured
+# neutral-to-negative on the step in round 5 and its switch is gone; the grouped weight gradient's remainder split in
+# tn_gemm_bf16_grouped is the form that paid.  The C entry point keeps the mode, tested by a direct call.)
 _NUM_CU = 256
 
 
@@ -741,27 +736,6 @@ def split_k(M: int, N: int, K: int, a_kmaj: bool, b_kmaj: bool) -> int:
         while s > 1 and stages % s:
             s -= 1
     return max(s, 1)
-
-
-def tail_split(M: int, N: int, K: int, a_kmaj: bool, b_kmaj: bool) -> int:
-    """Parts for the LAST PARTIAL ROUND of tiles only (0 = leave it whole).  One workgroup per CU walks the tiles in rounds of
-    256; a remainder of r tiles costs a whole extra round at r / 256 occupancy (the MLP weight gradients: 688 tiles = 2
-    rounds + 176).  Cut in S parts the remainder takes ceil(r S / 256) / S of a round; taken when that saves >= 1.5 % of
-    the product, with >= 8 stages per part and — contraction-contiguous operands — an even split."""
-    tiles = ((M + 255) // 256) * ((N + 255) // 256)
-    stages = (K + 63) // 64
-    r = tiles % _NUM_CU
-    if tiles <= _NUM_CU or r == 0 or os.environ.get("TN_GEMM_VARIANT"):
-        return 0
-    best, best_cost = 0, 1.0
-    for s in (2, 3, 4, 6, 8):
-        if stages // s < 8 or (not (a_kmaj and b_kmaj) and stages % s):
-            continue
-        cost = -(-r * s // _NUM_CU) / s
-        if cost < best_cost - 1e-9:
-            best, best_cost = s, cost
-    rounds = tiles // _NUM_CU + 1
-    return best if (1.0 - best_cost) / rounds >= 0.015 else 0
 
 
 def gemm_supported(M: int, N: int, Ks, a_kmaj: bool = False, b_kmaj: bool = False) -> bool:
