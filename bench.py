@@ -266,11 +266,13 @@ class Workload:
         return batch
 
 
-def cpu_baseline(workload: "Workload", seconds_budget: float = 20.0):
+def cpu_baseline(workload: "Workload", seconds_budget: float = 20.0, n_params: int = 0):
     """The reference's CPU path timed beside the GPU number: it has no CPU training entry point
     (SURVEY.md §0 fact 5), so this is the ORACLE restatement (oracle/nn.py + oracle/loss.py: eager HF maths +
     reference loss) in fp32 on the host cores — a bounded sample: ONE decoder block forward+backward at the
-    workload's widths on T=256 tokens plus the lm_head+CE on 64 tokens, extrapolated x layers to tokens/s.
+    workload's widths (T = 1024 and 2048) plus the lm_head+CE on 64 tokens, extrapolated x layers to tokens/s; for the
+    Qwen2-Audio workloads also one audio-tower layer on one clip and torch's AdamW on a parameter sample (x layers x clips,
+    x parameters), so that the figure estimates the whole step of config C.
     It is a reported baseline ("port"), never the measured product path."""
     from oracle import loss as oloss
     from oracle import nn as onn
@@ -330,12 +332,56 @@ def cpu_baseline(workload: "Workload", seconds_budget: float = 20.0):
         hs.append((time.perf_counter() - t0) / Th)
     t_head = sorted(hs)[REP // 2]
     per_token = t_block * cfg.num_hidden_layers + t_head
+    extra = "audio tower and optimizer excluded -> an upper bound on CPU throughput"
+    ac = getattr(workload.model_config, "audio_config", None)
+    if (workload.name.startswith("qwen2_audio_7b") and ac is not None and getattr(workload, "wav", None) is not None
+            and n_params > 0):
+        # (round 6) the rest of the step, so that the figure is an estimate of config C and not of its
+        # decoder: ONE Whisper encoder layer forward + backward on one clip's 1500 frames (oracle.nn.whisper_layer: the
+        # reference's patched tower, touchnet/models/qwen2_audio/__init__.py:18-133) x layers x clips, and torch's AdamW
+        # arithmetic (fp32, foreach form) on a 32 M-parameter sample x parameters / sample
+        C, heads, ffn, frames = ac.d_model, ac.encoder_attention_heads, ac.encoder_ffn_dim, 1500
+        tsd = {}
+        for n, (o, i) in {"self_attn.q_proj": (C, C), "self_attn.k_proj": (C, C), "self_attn.v_proj": (C, C),
+                          "self_attn.out_proj": (C, C), "fc1": (ffn, C), "fc2": (C, ffn)}.items():
+            tsd[f"t.{n}.weight"] = (torch.randn(o, i, generator=g) * 0.02).requires_grad_()
+            if n != "self_attn.k_proj":
+                tsd[f"t.{n}.bias"] = torch.zeros(o, requires_grad=True)
+        for n in ("self_attn_layer_norm", "final_layer_norm"):
+            tsd[f"t.{n}.weight"], tsd[f"t.{n}.bias"] = torch.ones(C, requires_grad=True), torch.zeros(C, requires_grad=True)
+        hx = torch.randn(1, frames, C, generator=g).requires_grad_()
+        allow = torch.ones(1, frames, frames, dtype=torch.bool).tril_()
+
+        def tower_layer():
+            onn.whisper_layer(tsd, "t.", hx, heads, allow).sum().backward()
+        tower_layer()
+        tt = []
+        for _ in range(REP):
+            t0 = time.perf_counter()
+            tower_layer()
+            tt.append(time.perf_counter() - t0)
+        t_tower = sorted(tt)[REP // 2] * ac.encoder_layers * int(workload.wav.shape[0])        # s per step
+        n_s = 32 << 20
+        pw = torch.zeros(n_s, requires_grad=True)
+        pw.grad = torch.full((n_s,), 1e-3)
+        opt = torch.optim.AdamW([pw], lr=1e-4, foreach=True)
+        opt.step()
+        to = []
+        for _ in range(REP):
+            t0 = time.perf_counter()
+            opt.step()
+            to.append(time.perf_counter() - t0)
+        t_opt = sorted(to)[REP // 2] * n_params / n_s                                            # s per step
+        tokens = workload.B * workload.T
+        per_token += (t_tower + t_opt) / tokens
+        extra = (f"+ 1 Whisper encoder layer fwd+bwd on 1500 frames x{ac.encoder_layers} layers x{int(workload.wav.shape[0])} clips "
+                 f"({t_tower:.1f} s/step) + torch AdamW on a {n_s >> 20} M-parameter sample x {n_params / 1e9:.2f} G parameters "
+                 f"({t_opt:.1f} s/step); conv stem, projector, log-mel and gradient clipping excluded")
     return {"value": round(1.0 / per_token, 2), "unit": "tokens/s (extrapolated)", "cores": cores, "kind": "port",
             "repeats": REP, "repeat_spread": round(spread, 3),
             "sample": f"oracle fp32 eager, {cores} threads: 1 decoder block fwd+bwd at T={T1} and T={T2}, median of {REP} repeats "
                       f"({t1 * 1e3:.3f} / {t2 * 1e3:.3f} ms per token per layer), per-token cost a + b*T evaluated at the "
-                      f"workload's T={workload.T}, x{cfg.num_hidden_layers} layers, + lm_head/CE on {Th} tokens; audio "
-                      f"tower and optimizer excluded -> an upper bound on CPU throughput"}
+                      f"workload's T={workload.T}, x{cfg.num_hidden_layers} layers, + lm_head/CE on {Th} tokens; " + extra}
 
 
 def executed_flops_per_gpu(wl: "Workload", trainer, layout: dict, lm_head_rows: int) -> float:
@@ -862,7 +908,7 @@ def main():
                 line["roofline"]["traffic_source"] = ("stale: profiles/" + os.path.basename(tfile) + " was taken with other "
                                                       "kernel sources / GEMM mode; re-run scripts/step_traffic.sh")
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(wl)
+            line["cpu_baseline"] = cpu_baseline(wl, n_params=int(trainer.num_params))
         print(json.dumps(line), flush=True)
     if dist.is_initialized():
         dist.barrier()

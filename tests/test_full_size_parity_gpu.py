@@ -3,8 +3,9 @@
 samples from data/synthetic.qwen2_audio_plan, padding slots dropped -> M = 15872 rows, lm_head on the labelled rows) — which no
 other test reaches (the per-kernel tests stop at M = 8200, the 7B-shape cases at M <= 2048).
 
-(i)  two layers, every fusion of the product path on (SwiGLU / RoPE epilogues, grouped MLP weight gradients, bias gradients
-     from the weight-gradient launches, hand-written GEMM, padding slots dropped, last layer on the labelled rows) against
+(i)  two layers, every fusion of the product path on (SwiGLU / RoPE epilogues, the rotary gradient in the attention backward,
+     grouped MLP weight gradients, bias gradients from the weight-gradient launches, hand-written GEMM, padding slots dropped,
+     last layer on the labelled rows) against
      the UNFUSED composition of the same step on hipBLASLt (`LINEAR_GEMM = "lib"`, every switch off, all slots computed):
      loss, gradient norm and sampled weight gradients at bf16 tolerance;
 (ii) one layer's forward against oracle/nn.py in fp32 on the host — the reference's maths
@@ -79,10 +80,10 @@ def test_two_layers_at_headline_size_fused_path_equals_the_unfused_library_path(
              "model.layers.0.mlp.gate_proj.weight", "model.layers.1.self_attn.q_proj.bias", "model.layers.0.input_layernorm.weight"]
     params = dict(m.named_parameters())
     got = {n: params[n].grad.float().clone() for n in names}
-    # the unfused arm: hipBLASLt GEMMs on transposed copies, separate RoPE / SwiGLU / column-sum kernels, one weight gradient
+    # the unfused arm: hipBLASLt GEMMs on transposed copies, separate RoPE (both directions) / SwiGLU / column-sum kernels, one weight gradient
     # per launch, every padding slot and every position through every layer
     for name, val in (("LINEAR_GEMM", "lib"), ("ROPE_EPILOGUE", False), ("MLP_EPILOGUE", False), ("GROUPED_WGRAD", False),
-                      ("BIAS_IN_WGRAD", False), ("_MLP_FUSED", False), ("SPLIT_K", False)):
+                      ("BIAS_IN_WGRAD", False), ("_MLP_FUSED", False), ("SPLIT_K", False), ("ROPE_GRAD_IN_ATTENTION", False)):
         monkeypatch.setattr(F, name, val)
     monkeypatch.setattr(ML, "SKIP_PAD_ROWS", False)
     monkeypatch.setattr(ML, "LAST_LAYER_LABELLED_ROWS", False)
