@@ -116,3 +116,21 @@ def test_round5_gemm_entry_points_refuse_malformed_arguments_before_any_launch()
     assert grouped(ngrp=0) == EINVAL
     assert grouped(ngrp=1000) == EINVAL
     assert grouped(a_kmaj=0) == EINVAL
+
+
+def test_attn_bwd_rope_refuses_missing_or_misaligned_tables_before_any_launch():
+    """tn_attn_bwd_rope (round 6: the rotary embedding's backward inside the attention backward) checks its tables and the head
+    geometry on the host: TN_EINVAL without touching the device.  (Valid calls: tests/test_kernels_gpu.py, bit-identity with
+    tn_attn_bwd + tn_rope_apply.)"""
+    import ctypes as C
+    from touchnet_amd import _C
+    lib = _C.lib()
+    EINVAL = -22
+    raw = (C.c_char * 4096)()
+    p = (C.addressof(raw) + 255) // 256 * 256
+    call = lambda cos, sin, D=128, Nh=4, Nkv=4: lib.tn_attn_bwd_rope(p, p, p, p, p, p, p, p, p, p, p, p, 1, 256, Nh, Nkv, D, 0.1,
+                                                                     cos, sin, None)
+    assert call(None, p) == EINVAL and call(p, None) == EINVAL
+    assert call(p + 2, p) == EINVAL and call(p, p + 8) == EINVAL          # 16-byte loads of the table rows
+    assert call(p, p, D=96) == EINVAL
+    assert call(p, p, Nh=6, Nkv=4) == EINVAL                              # query heads not a multiple of kv heads
