@@ -408,6 +408,63 @@ def test_packed_mask_metadata_matches_predicate(golden):
                 assert hi >= used.max() // 64, (b, kt, hi, used.max())
 
 
+def _meta_cases(golden):
+    """(doc ids [B, T], allow [B, T, T]) pairs: the reference-run mask of docmask.npz, packed batches with padded tails and a
+    ragged T, one long document (lists longer than the stored 64 entries), ids that are not runs in increasing order"""
+    g = golden("docmask.npz")
+    yield torch.tensor(g["big/doc_ids"]), g["big/allow"]
+    for B, T, maxlen, pad, seed in ((2, 1000, 150, 40, 1), (1, 2048, 700, 0, 2), (3, 333, 40, 30, 3), (1, 9000, 9000, 0, 4)):
+        doc = _docs(B, T, seed, maxlen, pad)
+        yield doc, onn.doc_causal_allow(doc).numpy()
+    doc = torch.tensor([[3] * 100 + [1] * 200 + [0] * 10 + [2] * 150 + [1] * 60 + [0] * 20])
+    yield doc, onn.doc_causal_allow(doc).numpy()
+
+
+def test_round6_tile_lists_and_row_statistics_never_drop_an_allowed_pair(golden):
+    """The round-6 metadata of tn_attn_build_meta (csrc/attn_common.h: qstat per 32 rows, klist per 128-row query tile, qlist
+    per 128-row KV tile — what the stream kernels and the dK / dV passes read instead of deriving it): the statistics are
+    EXACT, the lists are sorted, duplicate-free, carry the tiles' own statistics, and contain every tile that holds an
+    allowed (q, kv) pair of the reference's predicate (a list longer than the 64 stored entries says so by its count: the
+    kernels then build it themselves)."""
+    F = _f()
+    K = 64                                                              # kListPre
+    for doc, allow in _meta_cases(golden):
+        B, T = doc.shape
+        nt, nq32, nq128 = (T + 63) // 64, (T + 31) // 32, (T + 127) // 128
+        meta = F.build_packed_mask(doc.to(DEV)).meta.cpu().numpy()
+        tile = meta[:5 * B * nt].reshape(5, B, nt)                      # tmin, tmax, tminpos, q_lo, kv_hi
+        o = 5 * B * nt
+        qstat = meta[o:o + 4 * B * nq32].reshape(B, nq32, 4)
+        o += 4 * B * nq32
+        rec = 4 + 4 * K
+        klist = meta[o:o + rec * B * nq128].reshape(B, nq128, 1 + K, 4)
+        qlist = meta[o + rec * B * nq128:o + 2 * rec * B * nq128].reshape(B, nq128, 1 + K, 4)
+        d = doc.numpy()
+        for b in range(B):
+            for w in range(nq32):
+                rows = d[b, 32 * w:32 * w + 32]
+                pos = rows[rows > 0]
+                want = (int(pos.min()) if pos.size else 0x7fffffff, int(rows.max()) if rows.size else 0,
+                        int((rows == 0).any() or rows.size < 32))
+                assert tuple(int(v) for v in qstat[b, w, :3]) == want, (b, w, qstat[b, w], want)
+            for lists, q_side in ((klist, True), (qlist, False)):
+                for t128 in range(nq128):
+                    count, own = int(lists[b, t128, 0, 0]), int(lists[b, t128, 0, 1])
+                    assert own == t128
+                    blk = allow[b, 128 * t128:128 * t128 + 128] if q_side else allow[b, :, 128 * t128:128 * t128 + 128]
+                    used = blk.any(0) if q_side else blk.any(1)                       # positions on the other side
+                    need = sorted({int(p) // 64 for p in np.nonzero(used)[0]})
+                    if count > K:                                                     # overflow: the kernels rebuild the list
+                        assert len(need) <= count
+                        continue
+                    ent = lists[b, t128, 1:1 + count]
+                    got = [int(v) for v in ent[:, 0]]
+                    assert got == sorted(set(got)), (b, t128, got)
+                    assert set(need) <= set(got), (b, t128, q_side, need, got)
+                    for j, mn, mx, mp in ent:                                         # each entry carries its tile's statistics
+                        assert (mn, mx, mp) == tuple(tile[:3, b, j]), (b, t128, j)
+
+
 def test_frontend_stack(golden):
     F = _f()
     g = golden("audiofeat_stack.npz")
