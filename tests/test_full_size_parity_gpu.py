@@ -66,7 +66,7 @@ def _step(m, tok, fused):
     out.loss.backward()
     torch.cuda.synchronize()
     gn = torch.sqrt(sum((p.grad.float() ** 2).sum() for p in m.parameters() if p.grad is not None))
-    return float(out.loss), float(gn)
+    return float(out.loss.detach()), float(gn)
 
 
 def test_two_layers_at_headline_size_fused_path_equals_the_unfused_library_path(monkeypatch):
