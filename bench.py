@@ -733,6 +733,7 @@ def main():
     nonpad = int((wl.tokens["attention_mask"] > 0).sum()) if hasattr(wl, "tokens") else None
     lrm = None if args.all_rows_lm_head else wl.make_batch().get("labelled_rows_max")     # what the packer told the model
     loss = float(stats["loss_per_sample"])
+    loss_job = loss
     # what the job really ran on: read from the LIVE process group, with a one-element all-reduce over every rank (a
     # SCALE line can then be checked without trusting the command line: backend nccl == RCCL on ROCm, N ranks answered)
     dist_info = {"initialized": bool(dist.is_available() and dist.is_initialized())}
@@ -742,6 +743,12 @@ def main():
         dist_info.update(backend=str(dist.get_backend()), world_size=int(dist.get_world_size()),
                          ranks_answering_all_reduce=int(round(float(ones))),
                          devices_visible=int(torch.cuda.device_count()))
+        # rank 0's loss is ITS share (the per-sentence normalisation counts the sentences of all data- and context-parallel
+        # ranks, touchnet/loss/cross_entropy.py:12-50 under train.py's all-reduced num_sentence); the job's loss — what one
+        # GPU would print on the joined batch — is the sum over those ranks (tensor-parallel peers hold the same value)
+        lsum = torch.tensor([loss], dtype=torch.float64, device=device).float()
+        dist.all_reduce(lsum)
+        loss_job = float(lsum) / (1 if emu else max(int(layout["tp"]), 1))
     try:
         v = torch.cuda.nccl.version()
         dist_info["rccl_version"] = ".".join(str(x) for x in v) if isinstance(v, tuple) else str(v)
@@ -798,7 +805,7 @@ def main():
             "nonpad_tokens_per_s": (round(nonpad * layout["dp"] / (share if emu else 1) * args.steps / elapsed, 1)
                                     if nonpad is not None else None),
             "dist": dist_info,
-            "loss_per_sample_last": round(loss, 5), "hip_event_ms_per_step_rank0": round(ev_ms, 2),
+            "loss_per_sample_last": round(loss, 5), "loss_per_sample_job": round(loss_job, 5), "hip_event_ms_per_step_rank0": round(ev_ms, 2),
             "peak_mem_GB_rank0": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
             **({"emulated_state_shards": args.emulate_shards} if args.emulate_shards > 1 else {}),
             "roofline": {"bound": "mfma", "achieved": round(fpt * (tps / gpus_in_job) / 1e12, 1), "peak": MFMA_PEAK / 1e12,

@@ -33,12 +33,29 @@ def _launch(extra, n=2, backend="gloo"):
     return json.loads(lines[0])
 
 
+_ONE = {}
+
+
+def _one_gpu_loss_cached():
+    if "loss" not in _ONE:
+        _ONE["loss"] = _one_gpu_loss()
+    return _ONE["loss"]
+
+
 @pytest.mark.parametrize("extra,label", [([], "dp2"), (["--dp-engine", "fsdp2"], None), (["--cp", "2"], "cp2"),
                                          (["--tp", "2"], "tp2")])
 def test_bench_two_ranks_on_one_gpu(extra, label):
     if extra == ["--dp-engine", "fsdp2"]:
         pytest.skip("FSDP2's DTensor mesh must be a cuda mesh (RCCL): not runnable with two ranks on one GPU")
     line = _launch(extra)
+    # context- and tensor-parallel ranks work on ONE batch — the one-GPU run's: the JOB's loss (`loss_per_sample_job`: rank
+    # 0's share summed over the data- / context-parallel ranks) is the one-GPU loss, bf16 summation order apart; rank 0's own
+    # line entry is its share (half the sequence under cp 2)
+    if label in ("cp2", "tp2"):
+        one = _one_gpu_loss_cached()
+        assert abs(line["loss_per_sample_job"] - one) / abs(one) < 2e-2, (label, line["loss_per_sample_job"], one)
+    if label == "cp2":
+        assert line["loss_per_sample_last"] < 0.75 * line["loss_per_sample_job"]
     assert line["n_gpus"] == 2 and line["steps"] == 2 and line["warmup"] == 1 and line["scaling"] == "weak"
     assert line["value"] > 0 and line["ms_per_step"] > 0 and line["loss_per_sample_last"] == line["loss_per_sample_last"]
     if label is not None:
@@ -84,7 +101,7 @@ def test_bench_two_ranks_over_rccl_on_two_gpus():
         d = line["dist"]
         assert d["backend"] == "nccl" and d["world_size"] == 2 and d["ranks_answering_all_reduce"] == 2, d
         assert d["devices_visible"] >= 2 and d["rccl_version"], d
-        got[" ".join(extra) or "flat"] = line["loss_per_sample_last"]
+        got[" ".join(extra) or "flat"] = line["loss_per_sample_job"]
     for k in ("--cp 2", "--tp 2"):
         assert abs(got[k] - one) / abs(one) < 2e-2, (k, got, one)
     assert abs(got["flat"] - got["--dp-engine fsdp2"]) / abs(got["flat"]) < 2e-2, got
