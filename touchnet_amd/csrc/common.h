@@ -42,28 +42,41 @@ __device__ __forceinline__ float sigmoid_fast(float x) { return __builtin_amdgcn
 // erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7: three orders below bf16 resolution): 1 - erf(z) = t (a1 + t (a2 + t
 // (a3 + t (a4 + t a5)))) e^{-z^2}, t = 1 / (1 + p z) — ~15 VALU instructions with two transcendentals instead of libm's
 // erff (~40 with branches: too slow beside MFMAs, profiles/r05*), and e^{-z^2} = e^{-x^2 / 2} is the density's exponential too.
-__device__ __forceinline__ void gelu_parts(float x, float& cdf, float& e) {
-  const float z = fabsf(x) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.f));
-  float poly = __builtin_fmaf(t, 1.061405429f, -1.453152027f);
-  poly = __builtin_fmaf(t, poly, 1.421413741f);
-  poly = __builtin_fmaf(t, poly, -0.284496736f);
-  poly = __builtin_fmaf(t, poly, 0.254829592f);
-  e = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f);          // e^{-x^2 / 2}
-  const float q = 0.5f * (poly * t) * e;                                  // (1 - erf(z)) / 2
-  cdf = x >= 0.f ? 1.f - q : q;
+// ONE implementation, on PAIRS (v_pk_mul_f32 / v_pk_fma_f32: two IEEE operations per instruction — an epilogue's VALU time is
+// exposed, profiles/r06h_*): the scalar forms below run it on (x, 0).  Every product / sum is written out and contraction is off
+// inside, so that every caller — row kernel or GEMM epilogue, whatever is inlined around it — gets the same bits.
+typedef __attribute__((ext_vector_type(2))) float gelu_f32x2;
+__device__ __forceinline__ void gelu_parts2(gelu_f32x2 x, gelu_f32x2& cdf, gelu_f32x2& e) {
+#pragma clang fp contract(off)
+  const gelu_f32x2 ax = {fabsf(x.x), fabsf(x.y)};
+  const gelu_f32x2 z = ax * 0.70710678118654752440f;
+  const gelu_f32x2 den = __builtin_elementwise_fma(gelu_f32x2{0.3275911f, 0.3275911f}, z, gelu_f32x2{1.f, 1.f});
+  const gelu_f32x2 t = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+  gelu_f32x2 poly = __builtin_elementwise_fma(t, gelu_f32x2{1.061405429f, 1.061405429f}, gelu_f32x2{-1.453152027f, -1.453152027f});
+  poly = __builtin_elementwise_fma(t, poly, gelu_f32x2{1.421413741f, 1.421413741f});
+  poly = __builtin_elementwise_fma(t, poly, gelu_f32x2{-0.284496736f, -0.284496736f});
+  poly = __builtin_elementwise_fma(t, poly, gelu_f32x2{0.254829592f, 0.254829592f});
+  const gelu_f32x2 arg = (x * x) * -0.72134752044448170368f;                // e^{-x^2 / 2} = 2^arg
+  e = gelu_f32x2{__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};
+  const gelu_f32x2 q = ((poly * t) * 0.5f) * e;                             // (1 - erf(z)) / 2
+  const gelu_f32x2 omq = gelu_f32x2{1.f, 1.f} - q;
+  cdf = gelu_f32x2{x.x >= 0.f ? omq.x : q.x, x.y >= 0.f ? omq.y : q.y};
 }
-__device__ __forceinline__ float gelu_f(float x) {
-  float cdf, e;
-  gelu_parts(x, cdf, e);
+__device__ __forceinline__ gelu_f32x2 gelu_f2(gelu_f32x2 x) {
+#pragma clang fp contract(off)
+  gelu_f32x2 cdf, e;
+  gelu_parts2(x, cdf, e);
   return x * cdf;
 }
 // d gelu(x) / dx * dy = (cdf + x pdf) dy,  pdf = e^{-x^2 / 2} / sqrt(2 pi)
-__device__ __forceinline__ float gelu_grad_f(float x, float dy) {
-  float cdf, e;
-  gelu_parts(x, cdf, e);
-  return dy * __builtin_fmaf(x * 0.39894228040143267794f, e, cdf);
+__device__ __forceinline__ gelu_f32x2 gelu_grad_f2(gelu_f32x2 x, gelu_f32x2 dy) {
+#pragma clang fp contract(off)
+  gelu_f32x2 cdf, e;
+  gelu_parts2(x, cdf, e);
+  return dy * __builtin_elementwise_fma(x * 0.39894228040143267794f, e, cdf);
 }
+__device__ __forceinline__ float gelu_f(float x) { return gelu_f2(gelu_f32x2{x, 0.f}).x; }
+__device__ __forceinline__ float gelu_grad_f(float x, float dy) { return gelu_grad_f2(gelu_f32x2{x, 0.f}, gelu_f32x2{dy, 0.f}).x; }
 
 // RoPE rotation of one (x[i], x[i + D/2]) pair by (cos, sin) — ONE definition (explicit fma order) for the row kernel
 // (norm_act.hip rope_apply_kernel) and the GEMM's RoPE epilogue (gemm.hip EPI_ROPE), which must agree bit for bit

@@ -1713,6 +1713,17 @@ struct Kernel16 {
     const bool acc_c = p.accumulate != 0 || p.addend != nullptr;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
+      // GELU backward: the pre-activation rows this lane will meet in the read-out loop, asked for before the tile is parked
+      // (fetched row by row inside that loop every load's latency was exposed: one workgroup per CU, attn_bwd_dq_stream.hip)
+      uint4 xpre[8];
+      if constexpr (EPI == EPI_GELU_BWD) {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          const int m = wm0 + half * 64 + it * 8 + (lane >> 3), n = wn0 + (lane & 7) * 8;
+          xpre[it] = (m < p.M && n < p.N) ? *reinterpret_cast<const uint4*>(p.E1 + (long long)m * p.lde + n)
+                                          : make_uint4(0, 0, 0, 0);
+        }
+      }
 #pragma unroll
       for (int bi = 0; bi < 4; ++bi) {
         const int row = bi * 16 + l15;
@@ -1727,7 +1738,8 @@ struct Kernel16 {
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll 4
+      constexpr int kReadOutUnroll = EPI == EPI_GELU_BWD ? 8 : 4;       // (xpre[it] must be a register, not an indexed array)
+#pragma unroll kReadOutUnroll
       for (int it = 0; it < 8; ++it) {
         const int row = it * 8 + (lane >> 3), c = lane & 7;
         const u32x4_t pv = *reinterpret_cast<const u32x4_t*>(park + row * 128 + ((c ^ (row & 7)) << 4));
@@ -1743,7 +1755,11 @@ struct Kernel16 {
             float f[8];
             x.unpack(f);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) f[e] = gelu_f(f[e]);
+            for (int e = 0; e < 8; e += 2) {
+              const gelu_f32x2 r = gelu_f2(gelu_f32x2{f[e], f[e + 1]});
+              f[e] = r.x;
+              f[e + 1] = r.y;
+            }
             x.pack(f);
             *reinterpret_cast<uint4*>(p.C2 + (long long)m * p.ldc + n) = x.raw;
             continue;
@@ -1751,13 +1767,17 @@ struct Kernel16 {
           if constexpr (EPI == EPI_GELU_BWD) {
             // v = the rounded d(act): times gelu'(pre), what the GELU backward kernel made of the two
             Vec16<bf16_t> x, d;
-            x.load(p.E1 + (long long)m * p.lde + n);
+            x.raw = xpre[it];
             d.raw = v;
             float f[8], df[8];
             x.unpack(f);
             d.unpack(df);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) df[e] = gelu_grad_f(f[e], df[e]);
+            for (int e = 0; e < 8; e += 2) {
+              const gelu_f32x2 r = gelu_grad_f2(gelu_f32x2{f[e], f[e + 1]}, gelu_f32x2{df[e], df[e + 1]});
+              df[e] = r.x;
+              df[e + 1] = r.y;
+            }
             d.pack(df);
             *reinterpret_cast<uint4*>(dst) = d.raw;
             continue;

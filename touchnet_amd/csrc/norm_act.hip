@@ -566,7 +566,11 @@ __global__ __launch_bounds__(256) void gelu_fwd_kernel(const T* __restrict__ x, 
     a.load(x + v * N);
     a.unpack(f);
 #pragma unroll
-    for (int j = 0; j < N; ++j) f[j] = gelu_f(f[j]);
+    for (int j = 0; j < N; j += 2) {
+      const gelu_f32x2 r = gelu_f2(gelu_f32x2{f[j], f[j + 1]});
+      f[j] = r.x;
+      f[j + 1] = r.y;
+    }
     a.pack(f);
     a.store(out + v * N);
   }
@@ -584,7 +588,11 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const T* __restrict__ dou
     a.unpack(f);
     d.unpack(df);
 #pragma unroll
-    for (int j = 0; j < N; ++j) df[j] = gelu_grad_f(f[j], df[j]);
+    for (int j = 0; j < N; j += 2) {
+      const gelu_f32x2 r = gelu_grad_f2(gelu_f32x2{f[j], f[j + 1]}, gelu_f32x2{df[j], df[j + 1]});
+      df[j] = r.x;
+      df[j + 1] = r.y;
+    }
     d.pack(df);
     d.store(dx + v * N);
   }
